@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the fused random-policy rollout on 65 536 parallel
+MountainCarContinuous envs per GPU (BASELINE.json metric; config[1] at N=1, config[4] sharding
+for N>1).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one ssc_rollout launch: every env of the rank advances CHUNK (=1024) env-steps
+and the whole transition log (25 B per env-step, SoA [K][n]) is written to HBM.  Inputs
+(env state) are resident in HBM before the timed region.  With --gpus N each rank owns
+65 536 envs of one global id space (weak scaling) and, after every chunk, takes part in the
+bounded RCCL transition gather + 4-scalar stats all-reduce described in DESIGN.md.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_ENVS_PER_GPU = 65536
+CHUNK = 1024
+BYTES_PER_STEP = 25           # s[2] a r t(u8) s2[2]
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+GATHER_RECORDS = 1 << 20      # bounded gather: last G steps with G * N_total <= 2^20 records
+
+
+def cpu_baseline(budget_s=24.0):
+    """The CPU oracle timed on this box's host cores on a bounded sample of the same workload
+    (kind "port": the reference's Python/TF cannot travel)."""
+    import ctypes
+    import subprocess
+
+    import numpy as np
+
+    from oracle import ssc_oracle as O
+
+    out = {}
+    # (1) numpy-vectorised fp64 oracle, 65 536 envs, random policy with the engine RNG, 1 core
+    n = N_ENVS_PER_GPU
+    ids = np.arange(n, dtype=np.uint64)
+    pos, vel = O.mc_reset_state(1234, ids, O.RESET_T0)
+    pos, vel = pos.astype(np.float64), vel.astype(np.float64)
+    el = np.zeros(n, np.int64)
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < budget_s / 3:
+        a = O.random_policy_actions(1234, ids, k).astype(np.float64)
+        pos, vel, r, d = O.mc_step(pos, vel, a)
+        el += 1
+        d = O.time_limit(d, el, 999)
+        if d.any():
+            rp, _ = O.mc_reset_state(1234, ids, k)
+            pos = np.where(d, rp, pos)
+            vel = np.where(d, 0.0, vel)
+            el = np.where(d, 0, el)
+        k += 1
+    dt = time.perf_counter() - t0
+    out["value"] = n * k / dt
+    out["sample"] = f"numpy fp64 oracle, {n} envs x {k} steps (random policy, engine RNG), {dt:.1f} s"
+    # (2) the reference's execution model: one env, scalar Python loop (rlTrain.py:63-114)
+    env = O.ScalarMountainCar(1.0, 999, seed=1234)
+    rng = np.random.RandomState(1234)
+    t0 = time.perf_counter()
+    total = 0
+    while time.perf_counter() - t0 < budget_s / 3:
+        _, steps = O.rl_train_scalar(env, lambda obs: rng.uniform(-1.0, 1.0, (1,)), num_episodes=3, max_steps=1000)
+        total += steps
+    out["scalar_python_steps_per_s"] = total / (time.perf_counter() - t0)
+    # (3) C scalar restatement, same RNG, 1 core
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libssc_oracle.so"))
+        lib.ssc_oracle_mc_rollout_random.restype = ctypes.c_int64
+        nn, K = 4096, 256
+        p, v = O.mc_reset_state(1234, np.arange(nn, dtype=np.uint64), O.RESET_T0)
+        p, v = p.astype(np.float64), v.astype(np.float64)
+        st = np.zeros(nn, np.int32)
+        dp = ctypes.POINTER(ctypes.c_double)
+        t0 = time.perf_counter()
+        done_steps, step0 = 0, 0
+        while time.perf_counter() - t0 < budget_s / 3:
+            done_steps += lib.ssc_oracle_mc_rollout_random(
+                ctypes.c_int64(nn), ctypes.c_int32(K), p.ctypes.data_as(dp), v.ctypes.data_as(dp),
+                st.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.c_double(0.0015), ctypes.c_int32(999),
+                ctypes.c_uint64(1234), ctypes.c_uint64(0), ctypes.c_uint64(step0), None)
+            step0 += K
+        out["c_scalar_steps_per_s"] = done_steps / (time.perf_counter() - t0)
+    except Exception as e:  # the C half is optional for the baseline
+        out["c_scalar_steps_per_s"] = None
+        out["c_scalar_error"] = str(e)
+    out.update(unit="env-steps/s", cores=1, kind="port")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--envs-per-gpu", type=int, default=N_ENVS_PER_GPU)
+    ap.add_argument("--chunk", type=int, default=CHUNK)
+    ap.add_argument("--gather", choices=["bounded", "full", "none"], default="bounded")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=24.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from smartstartcontinuous_amd import RandomPolicy, TransitionChunk, VecEnv
+    from smartstartcontinuous_amd.sharding import TransitionGather
+
+    n, K = args.envs_per_gpu, args.chunk
+    env = VecEnv("MountainCarContinuous-v0", n, device=dev, seed=1234, env_id0=rank * n)
+    env.reset()
+    chunks = [TransitionChunk(env.obs_dim, K, n, dev) for _ in range(2)]   # double buffer
+    pd = env.policy_desc(RandomPolicy())
+    gather = None
+    if world > 1 and args.gather != "none":
+        g_steps = K if args.gather == "full" else max(1, min(K, GATHER_RECORDS // (n * world)))
+        gather = TransitionGather(env.obs_dim, g_steps, n, world, rank, dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(i, events=None):
+        chunk = chunks[i & 1]
+        if gather is not None:
+            gather.wait_buffer_free(i & 1)       # the side stream finished reading this buffer
+        if events is not None:
+            events[0].record()
+        env.rollout(K, out=chunk, policy_desc=pd)
+        if events is not None:
+            events[1].record()
+        if gather is not None:
+            gather.submit(chunk, i & 1, env.stats)
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i, evs[i])
+    if gather is not None:
+        gather.finish()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, args.steps)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+        kernel_ms = float(kms.item())
+
+    if rank == 0:
+        total_env_steps = float(n) * K * args.steps * world
+        value = total_env_steps / elapsed
+        per_launch_bytes = float(n) * K * BYTES_PER_STEP
+        achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9
+        result = {
+            "metric": "env-steps/sec (whole node), 65 536 parallel MountainCarContinuous envs",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("MountainCarContinuous-v0, %d batched envs per MI355X, random-policy fused rollout, "
+                             "%d env-steps per launch, full transition log to HBM" % (n, K)),
+                "envs_per_gpu": n, "chunk_steps": K, "global_envs": n * world,
+                "parallelism": "env-sharded x%d" % world,
+                "gather": (args.gather if world > 1 else "none"),
+                "gather_steps_per_chunk": (gather.g_steps if gather is not None else 0),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "ssc::rollout_kernel<McEnv, RandomPolicy<2>>",
+                "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/* ssc.h -- C ABI of libssc.so, the MI355X (gfx950) rollout engine behind the
+ * gym.Env / RLAgent surface of darren-huang/SmartStartContinuous.
+ *
+ * The reference is pure Python (no FFI of its own); each entry point below names the
+ * reference interface it replaces (file:line relative to the reference root).  The
+ * Python host layer (smartstartcontinuous_amd/_ffi.py) binds exactly these symbols with
+ * ctypes; INTEGRATION.md shows the stubs a reference maintainer would add.
+ *
+ * Conventions
+ *   - Every pointer named d_* / inside the descriptor structs marked "device" is a DEVICE
+ *     pointer owned by the caller (a PyTorch-ROCm tensor's data_ptr()).  The library
+ *     allocates nothing on the device and keeps no state between calls; all RNG is
+ *     counter-based (Philox4x32-10 keyed by seed / global env id / global step).
+ *   - All work is enqueued on the given hipStream_t (passed as void*); no call
+ *     synchronises, none uses the default stream implicitly.
+ *   - Return 0 (SSC_OK) or a negative SSC_E* code; ssc_last_error() returns a
+ *     thread-local message.  Nothing throws across the ABI, nothing exits.
+ *   - Arrays are structure-of-arrays, fp32 unless stated; "[K][n]" means K rows of n
+ *     contiguous elements.
+ */
+#ifndef SSC_H
+#define SSC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSC_VERSION 100 /* 0.1.0 */
+
+typedef void *ssc_stream_t; /* hipStream_t */
+
+enum {
+    SSC_OK = 0,
+    SSC_EINVAL = -1,       /* bad argument (null pointer, negative size, ...) */
+    SSC_EUNSUPPORTED = -2, /* shape / option outside what the kernels implement */
+    SSC_EHIP = -3          /* a HIP runtime call failed; see ssc_last_error() */
+};
+
+enum { SSC_ENV_MOUNTAINCAR = 0, SSC_ENV_PENDULUM = 1 };
+enum { SSC_POLICY_RANDOM = 0, SSC_POLICY_ACTOR = 1 };
+enum { SSC_PREC_F32 = 0, SSC_PREC_BF16_MFMA = 1 };
+
+#define SSC_MAX_OBS 3
+#define SSC_MAX_LAYERS 4
+#define SSC_MAX_STATE 8
+#define SSC_MAX_ACT 4
+
+/* Environment constants.
+ * MountainCar: Continuous_MountainCarEnv_Editted.__init__
+ *   (smartstart/environments/continuous_mountain_car_editted.py:35-54) + the gym TimeLimit
+ *   of make_timed_env (:154-159).
+ * Pendulum: gym 0.10.5 PendulumEnv.__init__ [third-party, pinned in Pipfile.lock]. */
+typedef struct ssc_env_params {
+    int32_t kind;              /* SSC_ENV_* */
+    int32_t max_episode_steps; /* TimeLimit; <= 0 means no limit */
+    /* MountainCar */
+    float min_action, max_action;
+    float min_position, max_position;
+    float max_speed, goal_position, power;
+    float reset_low, reset_high; /* reset(): pos ~ U(reset_low, reset_high), vel = 0 (:84-86) */
+    /* Pendulum */
+    float max_torque, pend_max_speed, dt, g, m, l;
+    int32_t pend_v1_order; /* 0: gym 0.10.5 "v0" update order, 1: modern "v1" order */
+} ssc_env_params;
+
+/* DDPG actor (Actor_Editted.__call__, DDPG_Baselines_editted/models_editted.py:38-61).
+ * Weights are fp32 device arrays in TensorFlow layout W[in][out]. */
+typedef struct ssc_actor_desc {
+    int32_t obs_dim, h1, h2, act_dim;
+    const float *W1, *b1, *W2, *b2, *W3, *b3; /* device */
+    int32_t last_layer_tanh;                  /* models_editted.py:53-56 */
+    int32_t precision;                        /* SSC_PREC_*: hidden GEMM in fp32 VALU or bf16 MFMA */
+} ssc_actor_desc;
+
+/* Exploration noise of DDPG_editted.pi (ddpg_editted.py:266-271):
+ * DecayingOrnsteinUhlenbeckActionNoise (smartstart/RLAgents/DDPG_Baselines_agent.py:52-78). */
+typedef struct ssc_ou_desc {
+    float mu, sigma, theta, dt;
+    float epsilon; /* current epsilon (decayed per episode by the host, :77-78); 0 disables noise */
+} ssc_ou_desc;
+
+typedef struct ssc_policy_desc {
+    int32_t kind;             /* SSC_POLICY_* */
+    float act_low, act_high;  /* action_space bounds (Policy_Random, policy_random.py:9-15;
+                                 DDPG_Baselines_agent.scale, DDPG_Baselines_agent.py:236-240) */
+    ssc_actor_desc actor;     /* SSC_POLICY_ACTOR */
+    ssc_ou_desc ou;           /* SSC_POLICY_ACTOR */
+} ssc_policy_desc;
+
+/* Per-env persistent state, each [n] (device).  s0/s1 = (position, velocity) for
+ * MountainCar, (theta, theta_dot) for Pendulum. */
+typedef struct ssc_rollout_state {
+    float *s0, *s1;
+    int32_t *steps; /* TimeLimit's elapsed-step counter of the running episode */
+    float *ep_ret;  /* running episode return (Episode.total_reward, datacontainers.py:41-49) */
+    float *ou_x;    /* OU-noise state x_prev; may be NULL for SSC_POLICY_RANDOM */
+} ssc_rollout_state;
+
+/* Transition log of one rollout chunk: the record ReplayBuffer.add stores
+ * (smartstart/RLAgents/replay_buffer.py:49-74, tuple (s, a, r, t, s2) :53), as SoA
+ * columns of [K][n].  obs/obs2 hold obs_dim columns (2 for MountainCar, 3 for Pendulum);
+ * unused entries may be NULL. */
+typedef struct ssc_transition_log {
+    float *obs[SSC_MAX_OBS];
+    float *act;
+    float *rew;
+    uint8_t *done;
+    float *obs2[SSC_MAX_OBS];
+} ssc_transition_log;
+
+/* Completed-episode records: what Summary.append keeps per episode
+ * (smartstart/utilities/datacontainers.py:173-193: (len(episode), total_reward)). */
+typedef struct ssc_episode_ring {
+    int64_t *env_id;  /* [capacity] global env id */
+    int32_t *length;  /* [capacity] */
+    float *ret;       /* [capacity] */
+    uint32_t *cursor; /* [1] device counter; records beyond capacity are dropped but counted */
+    int32_t capacity;
+} ssc_episode_ring;
+
+int ssc_version(void);
+const char *ssc_last_error(void);
+
+/* Fill *p with the reference defaults.  kind = SSC_ENV_MOUNTAINCAR: power = 0.0015 *
+ * power_scalar (continuous_mountain_car_editted.py:43). */
+int ssc_env_params_default(int kind, float power_scalar, int32_t max_episode_steps, ssc_env_params *p);
+
+/* One env.step for n envs -- Continuous_MountainCarEnv_Editted.step
+ * (continuous_mountain_car_editted.py:60-82) wrapped by gym TimeLimit.step when d_steps is
+ * given (d_steps[i] += 1; done |= d_steps[i] >= max_episode_steps).  pos/vel are updated
+ * in place.  d_steps may be NULL (bare env, no time limit). */
+int ssc_mc_step(const ssc_env_params *p, int64_t n, float *d_pos, float *d_vel, const float *d_act,
+                float *d_rew, uint8_t *d_done, int32_t *d_steps, ssc_stream_t stream);
+
+/* gym 0.10.5 PendulumEnv.step for n envs [third-party]; d_obs is [3][n] =
+ * (cos th, sin th, thdot) of the NEW state, may be NULL. */
+int ssc_pend_step(const ssc_env_params *p, int64_t n, float *d_th, float *d_thdot, const float *d_act,
+                  float *d_obs, float *d_rew, uint8_t *d_done, int32_t *d_steps, ssc_stream_t stream);
+
+/* env.reset for the envs selected by d_mask (NULL = all) --
+ * continuous_mountain_car_editted.py:84-86 / gym PendulumEnv.reset.  Draws come from
+ * Philox(seed; env_id0 + i, t, TAG_RESET); also zeroes d_steps / d_ep_ret / d_ou_x entries
+ * (each may be NULL). */
+int ssc_env_reset(const ssc_env_params *p, int64_t n, const uint8_t *d_mask, float *d_s0, float *d_s1,
+                  int32_t *d_steps, float *d_ep_ret, float *d_ou_x, uint64_t seed, uint64_t env_id0,
+                  uint64_t t, ssc_stream_t stream);
+
+/* Observation of the current state: MountainCar [2][n] = (pos, vel); Pendulum [3][n]. */
+int ssc_env_observe(const ssc_env_params *p, int64_t n, const float *d_s0, const float *d_s1,
+                    float *d_obs, ssc_stream_t stream);
+
+/* K fused steps of the rlTrain inner loop (smartstart/reinforcementLearningCore/rlTrain.py:75-100)
+ * for n independent envs: get_action -> env.step -> record -> auto-reset on done.
+ * One thread owns one env; state stays in registers for the K steps.
+ *   policy RANDOM = Policy_Random.get_action (NN_Dynamics_Model/policy_random.py:14-15), i.e. the
+ *     reference's collect_samples_threaded.py:52-111 rollout;
+ *   policy ACTOR  = DDPG_Baselines_agent.get_action (DDPG_Baselines_agent.py:206-234).
+ * log, ring, d_stats may each be NULL.  d_stats is double[4] on the device and is
+ * ACCUMULATED into: {sum of rewards, goal terminations, env-steps, finished episodes}.
+ * Global step index of the first step is step0; env i has global id env_id0 + i, so any
+ * sharding of the id space reproduces the same per-env streams. */
+int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *policy, int64_t n, int32_t K,
+                const ssc_rollout_state *state, const ssc_transition_log *log,
+                const ssc_episode_ring *ring, double *d_stats, uint64_t seed, uint64_t env_id0,
+                uint64_t step0, ssc_stream_t stream);
+
+/* Batched actor forward, act[m][act_dim] = Actor_Editted(obs[m][obs_dim])
+ * (models_editted.py:38-61); row-major in/out.  No noise, no clipping. */
+int ssc_actor_forward(const ssc_actor_desc *actor, int64_t m, const float *d_obs, float *d_act,
+                      ssc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSC_H */

@@ -1,0 +1,12 @@
+"""smartstartcontinuous_amd -- MI355X-native rollout engine behind the gym.Env / RLAgent
+surface of darren-huang/SmartStartContinuous.
+
+Importing the package does not touch the GPU; the HIP library (libssc.so) is loaded on
+first use and its absence is an error -- there is no CPU fallback."""
+
+__version__ = "0.1.0"
+
+from . import _ffi  # noqa: F401
+from .spaces import Box, EnvSpec  # noqa: F401
+from .vec_env import (ActorPolicy, Continuous_MountainCarEnv_Editted, EpisodeRing, RandomPolicy,  # noqa: F401
+                      SingleEnvView, TransitionChunk, VecEnv, make)

@@ -1,0 +1,122 @@
+"""ctypes binding of libssc.so (include/ssc.h).
+
+The HIP library is the product; there is NO CPU fallback.  Importing this module without a
+built ``libssc.so`` raises immediately (build it with ``python -m smartstartcontinuous_amd.build``
+or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, \
+    c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssc.so")
+
+SSC_OK, SSC_EINVAL, SSC_EUNSUPPORTED, SSC_EHIP = 0, -1, -2, -3
+SSC_ENV_MOUNTAINCAR, SSC_ENV_PENDULUM = 0, 1
+SSC_POLICY_RANDOM, SSC_POLICY_ACTOR = 0, 1
+SSC_PREC_F32, SSC_PREC_BF16_MFMA = 0, 1
+SSC_MAX_OBS, SSC_MAX_LAYERS, SSC_MAX_STATE, SSC_MAX_ACT = 3, 4, 8, 4
+
+
+class SscError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libssc error {code}: {msg}")
+        self.code = code
+
+
+class EnvParams(Structure):
+    _fields_ = [("kind", c_int32), ("max_episode_steps", c_int32),
+                ("min_action", c_float), ("max_action", c_float),
+                ("min_position", c_float), ("max_position", c_float),
+                ("max_speed", c_float), ("goal_position", c_float), ("power", c_float),
+                ("reset_low", c_float), ("reset_high", c_float),
+                ("max_torque", c_float), ("pend_max_speed", c_float), ("dt", c_float),
+                ("g", c_float), ("m", c_float), ("l", c_float), ("pend_v1_order", c_int32)]
+
+
+class ActorDesc(Structure):
+    _fields_ = [("obs_dim", c_int32), ("h1", c_int32), ("h2", c_int32), ("act_dim", c_int32),
+                ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
+                ("W3", c_void_p), ("b3", c_void_p),
+                ("last_layer_tanh", c_int32), ("precision", c_int32)]
+
+
+class OuDesc(Structure):
+    _fields_ = [("mu", c_float), ("sigma", c_float), ("theta", c_float), ("dt", c_float), ("epsilon", c_float)]
+
+
+class PolicyDesc(Structure):
+    _fields_ = [("kind", c_int32), ("act_low", c_float), ("act_high", c_float),
+                ("actor", ActorDesc), ("ou", OuDesc)]
+
+
+class RolloutState(Structure):
+    _fields_ = [("s0", c_void_p), ("s1", c_void_p), ("steps", c_void_p), ("ep_ret", c_void_p), ("ou_x", c_void_p)]
+
+
+class TransitionLog(Structure):
+    _fields_ = [("obs", c_void_p * SSC_MAX_OBS), ("act", c_void_p), ("rew", c_void_p), ("done", c_void_p),
+                ("obs2", c_void_p * SSC_MAX_OBS)]
+
+
+class EpisodeRing(Structure):
+    _fields_ = [("env_id", c_void_p), ("length", c_void_p), ("ret", c_void_p), ("cursor", c_void_p),
+                ("capacity", c_int32)]
+
+
+# symbol -> (restype, argtypes); every function include/ssc.h declares must be listed here
+# (tests/test_abi.py cross-checks the header against this table and the built library).
+_SIGNATURES = {
+    "ssc_version": (c_int, []),
+    "ssc_last_error": (c_char_p, []),
+    "ssc_env_params_default": (c_int, [c_int, c_float, c_int32, POINTER(EnvParams)]),
+    "ssc_mc_step": (c_int, [POINTER(EnvParams), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p]),
+    "ssc_pend_step": (c_int, [POINTER(EnvParams), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p]),
+    "ssc_env_reset": (c_int, [POINTER(EnvParams), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_uint64, c_uint64, c_uint64, c_void_p]),
+    "ssc_env_observe": (c_int, [POINTER(EnvParams), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ssc_rollout": (c_int, [POINTER(EnvParams), POINTER(PolicyDesc), c_int64, c_int32, POINTER(RolloutState),
+                            POINTER(TransitionLog), POINTER(EpisodeRing), c_void_p, c_uint64, c_uint64,
+                            c_uint64, c_void_p]),
+    "ssc_actor_forward": (c_int, [POINTER(ActorDesc), c_int64, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libssc.so once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP library is the product and there is no CPU fallback. "
+                "Build it with `python -m smartstartcontinuous_amd.build` (needs hipcc).")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != SSC_OK:
+        raise SscError(rc, lib().ssc_last_error().decode("utf-8", "replace"))
+
+
+def default_params(kind, power_scalar=1.0, max_episode_steps=0):
+    p = EnvParams()
+    check(lib().ssc_env_params_default(kind, power_scalar, max_episode_steps, ctypes.byref(p)))
+    return p
+
+
+def ptr(t):
+    """data_ptr() of a tensor (or None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())

@@ -1,0 +1,181 @@
+// actor_device.h -- DDPG actor forward as wave-level device code (gfx950).
+//
+// Actor_Editted.__call__ (DDPG_Baselines_editted/models_editted.py:38-61):
+//   x = relu(obs @ W1 + b1); x = tanh|relu(x @ W2 + b2); a = tanh(x @ W3 + b3)
+// with TensorFlow weight layout W[in][out].  Two implementations:
+//
+//  * ActorF32<OBS,H1,H2>   one env per lane, everything in fp32 on the VALU, weights read
+//                          through wave-uniform (scalar) loads.  The parity reference path.
+//  * ActorMfma<OBS,UT,JT>  one wave = 64 envs.  Layer 1 (K = obs_dim = 2..4) runs on the
+//                          exact-f32 MFMA v_mfma_f32_32x32x2_f32; its 32x32 accumulator tile
+//                          (hidden unit on the register index, env on the lane) is converted
+//                          to bf16 in registers and fed STRAIGHT BACK as the B operand of
+//                          v_mfma_f32_32x32x16_bf16 for the [H1]x[H2] hidden GEMM -- no LDS,
+//                          no lane movement (cdna_hip_programming.md section 3 "An accumulator
+//                          tile as the next MFMA's operand").  Layer 3 (H2 -> 1) is a per-lane
+//                          dot over the accumulator registers plus one cross-half add.
+#pragma once
+
+#include "ssc_device.h"
+
+namespace ssc {
+
+struct ActorWeights {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    int32_t obs_dim, h1, h2;
+    int32_t last_layer_tanh;
+};
+
+// ---------------------------------------------------------------------------------------
+// fp32 VALU path
+// ---------------------------------------------------------------------------------------
+template <int OBS, int H1, int H2>
+struct ActorF32 {
+    ActorWeights w;
+
+    __device__ void init(const ActorWeights &aw) { w = aw; }
+
+    __device__ float forward(const float (&obs)[OBS]) const {
+        float h1[H1];
+#pragma unroll
+        for (int j = 0; j < H1; ++j) {
+            float acc = w.b1[j];
+#pragma unroll
+            for (int i = 0; i < OBS; ++i) acc = fmaf(obs[i], w.W1[i * H1 + j], acc);
+            h1[j] = fmaxf(acc, 0.0f);  // models_editted.py:47
+        }
+        float out = w.b3[0];
+#pragma unroll 4
+        for (int j = 0; j < H2; ++j) {
+            float acc = w.b2[j];
+#pragma unroll
+            for (int i = 0; i < H1; ++i) acc = fmaf(h1[i], w.W2[i * H2 + j], acc);
+            const float h2 = w.last_layer_tanh ? tanh_fast(acc) : fmaxf(acc, 0.0f);  // :53-56
+            out = fmaf(h2, w.W3[j], out);
+        }
+        return tanh_fast(out);  // :60
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// MFMA path
+// ---------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// row of a 32x32 MFMA accumulator element: (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+template <int OBS, int UT, int JT>
+struct ActorMfma {
+    static constexpr int KS1 = (OBS + 1) / 2;  // 32x32x2 k-steps of layer 1
+    float a1[UT][KS1];     // layer-1 A operand: W1[k = 2ks + half][unit = ut*32 + (lane&31)]
+    f32x16 c1[UT];         // b1 broadcast in accumulator layout
+    bf16x8 a2[JT][UT][2];  // layer-2 A fragments (W2^T, k order matched to the layer-1 accumulator)
+    f32x16 c2[JT];         // b2 in accumulator layout
+    float w3[JT][16];      // W3[jt*32 + acc_row(reg)]
+    float b3;
+    int last_tanh;
+
+    __device__ void init(const ActorWeights &w) {
+        const int lane = threadIdx.x & 63;
+        const int r = lane & 31, half = lane >> 5;
+        const int H1 = w.h1, H2 = w.h2;
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            const int unit = ut * 32 + r;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int k = 2 * ks + half;
+                a1[ut][ks] = (k < OBS && unit < H1) ? w.W1[k * H1 + unit] : 0.0f;
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int u = ut * 32 + acc_row(reg, half);
+                c1[ut][reg] = (u < H1) ? w.b1[u] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int col = jt * 32 + r;  // layer-2 output unit held by this lane's A row
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // k slot (8*half + j) of k-step (ut, s) carries hidden unit u
+                        const int u = ut * 32 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
+                        const float v = (u < H1 && col < H2) ? w.W2[u * H2 + col] : 0.0f;
+                        a2[jt][ut][s][j] = (__bf16)v;
+                    }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int o = jt * 32 + acc_row(reg, half);
+                c2[jt][reg] = (o < H2) ? w.b2[o] : 0.0f;
+                w3[jt][reg] = (o < H2) ? w.W3[o] : 0.0f;
+            }
+        }
+        b3 = w.b3[0];
+        last_tanh = w.last_layer_tanh;
+    }
+
+    // obs: this lane's env observation.  Returns the actor output for this lane's env.
+    // Wave-collective: every lane of the wave must call it.
+    __device__ float forward(const float (&obs)[OBS]) const {
+        const int half = (threadIdx.x & 63) >> 5;
+        // layer-1 B operands for the two 32-env tiles
+        float bop[2][KS1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const float v0 = obs[2 * ks];
+            const float v1 = (2 * ks + 1 < OBS) ? obs[2 * ks + 1] : 0.0f;
+            const float x0 = __shfl_xor(v0, 32);
+            const float x1 = __shfl_xor(v1, 32);
+            bop[0][ks] = half ? x1 : v0;  // tile 0: env = lane & 31
+            bop[1][ks] = half ? v1 : x0;  // tile 1: env = 32 + (lane & 31)
+        }
+        f32x16 acc2[JT][2];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            acc2[jt][0] = c2[jt];
+            acc2[jt][1] = c2[jt];
+        }
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                f32x16 d = c1[ut];
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks)
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[ut][ks], bop[et][ks], d, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 frag;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) frag[j] = (__bf16)fmaxf(d[8 * s + j], 0.0f);  // relu :47
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+                        acc2[jt][et] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[jt][ut][s], frag, acc2[jt][et], 0, 0, 0);
+                }
+            }
+        }
+        float part0 = 0.0f, part1 = 0.0f;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float p0 = acc2[jt][0][reg], p1 = acc2[jt][1][reg];
+                const float h0 = last_tanh ? tanh_fast(p0) : fmaxf(p0, 0.0f);
+                const float h1v = last_tanh ? tanh_fast(p1) : fmaxf(p1, 0.0f);
+                part0 = fmaf(h0, w3[jt][reg], part0);
+                part1 = fmaf(h1v, w3[jt][reg], part1);
+            }
+        part0 += __shfl_xor(part0, 32);
+        part1 += __shfl_xor(part1, 32);
+        return tanh_fast((half ? part1 : part0) + b3);
+    }
+};
+
+}  // namespace ssc

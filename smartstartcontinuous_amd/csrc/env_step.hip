@@ -1,0 +1,168 @@
+// env_step.hip -- single-step / reset / observe kernels (the gym.Env-shaped API).
+//
+// These are the one-launch-per-step entry points behind VecEnv.step()/reset(); at
+// 65 536 envs one step touches 1.6 MB and is launch/L2-bound -- the
+// HBM-bound path is the fused K-step kernel in rollout.hip.  Elementwise, one thread per
+// env, coalesced dword accesses over the SoA state columns.
+#include "ssc_device.h"
+#include "ssc_host.h"
+
+namespace ssc {
+
+// Continuous_MountainCarEnv_Editted.step (continuous_mountain_car_editted.py:60-82) +
+// gym TimeLimit.step (:154-159) when steps != nullptr.
+__global__ __launch_bounds__(kBlock) void mc_step_kernel(McConst c, int64_t n, float *__restrict__ pos,
+                                                         float *__restrict__ vel,
+                                                         const float *__restrict__ act,
+                                                         float *__restrict__ rew,
+                                                         uint8_t *__restrict__ done,
+                                                         int32_t *__restrict__ steps) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float p = pos[i], v = vel[i], r;
+    bool goal;
+    mc_step_one(c, p, v, act[i], r, goal);
+    bool d = goal;
+    if (steps != nullptr) {
+        const int32_t el = steps[i] + 1;
+        steps[i] = el;
+        d = d || (c.max_episode_steps > 0 && el >= c.max_episode_steps);
+    }
+    pos[i] = p;
+    vel[i] = v;
+    rew[i] = r;
+    done[i] = d ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void pend_step_kernel(PendConst c, int64_t n, float *__restrict__ th,
+                                                           float *__restrict__ thdot,
+                                                           const float *__restrict__ act,
+                                                           float *__restrict__ obs, float *__restrict__ rew,
+                                                           uint8_t *__restrict__ done,
+                                                           int32_t *__restrict__ steps) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float t = th[i], td = thdot[i], r;
+    pend_step_one(c, t, td, act[i], r);
+    bool d = false;  // Pendulum never terminates by itself
+    if (steps != nullptr) {
+        const int32_t el = steps[i] + 1;
+        steps[i] = el;
+        d = c.max_episode_steps > 0 && el >= c.max_episode_steps;
+    }
+    th[i] = t;
+    thdot[i] = td;
+    rew[i] = r;
+    done[i] = d ? 1 : 0;
+    if (obs != nullptr) {
+        obs[i] = cosf(t);
+        obs[n + i] = sinf(t);
+        obs[2 * n + i] = td;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void env_reset_kernel(int kind, McConst mc, int64_t n,
+                                                           const uint8_t *__restrict__ mask,
+                                                           float *__restrict__ s0, float *__restrict__ s1,
+                                                           int32_t *__restrict__ steps,
+                                                           float *__restrict__ ep_ret, float *__restrict__ ou_x,
+                                                           uint64_t seed, uint64_t env_id0, uint64_t t) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (mask != nullptr && mask[i] == 0) return;
+    const u32x4 w = rng_words(seed, env_id0 + (uint64_t)i, t, TAG_RESET);
+    float a, b;
+    if (kind == SSC_ENV_MOUNTAINCAR)
+        mc_reset_one(mc, w, a, b);
+    else
+        pend_reset_one(w, a, b);
+    s0[i] = a;
+    s1[i] = b;
+    if (steps != nullptr) steps[i] = 0;
+    if (ep_ret != nullptr) ep_ret[i] = 0.0f;
+    if (ou_x != nullptr) ou_x[i] = 0.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void env_observe_kernel(int kind, int64_t n, const float *__restrict__ s0,
+                                                             const float *__restrict__ s1,
+                                                             float *__restrict__ obs) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (kind == SSC_ENV_MOUNTAINCAR) {
+        obs[i] = s0[i];
+        obs[n + i] = s1[i];
+    } else {
+        const float t = s0[i];
+        obs[i] = cosf(t);
+        obs[n + i] = sinf(t);
+        obs[2 * n + i] = s1[i];
+    }
+}
+
+// |3*pos| must stay inside cos_bounded's domain.
+int validate_mc_params(const ssc_env_params *p, const char *who) {
+    if (p->kind != SSC_ENV_MOUNTAINCAR) return set_error(SSC_EINVAL, "%s: params are not MountainCar", who);
+    if (!(p->min_position < p->max_position) || p->min_position < -1.5f || p->max_position > 1.5f)
+        return set_error(SSC_EUNSUPPORTED, "%s: position range [%g, %g] outside [-1.5, 1.5]", who,
+                         (double)p->min_position, (double)p->max_position);
+    if (!(p->max_speed > 0.0f) || !(p->min_action <= p->max_action))
+        return set_error(SSC_EINVAL, "%s: bad max_speed / action range", who);
+    return SSC_OK;
+}
+
+}  // namespace ssc
+
+using namespace ssc;
+
+extern "C" {
+
+int ssc_mc_step(const ssc_env_params *p, int64_t n, float *d_pos, float *d_vel, const float *d_act,
+                float *d_rew, uint8_t *d_done, int32_t *d_steps, ssc_stream_t stream) {
+    SSC_REQUIRE(p != nullptr, "ssc_mc_step: params NULL");
+    SSC_REQUIRE(n >= 0, "ssc_mc_step: n = %lld < 0", (long long)n);
+    if (int rc = validate_mc_params(p, "ssc_mc_step")) return rc;
+    if (n == 0) return SSC_OK;
+    SSC_REQUIRE(d_pos && d_vel && d_act && d_rew && d_done, "ssc_mc_step: NULL device pointer");
+    hipLaunchKernelGGL(mc_step_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream),
+                       make_mc_const(*p), n, d_pos, d_vel, d_act, d_rew, d_done, d_steps);
+    return check_launch("ssc_mc_step");
+}
+
+int ssc_pend_step(const ssc_env_params *p, int64_t n, float *d_th, float *d_thdot, const float *d_act,
+                  float *d_obs, float *d_rew, uint8_t *d_done, int32_t *d_steps, ssc_stream_t stream) {
+    SSC_REQUIRE(p != nullptr, "ssc_pend_step: params NULL");
+    SSC_REQUIRE(p->kind == SSC_ENV_PENDULUM, "ssc_pend_step: params are not Pendulum");
+    SSC_REQUIRE(n >= 0, "ssc_pend_step: n = %lld < 0", (long long)n);
+    if (n == 0) return SSC_OK;
+    SSC_REQUIRE(d_th && d_thdot && d_act && d_rew && d_done, "ssc_pend_step: NULL device pointer");
+    hipLaunchKernelGGL(pend_step_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream),
+                       make_pend_const(*p), n, d_th, d_thdot, d_act, d_obs, d_rew, d_done, d_steps);
+    return check_launch("ssc_pend_step");
+}
+
+int ssc_env_reset(const ssc_env_params *p, int64_t n, const uint8_t *d_mask, float *d_s0, float *d_s1,
+                  int32_t *d_steps, float *d_ep_ret, float *d_ou_x, uint64_t seed, uint64_t env_id0,
+                  uint64_t t, ssc_stream_t stream) {
+    SSC_REQUIRE(p != nullptr, "ssc_env_reset: params NULL");
+    SSC_REQUIRE(p->kind == SSC_ENV_MOUNTAINCAR || p->kind == SSC_ENV_PENDULUM, "ssc_env_reset: bad kind");
+    SSC_REQUIRE(n >= 0, "ssc_env_reset: n = %lld < 0", (long long)n);
+    if (n == 0) return SSC_OK;
+    SSC_REQUIRE(d_s0 && d_s1, "ssc_env_reset: NULL state pointer");
+    hipLaunchKernelGGL(env_reset_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream), p->kind,
+                       make_mc_const(*p), n, d_mask, d_s0, d_s1, d_steps, d_ep_ret, d_ou_x, seed, env_id0, t);
+    return check_launch("ssc_env_reset");
+}
+
+int ssc_env_observe(const ssc_env_params *p, int64_t n, const float *d_s0, const float *d_s1,
+                    float *d_obs, ssc_stream_t stream) {
+    SSC_REQUIRE(p != nullptr, "ssc_env_observe: params NULL");
+    SSC_REQUIRE(p->kind == SSC_ENV_MOUNTAINCAR || p->kind == SSC_ENV_PENDULUM, "ssc_env_observe: bad kind");
+    SSC_REQUIRE(n >= 0, "ssc_env_observe: n < 0");
+    if (n == 0) return SSC_OK;
+    SSC_REQUIRE(d_s0 && d_s1 && d_obs, "ssc_env_observe: NULL device pointer");
+    hipLaunchKernelGGL(env_observe_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream), p->kind, n,
+                       d_s0, d_s1, d_obs);
+    return check_launch("ssc_env_observe");
+}
+
+}  // extern "C"

@@ -1,0 +1,338 @@
+// rollout.hip -- the fused K-step rollout kernel: the rlTrain inner loop
+// (smartstart/reinforcementLearningCore/rlTrain.py:75-100) for n independent envs.
+//
+//   for k in range(K):  action = agent.get_action(obs)        (:81)
+//                       obs2, r, done = env.step(action)      (:84)  [+ gym TimeLimit]
+//                       record (obs, a, r, done, obs2)        (:91-94, replay_buffer.py:53)
+//                       if done: Summary.append((len, ret)); env.reset()   (:97-114)
+//
+// MI355X mapping: one thread owns one env; pos/vel/elapsed/return (and the OU state) live
+// in VGPRs for all K steps, so the only HBM traffic is the transition log itself --
+// [K][n] SoA columns, each wave-instruction storing 256 contiguous bytes (1 dword/lane).
+// 25 B per MountainCar env-step, 33 B per Pendulum env-step: the
+// kernel is HBM-write-bound by construction.  Episode records go to a ring through a
+// wave-aggregated atomic cursor; chunk statistics are reduced wave -> block -> one f64
+// atomic per block.
+#include "actor_device.h"
+#include "ssc_device.h"
+#include "ssc_host.h"
+
+namespace ssc {
+
+struct RolloutArgs {
+    int64_t n;
+    int32_t K;
+    ssc_rollout_state st;
+    ssc_transition_log log;
+    ssc_episode_ring ring;
+    double *stats;
+    uint64_t seed, env_id0, step0;
+    int32_t has_log, has_ring;
+};
+
+struct PolicyArgs {
+    float act_low, act_span, act_high;
+    ActorWeights actor;
+    float ou_mu, ou_sigma, ou_theta, ou_dt, ou_eps;
+};
+
+// ------------------------------------------------------------------------------- envs --
+struct McEnv {
+    using Const = McConst;
+    static constexpr int OBS = 2;
+    float pos, vel;
+    __device__ void load(float a, float b) { pos = a; vel = b; }
+    __device__ void observe(float (&o)[OBS]) const { o[0] = pos; o[1] = vel; }
+    __device__ void step(const Const &c, float a, float &rew, bool &goal) { mc_step_one(c, pos, vel, a, rew, goal); }
+    __device__ void reset(const Const &c, const u32x4 &w) { mc_reset_one(c, w, pos, vel); }
+    __device__ float s0() const { return pos; }
+    __device__ float s1() const { return vel; }
+};
+
+struct PendEnv {
+    using Const = PendConst;
+    static constexpr int OBS = 3;
+    float th, thdot;
+    __device__ void load(float a, float b) { th = a; thdot = b; }
+    __device__ void observe(float (&o)[OBS]) const {
+        float s, c;
+        sincosf(th, &s, &c);
+        o[0] = c; o[1] = s; o[2] = thdot;
+    }
+    __device__ void step(const Const &c, float a, float &rew, bool &goal) {
+        pend_step_one(c, th, thdot, a, rew);
+        goal = false;
+    }
+    __device__ void reset(const Const &, const u32x4 &w) { pend_reset_one(w, th, thdot); }
+    __device__ float s0() const { return th; }
+    __device__ float s1() const { return thdot; }
+};
+
+// --------------------------------------------------------------------------- policies --
+// Policy_Random.get_action = U(low, high)  (NN_Dynamics_Model/policy_random.py:14-15).
+// One Philox call serves 4 consecutive steps: counter t>>2, word t&3.
+template <int OBS>
+struct RandomPolicy {
+    u32x4 cache;
+    float low, span;
+    __device__ void init(const PolicyArgs &pa, const RolloutArgs &, int64_t) { low = pa.act_low; span = pa.act_span; }
+    __device__ float act(const float (&)[OBS], uint64_t seed, uint64_t env_id, uint64_t t, bool first) {
+        if (first || (t & 3) == 0) cache = rng_words(seed, env_id, t >> 2, TAG_ACTION);  // wave-uniform branch
+        return uniform_f32(pick(cache, (uint32_t)(t & 3)), low, span);
+    }
+    __device__ void on_reset() {}
+    __device__ void store(const RolloutArgs &, int64_t) const {}
+};
+
+// DDPG_Baselines_agent.get_action (smartstart/RLAgents/DDPG_Baselines_agent.py:206-234):
+//   a = actor(obs) + epsilon * OU();  a = clip(a, -1, 1)      (ddpg_editted.py:262-271)
+//   a = scale(scale(a))                                        (DDPG_Baselines_agent.py:236-240)
+// OU [third-party baselines 0.1.5 ddpg/noise.py]: x += theta*(mu-x)*dt + sigma*sqrt(dt)*N(0,1).
+// One Philox call serves the gaussians of 2 consecutive steps: counter t>>1.
+template <class Net, int OBS>
+struct ActorPolicy {
+    Net net;
+    u32x4 cache;
+    float ou_x, mu, sig_sqrt_dt, theta_dt, eps;
+    float low, high;
+    bool identity_scale;
+
+    __device__ void init(const PolicyArgs &pa, const RolloutArgs &ra, int64_t i) {
+        net.init(pa.actor);
+        mu = pa.ou_mu;
+        sig_sqrt_dt = pa.ou_sigma * sqrtf(pa.ou_dt);
+        theta_dt = pa.ou_theta * pa.ou_dt;
+        eps = fmaxf(pa.ou_eps, 0.0f);  // DDPG_Baselines_agent.py:74
+        ou_x = (ra.st.ou_x != nullptr) ? ra.st.ou_x[i] : 0.0f;
+        low = pa.act_low;
+        high = pa.act_high;
+        identity_scale = (low == -1.0f && high == 1.0f);
+    }
+    __device__ float scale(float a) const {  // DDPG_Baselines_agent.py:236-240
+        a = fminf(fmaxf(a, -1.0f), 1.0f);
+        return identity_scale ? a : fmaf((a + 1.0f) * 0.5f, high - low, low);
+    }
+    __device__ float act(const float (&obs)[OBS], uint64_t seed, uint64_t env_id, uint64_t t, bool first) {
+        float a = net.forward(obs);
+        if (eps > 0.0f) {  // wave-uniform
+            if (first || (t & 1) == 0) cache = rng_words(seed, env_id, t >> 1, TAG_OU);
+            const bool odd = (t & 1) != 0;
+            const float g = gaussian_f32(odd ? cache.z : cache.x, odd ? cache.w : cache.y);
+            ou_x = ou_x + theta_dt * (mu - ou_x) + sig_sqrt_dt * g;
+            a += ou_x * eps;  // ddpg_editted.py:267-270
+        }
+        a = fminf(fmaxf(a, -1.0f), 1.0f);  // ddpg_editted.py:271 (action_range = (-1, 1))
+        return scale(scale(a));
+    }
+    __device__ void on_reset() { ou_x = 0.0f; }  // DDPG_Baselines_agent.end_episode -> noise reset (:255-258)
+    __device__ void store(const RolloutArgs &ra, int64_t i) const {
+        if (ra.st.ou_x != nullptr) ra.st.ou_x[i] = ou_x;
+    }
+};
+
+// ----------------------------------------------------------------------------- kernel --
+template <class EnvT, class PolT>
+__global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec, PolicyArgs pa, RolloutArgs ra) {
+    constexpr int OBS = EnvT::OBS;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = gi < ra.n;
+    const int64_t i = active ? gi : ra.n - 1;  // inactive lanes shadow the last env, never store
+    const uint64_t env_id = ra.env_id0 + (uint64_t)i;
+    const int64_t n = ra.n;
+
+    EnvT env;
+    env.load(ra.st.s0[i], ra.st.s1[i]);
+    int32_t el = ra.st.steps[i];
+    float ep_ret = ra.st.ep_ret[i];
+    PolT pol;
+    pol.init(pa, ra, i);
+
+    float obs[OBS];
+    env.observe(obs);
+    float sum_r = 0.0f;
+    int32_t n_goal = 0, n_eps = 0;
+
+    // Retire the state loads HERE.  Otherwise hipcc places their s_waitcnt vmcnt(N) inside the
+    // loop, where vmcnt also counts the log stores: every iteration would then wait for the
+    // previous iteration's stores to land (0x0F70 = vmcnt(0), expcnt/lgkmcnt untouched).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    for (int32_t k = 0; k < ra.K; ++k) {
+        const uint64_t t = ra.step0 + (uint64_t)k;
+        const float a = pol.act(obs, ra.seed, env_id, t, k == 0);
+        float rew;
+        bool goal;
+        env.step(ec, a, rew, goal);
+        float obs2[OBS];
+        env.observe(obs2);
+        el += 1;
+        const bool done = goal || (ec.max_episode_steps > 0 && el >= ec.max_episode_steps);
+        ep_ret += rew;
+        sum_r += rew;
+        n_goal += goal ? 1 : 0;
+
+        if (ra.has_log && active) {
+            const int64_t off = (int64_t)k * n + i;
+#pragma unroll
+            for (int c = 0; c < OBS; ++c) __builtin_nontemporal_store(obs[c], ra.log.obs[c] + off);
+            __builtin_nontemporal_store(a, ra.log.act + off);
+            __builtin_nontemporal_store(rew, ra.log.rew + off);
+            __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), ra.log.done + off);
+#pragma unroll
+            for (int c = 0; c < OBS; ++c) __builtin_nontemporal_store(obs2[c], ra.log.obs2[c] + off);
+        }
+
+        if (done) {
+            if (ra.has_ring && active) {
+                const uint32_t slot = atomicAdd(ra.ring.cursor, 1u);
+                if (slot < (uint32_t)ra.ring.capacity) {
+                    ra.ring.env_id[slot] = (int64_t)env_id;
+                    ra.ring.length[slot] = el;
+                    ra.ring.ret[slot] = ep_ret;
+                }
+            }
+            n_eps += 1;
+            env.reset(ec, rng_words(ra.seed, env_id, t, TAG_RESET));
+            el = 0;
+            ep_ret = 0.0f;
+            pol.on_reset();
+            env.observe(obs);
+        } else {
+#pragma unroll
+            for (int c = 0; c < OBS; ++c) obs[c] = obs2[c];
+        }
+    }
+
+    if (active) {
+        ra.st.s0[i] = env.s0();
+        ra.st.s1[i] = env.s1();
+        ra.st.steps[i] = el;
+        ra.st.ep_ret[i] = ep_ret;
+        pol.store(ra, i);
+    }
+
+    if (ra.stats != nullptr) {
+        double v[4] = {active ? (double)sum_r : 0.0, active ? (double)n_goal : 0.0,
+                       active ? (double)ra.K : 0.0, active ? (double)n_eps : 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v[q] += __shfl_xor(v[q], m);
+        __shared__ double red[kBlock / 64][4];
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[wave][q] = v[q];
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) s += red[w][threadIdx.x];
+            atomicAdd(ra.stats + threadIdx.x, s);
+        }
+    }
+}
+
+template <class EnvT, class PolT>
+static int launch_rollout(const typename EnvT::Const &ec, const PolicyArgs &pa, const RolloutArgs &ra,
+                          hipStream_t stream) {
+    hipLaunchKernelGGL((rollout_kernel<EnvT, PolT>), dim3(blocks_for(ra.n)), dim3(kBlock), 0, stream, ec, pa, ra);
+    return check_launch("ssc_rollout");
+}
+
+int validate_mc_params(const ssc_env_params *p, const char *who);  // env_step.hip
+
+template <class EnvT>
+static int dispatch_policy(const typename EnvT::Const &ec, const ssc_policy_desc *pol, const PolicyArgs &pa,
+                           const RolloutArgs &ra, hipStream_t stream) {
+    constexpr int OBS = EnvT::OBS;
+    if (pol->kind == SSC_POLICY_RANDOM) return launch_rollout<EnvT, RandomPolicy<OBS>>(ec, pa, ra, stream);
+    const ssc_actor_desc &a = pol->actor;
+    if (a.obs_dim != OBS)
+        return set_error(SSC_EINVAL, "ssc_rollout: actor obs_dim %d != env obs_dim %d", a.obs_dim, OBS);
+    if (a.act_dim != 1) return set_error(SSC_EUNSUPPORTED, "ssc_rollout: act_dim %d (only 1)", a.act_dim);
+    if (a.precision == SSC_PREC_F32) {
+        if (a.h1 == 64 && a.h2 == 32)
+            return launch_rollout<EnvT, ActorPolicy<ActorF32<OBS, 64, 32>, OBS>>(ec, pa, ra, stream);
+        return set_error(SSC_EUNSUPPORTED,
+                         "ssc_rollout: fused fp32 actor supports h1-h2 = 64-32 (got %d-%d); use the bf16 MFMA "
+                         "path or step the env with ssc_actor_forward + ssc_*_step",
+                         a.h1, a.h2);
+    }
+    if (a.precision == SSC_PREC_BF16_MFMA) {
+        if (a.h1 <= 64 && a.h2 <= 32)
+            return launch_rollout<EnvT, ActorPolicy<ActorMfma<OBS, 2, 1>, OBS>>(ec, pa, ra, stream);
+        if (a.h1 <= 128 && a.h2 <= 64)
+            return launch_rollout<EnvT, ActorPolicy<ActorMfma<OBS, 4, 2>, OBS>>(ec, pa, ra, stream);
+        return set_error(SSC_EUNSUPPORTED, "ssc_rollout: MFMA actor supports h1 <= 128, h2 <= 64 (got %d-%d)",
+                         a.h1, a.h2);
+    }
+    return set_error(SSC_EINVAL, "ssc_rollout: unknown precision %d", a.precision);
+}
+
+}  // namespace ssc
+
+using namespace ssc;
+
+extern "C" int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *policy, int64_t n, int32_t K,
+                           const ssc_rollout_state *state, const ssc_transition_log *log,
+                           const ssc_episode_ring *ring, double *d_stats, uint64_t seed, uint64_t env_id0,
+                           uint64_t step0, ssc_stream_t stream) {
+    SSC_REQUIRE(p && policy && state, "ssc_rollout: NULL descriptor");
+    SSC_REQUIRE(n >= 0 && K >= 0, "ssc_rollout: n = %lld, K = %d", (long long)n, K);
+    SSC_REQUIRE(policy->kind == SSC_POLICY_RANDOM || policy->kind == SSC_POLICY_ACTOR,
+                "ssc_rollout: unknown policy kind %d", policy->kind);
+    if (n == 0 || K == 0) return SSC_OK;
+    SSC_REQUIRE(state->s0 && state->s1 && state->steps && state->ep_ret, "ssc_rollout: NULL state column");
+    SSC_REQUIRE(policy->act_low <= policy->act_high, "ssc_rollout: act_low > act_high");
+    const int obs_dim = (p->kind == SSC_ENV_MOUNTAINCAR) ? 2 : 3;
+    RolloutArgs ra;
+    ra.n = n;
+    ra.K = K;
+    ra.st = *state;
+    ra.has_log = log != nullptr;
+    ra.has_ring = ring != nullptr;
+    if (log) {
+        ra.log = *log;
+        for (int c = 0; c < obs_dim; ++c)
+            SSC_REQUIRE(log->obs[c] && log->obs2[c], "ssc_rollout: NULL log obs column %d", c);
+        SSC_REQUIRE(log->act && log->rew && log->done, "ssc_rollout: NULL log column");
+    } else {
+        ra.log = ssc_transition_log{};
+    }
+    if (ring) {
+        ra.ring = *ring;
+        SSC_REQUIRE(ring->env_id && ring->length && ring->ret && ring->cursor && ring->capacity >= 0,
+                    "ssc_rollout: bad episode ring");
+    } else {
+        ra.ring = ssc_episode_ring{};
+    }
+    ra.stats = d_stats;
+    ra.seed = seed;
+    ra.env_id0 = env_id0;
+    ra.step0 = step0;
+
+    PolicyArgs pa{};
+    pa.act_low = policy->act_low;
+    pa.act_high = policy->act_high;
+    pa.act_span = policy->act_high - policy->act_low;
+    if (policy->kind == SSC_POLICY_ACTOR) {
+        const ssc_actor_desc &a = policy->actor;
+        SSC_REQUIRE(a.W1 && a.b1 && a.W2 && a.b2 && a.W3 && a.b3, "ssc_rollout: NULL actor weight pointer");
+        SSC_REQUIRE(a.h1 > 0 && a.h2 > 0, "ssc_rollout: bad actor sizes");
+        pa.actor = ActorWeights{a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.obs_dim, a.h1, a.h2, a.last_layer_tanh};
+        pa.ou_mu = policy->ou.mu;
+        pa.ou_sigma = policy->ou.sigma;
+        pa.ou_theta = policy->ou.theta;
+        pa.ou_dt = policy->ou.dt;
+        pa.ou_eps = policy->ou.epsilon;
+        SSC_REQUIRE(!(pa.ou_eps > 0.0f) || state->ou_x != nullptr, "ssc_rollout: OU noise needs state->ou_x");
+    }
+    if (p->kind == SSC_ENV_MOUNTAINCAR) {
+        if (int rc = validate_mc_params(p, "ssc_rollout")) return rc;
+        return dispatch_policy<McEnv>(make_mc_const(*p), policy, pa, ra, as_stream(stream));
+    }
+    if (p->kind == SSC_ENV_PENDULUM)
+        return dispatch_policy<PendEnv>(make_pend_const(*p), policy, pa, ra, as_stream(stream));
+    return set_error(SSC_EINVAL, "ssc_rollout: unknown env kind %d", p->kind);
+}

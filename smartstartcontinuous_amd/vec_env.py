@@ -1,0 +1,364 @@
+"""Vectorised environments over the HIP kernels, keeping the ``gym.Env`` surface.
+
+``VecEnv`` is the batched counterpart of the reference environments
+(smartstart/environments/continuous_mountain_car_editted.py and ``gym.make(...)``):
+``reset() / step() / seed() / close()`` plus ``observation_space / action_space / spec.id``,
+with [N, ...] torch tensors on the GPU instead of scalars.  ``SingleEnvView`` presents an
+N=1 ``VecEnv`` with *exactly* the scalar tuple types of gym 0.10.5 so that an unchanged
+``rlTrain``-style loop and any ``RLAgent`` can drive it (BASELINE config 1).
+
+State lives in caller-visible torch tensors (structure of arrays, fp32); every call goes
+through the C ABI in ``include/ssc.h`` on ``torch.cuda.current_stream()``.
+"""
+from __future__ import annotations
+
+import ctypes
+import re
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .spaces import Box, EnvSpec
+
+RESET_T0 = (1 << 56) - 1  # RNG step index of the very first reset (oracle/ssc_oracle.py:RESET_T0)
+
+_MC_EDITTED = re.compile(r"^MountainCarContinuousActionX([0-9.]+)-v(\d+)$")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def parse_env_id(env_id, power_scalar=None, max_episode_steps=None):
+    """-> (kind, power_scalar, max_episode_steps, spec_id).
+
+    'MountainCarContinuous-v0'  : stock gym env, TimeLimit 999
+    'MountainCarContinuousActionX<ps>-v0' : Continuous_MountainCarEnv_Editted.get_name()
+        (continuous_mountain_car_editted.py:151-152); the examples wrap it in TimeLimit(1000)
+    'Pendulum-v0' : gym 0.10.5, TimeLimit 200 [third-party]
+    """
+    if env_id == "MountainCarContinuous-v0":
+        ps = 1.0 if power_scalar is None else power_scalar
+        return _ffi.SSC_ENV_MOUNTAINCAR, ps, 999 if max_episode_steps is None else max_episode_steps, env_id
+    m = _MC_EDITTED.match(env_id)
+    if m:
+        ps = float(m.group(1)) if power_scalar is None else power_scalar
+        return _ffi.SSC_ENV_MOUNTAINCAR, ps, 1000 if max_episode_steps is None else max_episode_steps, env_id
+    if env_id in ("Pendulum-v0", "Pendulum-v1"):
+        return _ffi.SSC_ENV_PENDULUM, 1.0, 200 if max_episode_steps is None else max_episode_steps, env_id
+    raise ValueError(f"unknown environment id {env_id!r}")
+
+
+@dataclass
+class RandomPolicy:
+    """Policy_Random (NN_Dynamics_Model/policy_random.py:3-15): a ~ U(action_space.low, high)."""
+
+
+@dataclass
+class ActorPolicy:
+    """DDPG_Baselines_agent.get_action (smartstart/RLAgents/DDPG_Baselines_agent.py:206-234):
+    actor forward + epsilon * OU noise + clip + scale.  ``weights`` = dict of fp32 CUDA
+    tensors W1[obs,h1] b1 W2[h1,h2] b2 W3[h2,1] b3 in TensorFlow layout."""
+    weights: dict
+    last_layer_tanh: bool = True
+    precision: str = "bf16_mfma"       # "f32" | "bf16_mfma"
+    ou_mu: float = 0.4
+    ou_sigma: float = 0.6
+    ou_theta: float = 0.15
+    ou_dt: float = 1e-2
+    ou_epsilon: float = 1.0
+
+
+class TransitionChunk:
+    """Transition log of one rollout chunk -- the (s, a, r, t, s2) records of
+    ReplayBuffer.add (smartstart/RLAgents/replay_buffer.py:49-74) as SoA columns.
+
+    obs, obs2: [obs_dim, K, N] fp32; act, rew: [K, N] fp32; done: [K, N] uint8."""
+
+    def __init__(self, obs_dim, K, N, device):
+        self.obs = torch.empty((obs_dim, K, N), dtype=torch.float32, device=device)
+        self.obs2 = torch.empty((obs_dim, K, N), dtype=torch.float32, device=device)
+        self.act = torch.empty((K, N), dtype=torch.float32, device=device)
+        self.rew = torch.empty((K, N), dtype=torch.float32, device=device)
+        self.done = torch.empty((K, N), dtype=torch.uint8, device=device)
+        self.K, self.N, self.obs_dim = K, N, obs_dim
+        self.step0 = 0
+        self.env_id0 = 0
+
+    BYTES_PER_STEP = {2: 25, 3: 33}
+
+    def nbytes(self):
+        return self.K * self.N * (8 * self.obs_dim + 9)
+
+    def columns(self):
+        """All columns as one list (used by the multi-GPU gather)."""
+        return [self.obs, self.act, self.rew, self.done, self.obs2]
+
+    def as_struct(self):
+        log = _ffi.TransitionLog()
+        for c in range(self.obs_dim):
+            log.obs[c] = self.obs[c].data_ptr()
+            log.obs2[c] = self.obs2[c].data_ptr()
+        log.act = self.act.data_ptr()
+        log.rew = self.rew.data_ptr()
+        log.done = self.done.data_ptr()
+        return log
+
+    def records(self):
+        """(s[KN,obs], a[KN,1], r[KN], t[KN] bool, s2[KN,obs]) in step-major order."""
+        s = self.obs.reshape(self.obs_dim, -1).t()
+        s2 = self.obs2.reshape(self.obs_dim, -1).t()
+        return s, self.act.reshape(-1, 1), self.rew.reshape(-1), self.done.reshape(-1).bool(), s2
+
+
+class EpisodeRing:
+    """Completed-episode records (len, total_reward) -- Summary.append
+    (smartstart/utilities/datacontainers.py:173-193)."""
+
+    def __init__(self, capacity, device):
+        self.env_id = torch.zeros(capacity, dtype=torch.int64, device=device)
+        self.length = torch.zeros(capacity, dtype=torch.int32, device=device)
+        self.ret = torch.zeros(capacity, dtype=torch.float32, device=device)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
+        self.capacity = capacity
+
+    def as_struct(self):
+        r = _ffi.EpisodeRing()
+        r.env_id, r.length, r.ret = self.env_id.data_ptr(), self.length.data_ptr(), self.ret.data_ptr()
+        r.cursor, r.capacity = self.cursor.data_ptr(), self.capacity
+        return r
+
+    def drain(self):
+        """-> (env_id, length, ret) numpy arrays of the recorded episodes, then clears.
+        Returns also the number of dropped records."""
+        n = int(self.cursor.item()) & 0xFFFFFFFF
+        kept = min(n, self.capacity)
+        out = (self.env_id[:kept].cpu().numpy(), self.length[:kept].cpu().numpy(), self.ret[:kept].cpu().numpy())
+        self.cursor.zero_()
+        return out, n - kept
+
+
+class VecEnv:
+    """N independent environments on one GPU.
+
+    Parameters mirror the reference: ``env_id`` is what ``env.spec.id`` reports;
+    ``power_scalar`` / ``max_episode_steps`` as in
+    ``Continuous_MountainCarEnv_Editted.make_timed_env`` (continuous_mountain_car_editted.py:154-159).
+    ``env_id0`` is the global id of env 0 (multi-GPU sharding keeps one id space).
+    """
+
+    def __init__(self, env_id="MountainCarContinuous-v0", n_envs=1, device="cuda", power_scalar=None,
+                 max_episode_steps=None, seed=1234, env_id0=0, auto_reset=False):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("VecEnv runs on the GPU only (device='cuda'); there is no CPU fallback")
+        self.lib = _ffi.lib()
+        kind, ps, mes, spec_id = parse_env_id(env_id, power_scalar, max_episode_steps)
+        self.kind, self.power_scalar, self.n = kind, ps, int(n_envs)
+        self.params = _ffi.default_params(kind, ps, mes or 0)
+        self.spec = EnvSpec(spec_id, mes)
+        self.env_id0 = int(env_id0)
+        self.auto_reset = auto_reset
+        if kind == _ffi.SSC_ENV_MOUNTAINCAR:
+            self.obs_dim = 2
+            # continuous_mountain_car_editted.py:45-51
+            self.action_space = Box(low=-1.0, high=1.0, shape=(1,))
+            self.observation_space = Box(low=np.array([-1.2, -0.07]), high=np.array([0.6, 0.07]))
+        else:
+            self.obs_dim = 3
+            self.action_space = Box(low=-2.0, high=2.0, shape=(1,))
+            self.observation_space = Box(low=np.array([-1.0, -1.0, -8.0]), high=np.array([1.0, 1.0, 8.0]))
+        dev, n = self.device, self.n
+        self.s0 = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.s1 = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.steps = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.ep_ret = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.ou_x = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._obs = torch.empty((self.obs_dim, n), dtype=torch.float32, device=dev)
+        self._rew = torch.empty(n, dtype=torch.float32, device=dev)
+        self._done = torch.empty(n, dtype=torch.uint8, device=dev)
+        self.stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        self._seed = int(seed)
+        self.t = 0            # global step index (RNG counter)
+        self._needs_reset = True
+
+    # ------------------------------------------------------------------ gym.Env surface --
+    def seed(self, seed=None):
+        """gym ``Env.seed`` (continuous_mountain_car_editted.py:56-58): returns [seed]."""
+        if seed is None:
+            seed = int(np.random.SeedSequence().entropy & ((1 << 63) - 1))
+        self._seed = int(seed)
+        return [self._seed]
+
+    def reset(self, mask=None):
+        """Reset all envs (``mask=None``) or those with ``mask[i] != 0``; returns obs [N, obs_dim]."""
+        with torch.cuda.device(self.device):
+            t = RESET_T0 if (mask is None and self._needs_reset) else max(self.t - 1, 0)
+            if mask is not None:
+                mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            _ffi.check(self.lib.ssc_env_reset(ctypes.byref(self.params), self.n, _ffi.ptr(mask), _ffi.ptr(self.s0),
+                                              _ffi.ptr(self.s1), _ffi.ptr(self.steps), _ffi.ptr(self.ep_ret),
+                                              _ffi.ptr(self.ou_x), self._seed, self.env_id0, t, _stream()))
+            if mask is None:
+                self._needs_reset = False
+            return self.observe()
+
+    def observe(self):
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.ssc_env_observe(ctypes.byref(self.params), self.n, _ffi.ptr(self.s0),
+                                                _ffi.ptr(self.s1), _ffi.ptr(self._obs), _stream()))
+        return self._obs.t()
+
+    def step(self, actions):
+        """actions [N, act_dim] (or [N]) -> (obs [N, obs_dim], rew [N], done [N] bool, {})."""
+        a = torch.as_tensor(actions, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
+        if a.numel() != self.n:
+            raise ValueError(f"expected {self.n} actions, got {a.numel()}")
+        with torch.cuda.device(self.device):
+            if self.kind == _ffi.SSC_ENV_MOUNTAINCAR:
+                _ffi.check(self.lib.ssc_mc_step(ctypes.byref(self.params), self.n, _ffi.ptr(self.s0),
+                                                _ffi.ptr(self.s1), _ffi.ptr(a), _ffi.ptr(self._rew),
+                                                _ffi.ptr(self._done), _ffi.ptr(self.steps), _stream()))
+                _ffi.check(self.lib.ssc_env_observe(ctypes.byref(self.params), self.n, _ffi.ptr(self.s0),
+                                                    _ffi.ptr(self.s1), _ffi.ptr(self._obs), _stream()))
+            else:
+                _ffi.check(self.lib.ssc_pend_step(ctypes.byref(self.params), self.n, _ffi.ptr(self.s0),
+                                                  _ffi.ptr(self.s1), _ffi.ptr(a), _ffi.ptr(self._obs),
+                                                  _ffi.ptr(self._rew), _ffi.ptr(self._done), _ffi.ptr(self.steps),
+                                                  _stream()))
+        self.t += 1
+        obs, rew, done = self._obs.t().clone(), self._rew.clone(), self._done.bool()
+        if self.auto_reset:
+            self.reset(mask=self._done)
+        return obs, rew, done, {}
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is out of scope (SURVEY.md section 8: visualisation)")
+
+    def close(self):
+        pass
+
+    # --------------------------------------------------------------------- fused rollout --
+    def policy_desc(self, policy):
+        pd = _ffi.PolicyDesc()
+        pd.act_low = float(self.action_space.low[0])
+        pd.act_high = float(self.action_space.high[0])
+        if isinstance(policy, RandomPolicy) or policy in ("random", None):
+            pd.kind = _ffi.SSC_POLICY_RANDOM
+            return pd, None
+        if not isinstance(policy, ActorPolicy):
+            raise TypeError("policy must be RandomPolicy() or ActorPolicy(...)")
+        w = {k: v.to(device=self.device, dtype=torch.float32).contiguous() for k, v in policy.weights.items()}
+        obs_dim, h1 = w["W1"].shape
+        h2 = w["W2"].shape[1]
+        if obs_dim != self.obs_dim or w["W2"].shape[0] != h1 or w["W3"].shape != (h2, 1):
+            raise ValueError("actor weight shapes do not match the environment")
+        pd.kind = _ffi.SSC_POLICY_ACTOR
+        a = pd.actor
+        a.obs_dim, a.h1, a.h2, a.act_dim = obs_dim, h1, h2, 1
+        a.W1, a.b1, a.W2, a.b2, a.W3, a.b3 = (w[k].data_ptr() for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
+        a.last_layer_tanh = int(policy.last_layer_tanh)
+        a.precision = {"f32": _ffi.SSC_PREC_F32, "bf16_mfma": _ffi.SSC_PREC_BF16_MFMA}[policy.precision]
+        pd.ou.mu, pd.ou.sigma, pd.ou.theta = policy.ou_mu, policy.ou_sigma, policy.ou_theta
+        pd.ou.dt, pd.ou.epsilon = policy.ou_dt, policy.ou_epsilon
+        return pd, w  # keep the tensors alive for the duration of the launch
+
+    def rollout(self, K, policy=None, out=None, ring=None, log=True, policy_desc=None):
+        """K fused steps for every env (ssc_rollout).  Returns the TransitionChunk (or None if
+        ``log=False``).  ``self.stats`` (f64[4]: sum reward, goal terminations, env-steps,
+        finished episodes) is accumulated on the device."""
+        if self._needs_reset:
+            self.reset()
+        if policy_desc is None:
+            policy_desc = self.policy_desc(policy)
+        pd, keep = policy_desc
+        chunk = None
+        if log:
+            chunk = out if out is not None else TransitionChunk(self.obs_dim, K, self.n, self.device)
+            if (chunk.K, chunk.N, chunk.obs_dim) != (K, self.n, self.obs_dim):
+                raise ValueError("out chunk has the wrong shape")
+            chunk.step0, chunk.env_id0 = self.t, self.env_id0
+        st = _ffi.RolloutState(self.s0.data_ptr(), self.s1.data_ptr(), self.steps.data_ptr(),
+                               self.ep_ret.data_ptr(), self.ou_x.data_ptr())
+        log_s = chunk.as_struct() if chunk is not None else None
+        ring_s = ring.as_struct() if ring is not None else None
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.ssc_rollout(
+                ctypes.byref(self.params), ctypes.byref(pd), self.n, K, ctypes.byref(st),
+                ctypes.byref(log_s) if log_s is not None else None,
+                ctypes.byref(ring_s) if ring_s is not None else None,
+                _ffi.ptr(self.stats), self._seed, self.env_id0, self.t, _stream()))
+        self.t += K
+        del keep
+        return chunk
+
+
+class SingleEnvView:
+    """An N=1 ``VecEnv`` behind the exact scalar ``gym.Env`` protocol of gym 0.10.5:
+    ``reset() -> ndarray(obs_dim,)``, ``step(ndarray(act_dim,)) -> (ndarray, float, bool, {})``
+    (what rlTrain.py:68,84 and every RLAgent consume)."""
+
+    def __init__(self, vec_env):
+        if vec_env.n != 1:
+            raise ValueError("SingleEnvView needs a VecEnv with n_envs=1")
+        self.vec = vec_env
+        self.observation_space = vec_env.observation_space
+        self.action_space = vec_env.action_space
+        self.spec = vec_env.spec
+        self._first = True
+
+    def seed(self, seed=None):
+        return self.vec.seed(seed)
+
+    def reset(self):
+        if self._first:
+            obs = self.vec.reset()
+            self._first = False
+        else:
+            obs = self.vec.reset(mask=torch.ones(1, dtype=torch.uint8))
+        return obs[0].double().cpu().numpy()
+
+    def step(self, action):
+        a = np.asarray(action, dtype=np.float64).reshape(-1)
+        obs, rew, done, info = self.vec.step(torch.as_tensor(a, dtype=torch.float32))
+        return obs[0].double().cpu().numpy(), float(rew[0].item()), bool(done[0].item()), info
+
+    def render(self, mode="human"):
+        return self.vec.render(mode)
+
+    def close(self):
+        self.vec.close()
+
+
+class Continuous_MountainCarEnv_Editted(SingleEnvView):
+    """Drop-in for smartstart/environments/continuous_mountain_car_editted.py:27 (N=1)."""
+
+    version = 0
+
+    def __init__(self, power_scalar, max_episode_steps=None, device="cuda", seed=1234):
+        self.power_scalar = power_scalar
+        name = "MountainCarContinuousActionX" + str(power_scalar) + "-v" + str(self.version)
+        super().__init__(VecEnv(name, 1, device=device, power_scalar=power_scalar,
+                                max_episode_steps=max_episode_steps or 0, seed=seed))
+        if max_episode_steps is None:
+            self.vec.params.max_episode_steps = 0
+            self.spec = None  # the bare reference env has no spec until make_timed_env sets one (:157)
+
+    def get_name(self):
+        return "MountainCarContinuousActionX" + str(self.power_scalar) + "-v" + str(self.version)
+
+    @classmethod
+    def make_timed_env(cls, power_scalar, max_episode_steps=None, max_episode_seconds=None, device="cuda", seed=1234):
+        """continuous_mountain_car_editted.py:154-159"""
+        if max_episode_seconds is not None:
+            raise NotImplementedError("max_episode_seconds is not supported")
+        env = cls(power_scalar, max_episode_steps=max_episode_steps or 0, device=device, seed=seed)
+        env.spec = EnvSpec(env.get_name(), max_episode_steps)
+        return env
+
+
+def make(env_id, device="cuda", seed=1234):
+    """``gym.make`` for the ids the reference uses (DDPG_Baselines_agent.py:293-294 ...)."""
+    return SingleEnvView(VecEnv(env_id, 1, device=device, seed=seed))

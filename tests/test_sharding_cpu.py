@@ -1,0 +1,76 @@
+"""The N>1 exchange path on CPU: world_size-2 gloo processes gather packed transition records
+to the learner rank and all-reduce the chunk statistics; plus the shard arithmetic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from smartstartcontinuous_amd.sharding import TransitionGather, record_bytes, shard_range
+
+
+def test_shard_ranges_cover_the_id_space():
+    for n, w in [(65536 * 8, 8), (10, 3), (7, 8), (1, 1), (524288, 6)]:
+        spans = [shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert record_bytes(2) == 25 and record_bytes(3) == 33
+
+
+class FakeChunk:
+    """A TransitionChunk-shaped object on the CPU with deterministic content per (rank, k, i)."""
+
+    def __init__(self, obs_dim, K, N, rank):
+        self.K, self.N, self.obs_dim = K, N, obs_dim
+        base = torch.arange(K * N, dtype=torch.float32).reshape(K, N) + 1000.0 * rank
+        self.obs = torch.stack([base + 0.25 * c for c in range(obs_dim)])
+        self.obs2 = self.obs + 0.5
+        self.act = -base
+        self.rew = base * 2
+        self.done = ((torch.arange(K * N).reshape(K, N) + rank) % 7 == 0).to(torch.uint8)
+
+
+def _worker(rank, world, port, obs_dim, g, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    K, N = 12, 37
+    tg = TransitionGather(obs_dim, g, N, world, rank, "cpu")
+    for it in range(3):
+        chunk = FakeChunk(obs_dim, K, N, rank)
+        chunk.act += it
+        stats = torch.tensor([1.5 * (rank + 1), rank, K * N, it], dtype=torch.float64)
+        tg.wait_buffer_free(it & 1)
+        tg.submit(chunk, it & 1, stats)
+    tg.finish()
+    ok = True
+    if rank == 0:
+        for src in range(world):
+            ref = FakeChunk(obs_dim, K, N, src)
+            ref.act += 2
+            obs, act, rew, obs2, done = tg.unpack(src)
+            ok &= torch.equal(obs, ref.obs[:, K - g:]) and torch.equal(obs2, ref.obs2[:, K - g:])
+            ok &= torch.equal(act, ref.act[K - g:]) and torch.equal(rew, ref.rew[K - g:])
+            ok &= torch.equal(done, ref.done[K - g:])
+    exp = torch.tensor([1.5 * sum(r + 1 for r in range(world)), sum(range(world)), world * K * N, 2 * world],
+                       dtype=torch.float64)
+    ok &= torch.equal(tg.global_stats, exp)
+    ok &= tg.chunks_gathered == 3
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("obs_dim,g", [(2, 3), (3, 12)])
+def test_gather_and_allreduce_world2_gloo(tmp_path, obs_dim, g):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, obs_dim, g, str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
