@@ -69,10 +69,40 @@ struct PendEnv {
 };
 
 // --------------------------------------------------------------------------- policies --
+// A Philox4x32-10 evaluation that can be advanced a few rounds at a time, so that the
+// (independent) RNG chain of the NEXT 4-step group is interleaved with the serial dynamics
+// chain of the current steps: at 65 536 envs there is one wave per SIMD and instruction-level
+// parallelism is the only latency hiding available (DESIGN.md "rollout kernel").
+struct PhiloxPipe {
+    uint32_t c0, c1, c2, c3, k0, k1;
+    __device__ __forceinline__ void start(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t tag) {
+        c0 = (uint32_t)env_id; c1 = (uint32_t)(env_id >> 32);
+        c2 = (uint32_t)t; c3 = (uint32_t)(((t >> 32) << 8) | tag);
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+    }
+    template <int R>
+    __device__ __forceinline__ void rounds() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+            const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+            const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+            c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+    }
+    // Keeps the rounds issued so far in the basic block where they were written (the optimiser
+    // would otherwise sink the whole evaluation to its single use at the end of the group).
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)); }
+    __device__ __forceinline__ u32x4 get() const { return u32x4{c0, c1, c2, c3}; }
+};
+
 // Policy_Random.get_action = U(low, high)  (NN_Dynamics_Model/policy_random.py:14-15).
 // One Philox call serves 4 consecutive steps: counter t>>2, word t&3.
 template <int OBS>
 struct RandomPolicy {
+    static constexpr bool kPipelined = true;
     u32x4 cache;
     float low, span;
     __device__ void init(const PolicyArgs &pa, const RolloutArgs &, int64_t) { low = pa.act_low; span = pa.act_span; }
@@ -80,6 +110,7 @@ struct RandomPolicy {
         if (first || (t & 3) == 0) cache = rng_words(seed, env_id, t >> 2, TAG_ACTION);  // wave-uniform branch
         return uniform_f32(pick(cache, (uint32_t)(t & 3)), low, span);
     }
+    __device__ float from_word(uint32_t w) const { return uniform_f32(w, low, span); }
     __device__ void on_reset() {}
     __device__ void store(const RolloutArgs &, int64_t) const {}
 };
@@ -91,6 +122,7 @@ struct RandomPolicy {
 // One Philox call serves the gaussians of 2 consecutive steps: counter t>>1.
 template <class Net, int OBS>
 struct ActorPolicy {
+    static constexpr bool kPipelined = false;
     Net net;
     u32x4 cache;
     float ou_x, mu, sig_sqrt_dt, theta_dt, eps;
@@ -124,6 +156,7 @@ struct ActorPolicy {
         a = fminf(fmaxf(a, -1.0f), 1.0f);  // ddpg_editted.py:271 (action_range = (-1, 1))
         return scale(scale(a));
     }
+    __device__ float from_word(uint32_t) const { return 0.0f; }
     __device__ void on_reset() { ou_x = 0.0f; }  // DDPG_Baselines_agent.end_episode -> noise reset (:255-258)
     __device__ void store(const RolloutArgs &ra, int64_t i) const {
         if (ra.st.ou_x != nullptr) ra.st.ou_x[i] = ou_x;
@@ -131,89 +164,138 @@ struct ActorPolicy {
 };
 
 // ----------------------------------------------------------------------------- kernel --
-template <class EnvT, class PolT>
-__global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec, PolicyArgs pa, RolloutArgs ra) {
-    constexpr int OBS = EnvT::OBS;
-    const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool active = gi < ra.n;
-    const int64_t i = active ? gi : ra.n - 1;  // inactive lanes shadow the last env, never store
-    const uint64_t env_id = ra.env_id0 + (uint64_t)i;
-    const int64_t n = ra.n;
-
+// Per-thread rollout state + the one-step body shared by the generic and the pipelined loop.
+template <class EnvT, class PolT, bool LOG>
+struct Rollout {
+    static constexpr int OBS = EnvT::OBS;
+    const typename EnvT::Const &ec;
+    const RolloutArgs &ra;
     EnvT env;
-    env.load(ra.st.s0[i], ra.st.s1[i]);
-    int32_t el = ra.st.steps[i];
-    float ep_ret = ra.st.ep_ret[i];
     PolT pol;
-    pol.init(pa, ra, i);
-
     float obs[OBS];
-    env.observe(obs);
-    float sum_r = 0.0f;
-    int32_t n_goal = 0, n_eps = 0;
+    int32_t el;
+    float ep_ret, sum_r;
+    int32_t n_goal, n_eps;
+    uint64_t env_id;
+    uint32_t voff;  // byte offset of this env inside a log row (fp32 columns); row bases are wave-uniform
+    bool active;
+
+    __device__ __forceinline__ Rollout(const typename EnvT::Const &ec_, const RolloutArgs &ra_) : ec(ec_), ra(ra_) {}
+
+    // Everything after the action is chosen: env.step, bookkeeping, log row k, rare reset path.
+    // Inactive lanes of a ragged last wave shadow env n-1 and store the same values to the same
+    // addresses as its owner -- benign, and it keeps the hot loop free of exec-mask branches.
+    __device__ __forceinline__ void step(float a, int32_t k) {
+        float rew;
+        bool goal;
+        float obs2[OBS];
+        env.step(ec, a, rew, goal);
+        env.observe(obs2);
+        el += 1;
+        // bitwise, not short-circuit: no exec-mask region in the hot loop
+        const bool done = goal | ((ec.max_episode_steps > 0) & (el >= ec.max_episode_steps));
+        ep_ret += rew;
+        sum_r += rew;
+        n_goal += goal ? 1 : 0;
+        if (LOG) {
+            const int64_t row = (int64_t)k * ra.n;  // wave-uniform
+#pragma unroll
+            for (int c = 0; c < OBS; ++c)
+                __builtin_nontemporal_store(obs[c], (float *)((char *)(ra.log.obs[c] + row) + voff));
+            __builtin_nontemporal_store(a, (float *)((char *)(ra.log.act + row) + voff));
+            __builtin_nontemporal_store(rew, (float *)((char *)(ra.log.rew + row) + voff));
+            __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), ra.log.done + row + (voff >> 2));
+#pragma unroll
+            for (int c = 0; c < OBS; ++c)
+                __builtin_nontemporal_store(obs2[c], (float *)((char *)(ra.log.obs2[c] + row) + voff));
+        }
+#pragma unroll
+        for (int c = 0; c < OBS; ++c) obs[c] = obs2[c];
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(done) != 0, 0)) {  // wave-uniform, rare
+            if (done) {
+                if (ra.has_ring && active) {
+                    const uint32_t slot = atomicAdd(ra.ring.cursor, 1u);
+                    if (slot < (uint32_t)ra.ring.capacity) {
+                        ra.ring.env_id[slot] = (int64_t)env_id;
+                        ra.ring.length[slot] = el;
+                        ra.ring.ret[slot] = ep_ret;
+                    }
+                }
+                n_eps += 1;
+                env.reset(ec, rng_words(ra.seed, env_id, ra.step0 + (uint64_t)k, TAG_RESET));
+                el = 0;
+                ep_ret = 0.0f;
+                pol.on_reset();
+                env.observe(obs);
+            }
+        }
+    }
+};
+
+template <class EnvT, class PolT, bool LOG>
+__global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec, PolicyArgs pa, RolloutArgs ra) {
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    Rollout<EnvT, PolT, LOG> r(ec, ra);
+    r.active = gi < ra.n;
+    const int64_t i = r.active ? gi : ra.n - 1;
+    r.env_id = ra.env_id0 + (uint64_t)i;
+    r.voff = (uint32_t)i * 4u;
+
+    r.env.load(ra.st.s0[i], ra.st.s1[i]);
+    r.el = ra.st.steps[i];
+    r.ep_ret = ra.st.ep_ret[i];
+    r.pol.init(pa, ra, i);
+    r.env.observe(r.obs);
+    r.sum_r = 0.0f;
+    r.n_goal = 0;
+    r.n_eps = 0;
 
     // Retire the state loads HERE.  Otherwise hipcc places their s_waitcnt vmcnt(N) inside the
     // loop, where vmcnt also counts the log stores: every iteration would then wait for the
     // previous iteration's stores to land (0x0F70 = vmcnt(0), expcnt/lgkmcnt untouched).
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
-    for (int32_t k = 0; k < ra.K; ++k) {
-        const uint64_t t = ra.step0 + (uint64_t)k;
-        const float a = pol.act(obs, ra.seed, env_id, t, k == 0);
-        float rew;
-        bool goal;
-        env.step(ec, a, rew, goal);
-        float obs2[OBS];
-        env.observe(obs2);
-        el += 1;
-        const bool done = goal || (ec.max_episode_steps > 0 && el >= ec.max_episode_steps);
-        ep_ret += rew;
-        sum_r += rew;
-        n_goal += goal ? 1 : 0;
-
-        if (ra.has_log && active) {
-            const int64_t off = (int64_t)k * n + i;
-#pragma unroll
-            for (int c = 0; c < OBS; ++c) __builtin_nontemporal_store(obs[c], ra.log.obs[c] + off);
-            __builtin_nontemporal_store(a, ra.log.act + off);
-            __builtin_nontemporal_store(rew, ra.log.rew + off);
-            __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), ra.log.done + off);
-#pragma unroll
-            for (int c = 0; c < OBS; ++c) __builtin_nontemporal_store(obs2[c], ra.log.obs2[c] + off);
-        }
-
-        if (done) {
-            if (ra.has_ring && active) {
-                const uint32_t slot = atomicAdd(ra.ring.cursor, 1u);
-                if (slot < (uint32_t)ra.ring.capacity) {
-                    ra.ring.env_id[slot] = (int64_t)env_id;
-                    ra.ring.length[slot] = el;
-                    ra.ring.ret[slot] = ep_ret;
-                }
+    int32_t k = 0;
+    if constexpr (PolT::kPipelined) {
+        // head: single steps until the global step index is a multiple of 4
+        for (; k < ra.K && ((ra.step0 + (uint64_t)k) & 3) != 0; ++k)
+            r.step(r.pol.act(r.obs, ra.seed, r.env_id, ra.step0 + (uint64_t)k, k == 0), k);
+        if (k + 4 <= ra.K) {
+            u32x4 cur = rng_words(ra.seed, r.env_id, (ra.step0 + (uint64_t)k) >> 2, TAG_ACTION);
+            for (; k + 4 <= ra.K; k += 4) {
+                PhiloxPipe nx;
+                nx.start(ra.seed, r.env_id, ((ra.step0 + (uint64_t)k) >> 2) + 1, TAG_ACTION);
+                nx.rounds<3>(); nx.pin();
+                r.step(r.pol.from_word(cur.x), k);
+                nx.rounds<3>(); nx.pin();
+                r.step(r.pol.from_word(cur.y), k + 1);
+                nx.rounds<2>(); nx.pin();
+                r.step(r.pol.from_word(cur.z), k + 2);
+                nx.rounds<2>(); nx.pin();
+                r.step(r.pol.from_word(cur.w), k + 3);
+                cur = nx.get();
             }
-            n_eps += 1;
-            env.reset(ec, rng_words(ra.seed, env_id, t, TAG_RESET));
-            el = 0;
-            ep_ret = 0.0f;
-            pol.on_reset();
-            env.observe(obs);
-        } else {
-#pragma unroll
-            for (int c = 0; c < OBS; ++c) obs[c] = obs2[c];
         }
+        // tail (< 4 steps)
+        const int32_t k_tail = k;
+        for (; k < ra.K; ++k)
+            r.step(r.pol.act(r.obs, ra.seed, r.env_id, ra.step0 + (uint64_t)k, k == k_tail), k);
+    } else {
+        for (; k < ra.K; ++k)
+            r.step(r.pol.act(r.obs, ra.seed, r.env_id, ra.step0 + (uint64_t)k, k == 0), k);
     }
 
-    if (active) {
-        ra.st.s0[i] = env.s0();
-        ra.st.s1[i] = env.s1();
-        ra.st.steps[i] = el;
-        ra.st.ep_ret[i] = ep_ret;
-        pol.store(ra, i);
+    if (r.active) {
+        ra.st.s0[i] = r.env.s0();
+        ra.st.s1[i] = r.env.s1();
+        ra.st.steps[i] = r.el;
+        ra.st.ep_ret[i] = r.ep_ret;
+        r.pol.store(ra, i);
     }
 
     if (ra.stats != nullptr) {
-        double v[4] = {active ? (double)sum_r : 0.0, active ? (double)n_goal : 0.0,
-                       active ? (double)ra.K : 0.0, active ? (double)n_eps : 0.0};
+        double v[4] = {r.active ? (double)r.sum_r : 0.0, r.active ? (double)r.n_goal : 0.0,
+                       r.active ? (double)ra.K : 0.0, r.active ? (double)r.n_eps : 0.0};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -236,7 +318,12 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec
 template <class EnvT, class PolT>
 static int launch_rollout(const typename EnvT::Const &ec, const PolicyArgs &pa, const RolloutArgs &ra,
                           hipStream_t stream) {
-    hipLaunchKernelGGL((rollout_kernel<EnvT, PolT>), dim3(blocks_for(ra.n)), dim3(kBlock), 0, stream, ec, pa, ra);
+    if (ra.has_log)
+        hipLaunchKernelGGL((rollout_kernel<EnvT, PolT, true>), dim3(blocks_for(ra.n)), dim3(kBlock), 0, stream, ec,
+                           pa, ra);
+    else
+        hipLaunchKernelGGL((rollout_kernel<EnvT, PolT, false>), dim3(blocks_for(ra.n)), dim3(kBlock), 0, stream, ec,
+                           pa, ra);
     return check_launch("ssc_rollout");
 }
 
@@ -280,6 +367,7 @@ extern "C" int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *polic
                            uint64_t step0, ssc_stream_t stream) {
     SSC_REQUIRE(p && policy && state, "ssc_rollout: NULL descriptor");
     SSC_REQUIRE(n >= 0 && K >= 0, "ssc_rollout: n = %lld, K = %d", (long long)n, K);
+    SSC_REQUIRE(n <= ((int64_t)1 << 30), "ssc_rollout: n = %lld > 2^30 envs per launch", (long long)n);
     SSC_REQUIRE(policy->kind == SSC_POLICY_RANDOM || policy->kind == SSC_POLICY_ACTOR,
                 "ssc_rollout: unknown policy kind %d", policy->kind);
     if (n == 0 || K == 0) return SSC_OK;

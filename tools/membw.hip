@@ -1,0 +1,119 @@
+// Write-bandwidth ceilings on MI355X for the store shapes the rollout kernel can use.
+// build: hipcc -O3 --offload-arch=gfx950 tools/membw.hip -o gpurun_out/membw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+// each thread = one column i of a [K][n] array, writes K rows (the rollout's access pattern)
+template <int NT, typename T>
+__global__ __launch_bounds__(256) void col_writer(T *__restrict__ p, int64_t n, int K, int ncols) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < K; ++k)
+        for (int c = 0; c < ncols; ++c) {
+            T v;
+            if constexpr (sizeof(T) == 4) v = (T)(k + c);
+            else if constexpr (sizeof(T) == 1) v = (T)(k);
+            else { v = T{(float)k, (float)c, 0.f, 1.f}; }
+            T *dst = p + ((int64_t)c * K + k) * n + i;
+            if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
+        }
+}
+
+// rollout-like mix: 6 float columns + 1 byte column
+template <int NT, int BYTE>
+__global__ __launch_bounds__(256) void mix_writer(float *__restrict__ p, uint8_t *__restrict__ b, int64_t n, int K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < K; ++k) {
+        for (int c = 0; c < 6; ++c) {
+            float *dst = p + ((int64_t)c * K + k) * n + i;
+            if (NT) __builtin_nontemporal_store((float)(k + c), dst); else *dst = (float)(k + c);
+        }
+        if (BYTE) {
+            uint8_t *d = b + (int64_t)k * n + i;
+            if (NT) __builtin_nontemporal_store((uint8_t)k, d); else *d = (uint8_t)k;
+        }
+    }
+}
+
+// packed rows: [K][6][n] floats (one contiguous 6*n*4-byte region per step) + done [K][n]
+template <int NT, int BYTE, int DONE_PACK>
+__global__ __launch_bounds__(256) void packed_writer(float *__restrict__ p, uint8_t *__restrict__ b, int64_t n, int K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < K; ++k) {
+        for (int c = 0; c < 6; ++c) {
+            float *dst = p + ((int64_t)k * 6 + c) * n + i;
+            if (NT) __builtin_nontemporal_store((float)(k + c), dst); else *dst = (float)(k + c);
+        }
+        if (BYTE) {
+            if (DONE_PACK) {
+                // one dword store per 4 steps: lane L writes bytes of envs 4*(L&15)..+3 of step (k&~3)+(L>>4)
+                if ((k & 3) == 3) {
+                    const int lane = threadIdx.x & 63;
+                    const int64_t wave_base = i - lane;
+                    uint32_t *d = (uint32_t *)(b + (int64_t)((k & ~3) + (lane >> 4)) * n + wave_base) + (lane & 15);
+                    if (NT) __builtin_nontemporal_store((uint32_t)k, d); else *d = (uint32_t)k;
+                }
+            } else {
+                uint8_t *d = b + (int64_t)k * n + i;
+                if (NT) __builtin_nontemporal_store((uint8_t)k, d); else *d = (uint8_t)k;
+            }
+        }
+    }
+}
+
+// grid-stride f4 fill (the classic streaming-store ceiling)
+template <int NT>
+__global__ __launch_bounds__(256) void fill4(f4 *__restrict__ p, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f4 v = {1.f, 2.f, 3.f, 4.f};
+        if (NT) __builtin_nontemporal_store(v, p + i); else p[i] = v;
+    }
+}
+
+template <typename F>
+float time_ms(F f, int reps = 10) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); f(); hipDeviceSynchronize();
+    std::vector<float> t;
+    for (int r = 0; r < reps; ++r) { hipEventRecord(a); f(); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); t.push_back(ms); }
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+}
+
+int main() {
+    const size_t bytes = (size_t)2 << 30;
+    float *p; uint8_t *b;
+    CK(hipMalloc(&p, bytes)); CK(hipMalloc(&b, (size_t)256 << 20));
+    const int64_t n4 = bytes / 16;
+    float ms;
+    ms = time_ms([&] { fill4<0><<<2048, 256>>>((f4 *)p, n4); }); printf("fill4 plain grid2048 : %.1f GB/s\n", bytes / ms / 1e6);
+    ms = time_ms([&] { fill4<1><<<2048, 256>>>((f4 *)p, n4); }); printf("fill4 nt    grid2048 : %.1f GB/s\n", bytes / ms / 1e6);
+    ms = time_ms([&] { fill4<1><<<256, 256>>>((f4 *)p, n4); });  printf("fill4 nt    grid256  : %.1f GB/s\n", bytes / ms / 1e6);
+    for (int64_t n : {65536, 262144}) {
+        const int K = (int)(1024 * 65536 / n);
+        const double gb6 = 6.0 * 4 * n * K, gb = gb6 + (double)n * K;
+        ms = time_ms([&] { col_writer<0, float><<<n / 256, 256>>>(p, n, K, 6); }); printf("n=%ld 6xdword plain : %.1f GB/s\n", (long)n, gb6 / ms / 1e6);
+        ms = time_ms([&] { col_writer<1, float><<<n / 256, 256>>>(p, n, K, 6); }); printf("n=%ld 6xdword nt    : %.1f GB/s\n", (long)n, gb6 / ms / 1e6);
+        ms = time_ms([&] { mix_writer<1, 1><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld 6xdword+byte nt : %.1f GB/s\n", (long)n, gb / ms / 1e6);
+        ms = time_ms([&] { mix_writer<0, 1><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld 6xdword+byte plain : %.1f GB/s\n", (long)n, gb / ms / 1e6);
+        ms = time_ms([&] { packed_writer<1, 0, 0><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld packed rows 6xdword nt : %.1f GB/s\n", (long)n, gb6 / ms / 1e6);
+        ms = time_ms([&] { packed_writer<0, 0, 0><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld packed rows 6xdword plain : %.1f GB/s\n", (long)n, gb6 / ms / 1e6);
+        ms = time_ms([&] { packed_writer<1, 1, 0><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld packed rows + byte nt : %.1f GB/s\n", (long)n, gb / ms / 1e6);
+        ms = time_ms([&] { packed_writer<0, 1, 0><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld packed rows + byte plain : %.1f GB/s\n", (long)n, gb / ms / 1e6);
+        ms = time_ms([&] { packed_writer<1, 1, 1><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld packed rows + done-as-dword/4steps nt : %.1f GB/s\n", (long)n, gb / ms / 1e6);
+        ms = time_ms([&] { packed_writer<0, 1, 1><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld packed rows + done-as-dword/4steps plain : %.1f GB/s\n", (long)n, gb / ms / 1e6);
+        // same bytes as f4 columns: n/4 threads... emulate "4 envs per lane" = 16 B per lane, 1.5 columns of f4
+        const int64_t nq = n / 4;
+        ms = time_ms([&] { col_writer<1, f4><<<nq / 256, 256>>>((f4 *)p, nq, K, 6); }); printf("n=%ld 6xdwordx4 nt (n/4 threads) : %.1f GB/s\n", (long)n, gb6 / ms / 1e6);
+        ms = time_ms([&] { col_writer<1, f4><<<n / 256, 256>>>((f4 *)p, n, K / 4, 6); }); printf("n=%ld 6xdwordx4 nt (n threads, K/4 rows) : %.1f GB/s\n", (long)n, gb6 / ms / 1e6);
+    }
+    return 0;
+}

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (tools/profile_bench.sh) into the small files
+committed under profiles/: kernel stats CSV, per-kernel PMC averages, and the bench line."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+pmc = {}
+for tag in ("write", "fetch"):
+    for f in glob.glob(os.path.join(src, f"pmc_{tag}", "*", "*_counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in agg.items():
+            pmc.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+json.dump(pmc, open(os.path.join(dst, "pmc_per_kernel.json"), "w"), indent=1)
+bj = os.path.join(src, "bench.json")
+if os.path.exists(bj):
+    shutil.copy(bj, os.path.join(dst, "bench.json"))
+    b = json.loads(open(bj).read().strip().splitlines()[-1])
+    k = [v for name, v in pmc.items() if "rollout_kernel" in name]
+    if k:
+        w = k[0].get("WRITE_SIZE", {}).get("mean", 0) * 1024
+        r = k[0].get("FETCH_SIZE", {}).get("mean", 0) * 1024 * 2   # gfx950: FETCH_SIZE reads 1/2 (MI355X_MICROARCH.md HBM)
+        alg = b["roofline"]["algorithmic_bytes_per_launch"]
+        print("rollout kernel: WRITE_SIZE %.4g B, FETCH_SIZE(x2) %.4g B, algorithmic %.4g B, traffic/alg = %.4f"
+              % (w, r, alg, (w + r) / alg))
+        json.dump({"write_bytes": w, "fetch_bytes_corrected": r, "algorithmic_bytes": alg,
+                   "traffic_over_algorithmic": (w + r) / alg}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, "kernel_stats.csv")).read()[:600])
