@@ -1,0 +1,198 @@
+"""GPU parity tests: DDPG actor forward (fp32 VALU + bf16 MFMA), the fused actor rollout
+(BASELINE config 3) and the Pendulum kernels, all through the C ABI and against the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import ssc_oracle as O
+from tests.gpu_util import actor_weights
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL_ACT_F32 = 1e-5     # fp32 kernel vs fp64 oracle, abs on actions
+TOL_ACT_BF16 = 2e-2    # bf16 MFMA kernel vs fp32/fp64
+TOL_ACT_BF16_EMU = 1.5e-3  # vs the oracle's own bf16 emulation: equal except where a hidden activation sits on a
+                         # bf16 rounding boundary and fp32/fp64 evaluation rounds it to different neighbours
+
+
+@pytest.fixture(scope="module")
+def ssc():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no fallback")
+    import smartstartcontinuous_amd as pkg
+    pkg._ffi.lib()
+    return pkg
+
+
+def _actor_forward_gpu(ssc, w, obs, precision, last_layer_tanh=True, act_dim=1):
+    ffi = ssc._ffi
+    d = {k: torch.as_tensor(v, device="cuda").contiguous() for k, v in w.items()}
+    a = ffi.ActorDesc()
+    a.obs_dim, a.h1 = w["W1"].shape
+    a.h2, a.act_dim = w["W2"].shape[1], act_dim
+    a.W1, a.b1, a.W2, a.b2, a.W3, a.b3 = (d[k].data_ptr() for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
+    a.last_layer_tanh, a.precision = int(last_layer_tanh), precision
+    o = torch.as_tensor(obs, dtype=torch.float32, device="cuda").contiguous()
+    out = torch.empty((o.shape[0], act_dim), dtype=torch.float32, device="cuda")
+    ffi.check(ffi.lib().ssc_actor_forward(ctypes.byref(a), o.shape[0], ffi.ptr(o), ffi.ptr(out), None))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("obs_dim", [2, 3])
+@pytest.mark.parametrize("llt", [True, False])
+def test_actor_forward_f32_and_mfma(ssc, obs_dim, llt):
+    ffi = ssc._ffi
+    rng = np.random.default_rng(10 + obs_dim)
+    for (h1, h2) in [(64, 32), (128, 64), (48, 24)]:
+        w = actor_weights(obs_dim, h1, h2, seed=h1 + obs_dim, w3_scale=0.3)
+        for m in (1, 63, 1000, 4096 + 17):
+            obs = rng.uniform(-1.2, 1.2, size=(m, obs_dim)).astype(np.float32)
+            ref = O.actor_forward(obs, **w, last_layer_tanh=llt)
+            got = _actor_forward_gpu(ssc, w, obs, ffi.SSC_PREC_F32, llt)
+            assert np.max(np.abs(got - ref)) <= TOL_ACT_F32, (h1, h2, m)
+            got_b = _actor_forward_gpu(ssc, w, obs, ffi.SSC_PREC_BF16_MFMA, llt)
+            assert np.max(np.abs(got_b - ref)) <= TOL_ACT_BF16, (h1, h2, m)
+            emu = O.actor_forward_bf16emu(obs, **w, last_layer_tanh=llt)
+            assert np.max(np.abs(got_b - emu)) <= TOL_ACT_BF16_EMU, (h1, h2, m)
+
+
+def test_actor_forward_generic_sizes(ssc):
+    """200-100 (hidden_layer_size_experiment) and multi-action heads through the generic fp32 kernel."""
+    ffi = ssc._ffi
+    rng = np.random.default_rng(5)
+    w = actor_weights(2, 200, 100, seed=3, w3_scale=0.2)
+    obs = rng.uniform(-1, 1, size=(777, 2)).astype(np.float32)
+    got = _actor_forward_gpu(ssc, w, obs, ffi.SSC_PREC_F32)
+    assert np.max(np.abs(got - O.actor_forward(obs, **w))) <= TOL_ACT_F32
+    w = actor_weights(4, 64, 32, seed=4, w3_scale=0.2)
+    w["W3"] = rng.uniform(-0.2, 0.2, size=(32, 3)).astype(np.float32)
+    w["b3"] = rng.uniform(-0.1, 0.1, size=3).astype(np.float32)
+    obs = rng.uniform(-1, 1, size=(130, 4)).astype(np.float32)
+    got = _actor_forward_gpu(ssc, w, obs, ffi.SSC_PREC_F32, act_dim=3)
+    assert got.shape == (130, 3) and np.max(np.abs(got - O.actor_forward(obs, **w))) <= TOL_ACT_F32
+
+
+def test_mfma_layout_with_asymmetric_weights(ssc):
+    """A=I-style check: one-hot weights expose any row/col or k-permutation mix-up exactly."""
+    ffi = ssc._ffi
+    h1, h2 = 64, 32
+    for trial in range(4):
+        rng = np.random.default_rng(trial)
+        w = dict(W1=np.zeros((2, h1), np.float32), b1=np.zeros(h1, np.float32), W2=np.zeros((h1, h2), np.float32),
+                 b2=np.zeros(h2, np.float32), W3=np.zeros((h2, 1), np.float32), b3=np.zeros(1, np.float32))
+        u, j = int(rng.integers(h1)), int(rng.integers(h2))
+        w["W1"][trial % 2, u] = 1.0          # hidden unit u copies obs component
+        w["W2"][u, j] = 0.5                  # exactly representable in bf16
+        w["W3"][j, 0] = 1.0
+        obs = rng.uniform(0.1, 1.0, size=(64 * 3, 2)).astype(np.float32)
+        got = _actor_forward_gpu(ssc, w, obs, ffi.SSC_PREC_BF16_MFMA, last_layer_tanh=False)
+        ref = np.tanh(0.5 * O.round_bf16(obs[:, trial % 2]).astype(np.float64))[:, None]
+        assert np.max(np.abs(got - ref)) < 1e-6, (trial, u, j)
+
+
+def _log(chunk):
+    return dict(obs=chunk.obs.cpu().numpy(), act=chunk.act.cpu().numpy(), rew=chunk.rew.cpu().numpy(),
+                done=chunk.done.cpu().numpy(), obs2=chunk.obs2.cpu().numpy())
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("bf16_mfma", TOL_ACT_BF16)])
+def test_rollout_actor_mountaincar_teacher_forced(ssc, precision, tol):
+    """BASELINE config 3 at test size: actor 64-32 + OU noise fused with the step."""
+    n, K, seed, id0 = 1000, 50, 1234, 77
+    w = actor_weights(2, 64, 32, seed=1234, w3_scale=0.5)
+    env = ssc.VecEnv("MountainCarContinuous-v0", n, seed=seed, env_id0=id0)
+    obs0 = env.reset().cpu().numpy()
+    env.steps.fill_(970)           # time-limit reset (and OU reset) inside the window
+    env.t = 3                      # odd, unaligned start
+    pol = ssc.ActorPolicy({k: torch.as_tensor(v) for k, v in w.items()}, precision=precision)
+    chunk = env.rollout(K, pol)
+    torch.cuda.synchronize()
+    oracle_pol = O.OracleDDPGPolicy(w, seed, id0, n, bf16=False)
+    res = O.replay_rollout("mc", _log(chunk), seed, id0, 3, 999, obs0, np.full(n, 970), oracle_pol)
+    assert res["start_max_err"] == 0 and res["continuity_mismatch"] == 0 and res["done_mismatch"] == 0, res
+    assert res["max_dact"] <= tol, res
+    assert res["max_dobs2"][0] <= 2.4e-7 and res["max_dobs2"][1] <= 1e-8, res
+    assert res["max_drew_rel"] <= 1e-6 and res["reset_max_err"] == 0, res
+    # OU state written back == the oracle's (fp64) state
+    assert np.max(np.abs(env.ou_x.cpu().numpy() - oracle_pol.x)) < 2e-5
+    if precision == "bf16_mfma":
+        emu = O.OracleDDPGPolicy(w, seed, id0, n, bf16=True)
+        res = O.replay_rollout("mc", _log(chunk), seed, id0, 3, 999, obs0, np.full(n, 970), emu)
+        assert res["max_dact"] <= TOL_ACT_BF16_EMU, res
+
+
+def test_rollout_actor_without_noise_equals_actor_forward(ssc):
+    n, K = 320, 9
+    w = actor_weights(2, 64, 32, seed=9, w3_scale=0.5)
+    env = ssc.VecEnv("MountainCarContinuous-v0", n, seed=5)
+    env.reset()
+    pol = ssc.ActorPolicy({k: torch.as_tensor(v) for k, v in w.items()}, precision="f32", ou_epsilon=0.0)
+    chunk = env.rollout(K, pol)
+    torch.cuda.synchronize()
+    obs = chunk.obs.cpu().numpy().transpose(1, 2, 0).reshape(-1, 2)
+    ref = np.clip(O.actor_forward(obs, **w)[:, 0], -1, 1)
+    assert np.max(np.abs(chunk.act.cpu().numpy().reshape(-1) - ref)) <= TOL_ACT_F32
+
+
+# ------------------------------------------------------------------------- Pendulum --
+def test_pendulum_step_kernel(ssc):
+    ffi = ssc._ffi
+    rng = np.random.default_rng(8)
+    n = 1 << 18
+    th = rng.uniform(-30, 30, n).astype(np.float32)
+    thd = rng.uniform(-8, 8, n).astype(np.float32)
+    act = rng.uniform(-3, 3, n).astype(np.float32)
+    for v1 in (0, 1):
+        p = ffi.default_params(ffi.SSC_ENV_PENDULUM, 1.0, 200)
+        p.pend_v1_order = v1
+        dt, dd, da = (torch.as_tensor(x.copy(), device="cuda") for x in (th, thd, act))
+        obs = torch.empty((3, n), dtype=torch.float32, device="cuda")
+        rew = torch.empty(n, dtype=torch.float32, device="cuda")
+        done = torch.empty(n, dtype=torch.uint8, device="cuda")
+        steps = torch.full((n,), 198, dtype=torch.int32, device="cuda")
+        steps[: n // 2] = 199
+        ffi.check(ffi.lib().ssc_pend_step(ctypes.byref(p), n, ffi.ptr(dt), ffi.ptr(dd), ffi.ptr(da), ffi.ptr(obs),
+                                          ffi.ptr(rew), ffi.ptr(done), ffi.ptr(steps), None))
+        torch.cuda.synchronize()
+        rt, rd, rr, _ = O.pend_step(th, thd, act, v1_order=bool(v1))
+        assert np.max(np.abs(dt.cpu().numpy() - rt)) <= 4e-6
+        assert np.max(np.abs(dd.cpu().numpy() - rd)) <= 2e-6
+        assert np.max(np.abs(rew.cpu().numpy() - rr) / np.maximum(1, np.abs(rr))) <= 2e-5
+        o = obs.cpu().numpy()
+        assert np.max(np.abs(o[0] - np.cos(rt))) <= 5e-6 and np.max(np.abs(o[1] - np.sin(rt))) <= 5e-6
+        assert np.array_equal(o[2], dd.cpu().numpy())
+        d = done.cpu().numpy()
+        assert d[: n // 2].all() and not d[n // 2:].any()       # TimeLimit(200) only
+
+
+@pytest.mark.parametrize("policy", ["random", "actor_f32", "actor_mfma"])
+def test_rollout_pendulum_teacher_forced(ssc, policy):
+    n, K, seed, id0 = 777, 40, 4321, 5
+    env = ssc.VecEnv("Pendulum-v0", n, seed=seed, env_id0=id0)
+    assert env.obs_dim == 3 and env.spec.max_episode_steps == 200 and env.action_space.high[0] == 2.0
+    obs0 = env.reset().cpu().numpy()
+    rt, rd = O.pend_reset_state(seed, np.uint64(id0) + np.arange(n, dtype=np.uint64), O.RESET_T0)
+    assert np.max(np.abs(obs0[:, 0] - np.cos(rt.astype(np.float64)))) < 2e-6 and np.array_equal(obs0[:, 2], rd)
+    env.steps.fill_(180)
+    env.t = 2
+    if policy == "random":
+        pol, oracle_pol, tol = ssc.RandomPolicy(), O.OracleRandomPolicy(seed, id0, n, -2.0, 2.0), 0.0
+    else:
+        w = actor_weights(3, 64, 32, seed=21, w3_scale=0.5)
+        prec = "f32" if policy == "actor_f32" else "bf16_mfma"
+        pol = ssc.ActorPolicy({k: torch.as_tensor(v) for k, v in w.items()}, precision=prec)
+        oracle_pol = O.OracleDDPGPolicy(w, seed, id0, n, low=-2.0, high=2.0)
+        tol = 4e-5 if prec == "f32" else 2 * TOL_ACT_BF16
+    chunk = env.rollout(K, pol)
+    torch.cuda.synchronize()
+    res = O.replay_rollout("pend", _log(chunk), seed, id0, 2, 200, obs0, np.full(n, 180), oracle_pol)
+    assert res["start_max_err"] == 0 and res["continuity_mismatch"] == 0 and res["done_mismatch"] == 0, res
+    assert res["max_dact"] <= tol, res
+    assert (res["max_dobs2"] <= [3e-6, 3e-6, 3e-6]).all(), res
+    assert res["max_drew_rel"] <= 2e-5 and res["reset_max_err"] <= 2e-6, res
+    log = _log(chunk)
+    assert (log["done"][19] == 1).all() and log["done"].sum() == n           # 180 + 20 = 200
+    assert abs(env.stats.cpu().numpy()[0] - log["rew"].astype(np.float64).sum()) < 0.5

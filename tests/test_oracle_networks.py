@@ -1,0 +1,127 @@
+"""Parity-unpinned parts of the oracle (actor, critic, dynamics MLP, forward sim, OU, Pendulum):
+the reference needs TensorFlow 1.5 / gym and ships no fixture for them, so the restatement is
+cross-checked structurally against independent torch-CPU fp64 implementations."""
+import ctypes
+
+import numpy as np
+import torch
+
+from oracle import ssc_oracle as O
+from tests.gpu_util import actor_weights
+
+
+def _lin(W, b):
+    lin = torch.nn.Linear(W.shape[0], W.shape[1]).double()
+    with torch.no_grad():
+        lin.weight.copy_(torch.as_tensor(W, dtype=torch.float64).t())   # TF [in,out] -> torch [out,in]
+        lin.bias.copy_(torch.as_tensor(b, dtype=torch.float64))
+    return lin
+
+
+def test_actor_matches_torch_stack():
+    rng = np.random.default_rng(0)
+    for (h1, h2, llt) in [(64, 32, True), (128, 64, False), (200, 100, True)]:
+        w = actor_weights(2, h1, h2, seed=h1, w3_scale=0.5)
+        obs = rng.uniform(-1, 1, size=(257, 2))
+        net = [_lin(w["W1"], w["b1"]), _lin(w["W2"], w["b2"]), _lin(w["W3"], w["b3"])]
+        x = torch.relu(net[0](torch.as_tensor(obs)))
+        x = net[1](x)
+        x = torch.tanh(x) if llt else torch.relu(x)
+        ref = torch.tanh(net[2](x)).detach().numpy()
+        got = O.actor_forward(obs, **w, last_layer_tanh=llt)
+        assert np.allclose(got, ref, rtol=0, atol=1e-14)
+        # bf16 emulation stays within the bf16 budget of the exact forward
+        emu = O.actor_forward_bf16emu(obs, **w, last_layer_tanh=llt)
+        assert np.max(np.abs(emu - got)) < 2e-2
+
+
+def test_critic_matches_torch_stack():
+    rng = np.random.default_rng(1)
+    W1, b1 = rng.normal(size=(2, 64)), rng.normal(size=64)
+    W2, b2 = rng.normal(size=(65, 32)) * 0.2, rng.normal(size=32)
+    W3, b3 = rng.normal(size=(32, 1)) * 0.1, rng.normal(size=1)
+    obs, act = rng.normal(size=(50, 2)), rng.uniform(-1, 1, size=(50, 1))
+    x = torch.relu(_lin(W1, b1)(torch.as_tensor(obs)))
+    x = torch.tanh(_lin(W2, b2)(torch.cat([x, torch.as_tensor(act)], dim=-1)))
+    ref = _lin(W3, b3)(x).detach().numpy()
+    assert np.allclose(O.critic_forward(obs, act, W1, b1, W2, b2, W3, b3), ref, atol=1e-13)
+
+
+def _mlp(rng, dims):
+    Ws = [rng.normal(size=(dims[i], dims[i + 1])) * np.sqrt(2.0 / (dims[i] + dims[i + 1])) for i in range(len(dims) - 1)]
+    bs = [rng.normal(size=dims[i + 1]) * 0.1 for i in range(len(dims) - 1)]
+    return Ws, bs
+
+
+def test_mlp_and_forward_sim(oracle_clib):
+    rng = np.random.default_rng(2)
+    for dims in [(3, 32, 2), (4, 500, 500, 3), (3, 500, 2)]:
+        Ws, bs = _mlp(rng, dims)
+        x = rng.normal(size=(33, dims[0]))
+        h = torch.as_tensor(x)
+        for W, b in zip(Ws[:-1], bs[:-1]):
+            h = torch.relu(_lin(W, b)(h))
+        ref = _lin(Ws[-1], bs[-1])(h).detach().numpy()
+        got = O.mlp_forward(x, Ws, bs)
+        assert np.allclose(got, ref, atol=1e-12)
+        # the C restatement
+        w = np.concatenate([W.reshape(-1) for W in Ws])
+        b = np.concatenate(bs)
+        y = np.empty((33, dims[-1]))
+        scratch = np.empty(2 * 33 * max(dims))
+        d32 = np.asarray(dims, np.int32)
+        dp = ctypes.POINTER(ctypes.c_double)
+        oracle_clib.ssc_oracle_mlp_forward(ctypes.c_int64(33), ctypes.c_int(len(dims) - 1),
+                                           d32.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), w.ctypes.data_as(dp),
+                                           b.ctypes.data_as(dp), np.ascontiguousarray(x).ctypes.data_as(dp),
+                                           y.ctypes.data_as(dp), scratch.ctypes.data_as(dp))
+        assert np.allclose(y, ref, atol=1e-12)
+    # forward sim == explicit loop; std==0 normalisation quirk (nan_to_num)
+    Ws, bs = _mlp(rng, (3, 32, 2))
+    norm = dict(mean_x=np.array([-0.5, 0.0]), std_x=np.array([0.2, 0.0]), mean_y=np.array([0.1]),
+                std_y=np.array([0.6]), mean_z=np.array([0.0, 0.0]), std_z=np.array([0.01, 0.001]))
+    A = rng.uniform(-1, 1, size=(17, 5, 1))
+    S = O.dyn_forward_sim(np.array([-0.5, 0.0]), A, norm, Ws, bs)
+    assert S.shape == (6, 17, 2) and np.all(S[0] == [-0.5, 0.0])
+    cur = np.tile([-0.5, 0.0], (17, 1))
+    for t in range(5):
+        xs = np.zeros_like(cur)
+        xs[:, 0] = (cur[:, 0] + 0.5) / 0.2
+        d = cur[:, 1] - 0.0
+        xs[:, 1] = np.where(d == 0, 0.0, np.sign(d) * np.finfo(np.float64).max)   # x/0 -> +-DBL_MAX, 0/0 -> 0
+        ys = (A[:, t] - 0.1) / 0.6
+        z = O.mlp_forward(np.concatenate([xs, ys], 1), Ws, bs)
+        cur = cur + z * norm["std_z"] + norm["mean_z"]
+        assert np.allclose(S[t + 1], cur, rtol=1e-12, atol=1e-300) or not np.isfinite(cur).all()
+
+
+def test_ou_and_action_path():
+    x = O.ou_step(np.array([0.0, 0.3]), np.array([1.0, -2.0]), 0.4, 0.6, 0.15, 1e-2)
+    assert np.allclose(x, [0.0 + 0.15 * 0.4 * 0.01 + 0.6 * 0.1 * 1.0, 0.3 + 0.15 * 0.1 * 0.01 - 0.6 * 0.1 * 2.0])
+    a = O.ddpg_action(np.array([0.9, -0.2]), np.array([0.5, 0.1]), 1.0)
+    assert np.allclose(a, [1.0, -0.1])
+    assert np.allclose(O.scale_action(np.array([-2.0, 0.0, 0.5]), -2.0, 2.0), [-2.0, 0.0, 1.0])
+    g = O.ou_gaussian(7, np.arange(200000, dtype=np.uint64), 5)
+    assert abs(g.mean()) < 0.01 and abs(g.std() - 1) < 0.01
+
+
+def test_pendulum_restatement_properties(oracle_clib):
+    rng = np.random.default_rng(3)
+    th, thd, a = rng.uniform(-10, 10, 1000), rng.uniform(-8, 8, 1000), rng.uniform(-3, 3, 1000)
+    t0, d0, r0, u = O.pend_step(th, thd, a)
+    t1, d1, r1, _ = O.pend_step(th, thd, a, v1_order=True)
+    assert np.all(np.abs(u) <= 2) and np.all(np.abs(d0) <= 8) and np.all(r0 <= 0)
+    unclipped = np.abs(d0) < 8
+    assert np.allclose(t0[unclipped], t1[unclipped]) and np.allclose(r0, r1)
+    # hanging straight down with zero torque is a fixed point of the angle dynamics' sign: gravity pulls to pi
+    t, d, r, _ = O.pend_step(np.array([np.pi]), np.array([0.0]), np.array([0.0]))
+    assert abs(d[0]) < 1e-14 and abs(r[0] + np.pi ** 2) < 1e-12
+    # C twin
+    ct, cd = th.copy(), thd.copy()
+    cr = np.empty(1000)
+    dp = ctypes.POINTER(ctypes.c_double)
+    oracle_clib.ssc_oracle_pend_step(ctypes.c_int64(1000), ct.ctypes.data_as(dp), cd.ctypes.data_as(dp),
+                                     a.ctypes.data_as(dp), ctypes.c_int(0), cr.ctypes.data_as(dp))
+    assert np.allclose(ct, t0, atol=1e-13) and np.allclose(cd, d0, atol=1e-13) and np.allclose(cr, r0, atol=1e-12)
+    obs = O.pend_obs(th, thd)
+    assert obs.shape == (1000, 3) and np.allclose(obs[:, 0] ** 2 + obs[:, 1] ** 2, 1)
