@@ -100,6 +100,22 @@ def cpu_baseline(budget_s=24.0):
     return out
 
 
+def profiled_traffic():
+    """HBM bytes per launch of the rollout kernel from the committed rocprofv3 PMC passes
+    (profiles/<tag>/traffic.json: WRITE_SIZE*1024 + 2*FETCH_SIZE*1024, gfx950 correction) -- the
+    counters cannot be read from inside the process, so the latest committed profile of this same
+    command is reported, or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+        try:
+            d = json.load(open(f))
+            best = (d["write_bytes"] + d["fetch_bytes_corrected"], os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,6 +231,10 @@ def main():
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
             },
         }
+        tr = profiled_traffic()
+        if tr is not None and n == N_ENVS_PER_GPU and K == CHUNK:
+            result["roofline"]["traffic"] = tr[0]
+            result["roofline"]["traffic_source"] = tr[1]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(result), flush=True)

@@ -162,16 +162,23 @@ struct ActorMfma {
             }
         }
         float part0 = 0.0f, part1 = 0.0f;
+        if (last_tanh) {  // one wave-uniform branch around the whole layer, not one per element
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
+            for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float p0 = acc2[jt][0][reg], p1 = acc2[jt][1][reg];
-                const float h0 = last_tanh ? tanh_fast(p0) : fmaxf(p0, 0.0f);
-                const float h1v = last_tanh ? tanh_fast(p1) : fmaxf(p1, 0.0f);
-                part0 = fmaf(h0, w3[jt][reg], part0);
-                part1 = fmaf(h1v, w3[jt][reg], part1);
-            }
+                for (int reg = 0; reg < 16; ++reg) {
+                    part0 = fmaf(tanh_fast(acc2[jt][0][reg]), w3[jt][reg], part0);
+                    part1 = fmaf(tanh_fast(acc2[jt][1][reg]), w3[jt][reg], part1);
+                }
+        } else {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    part0 = fmaf(fmaxf(acc2[jt][0][reg], 0.0f), w3[jt][reg], part0);
+                    part1 = fmaf(fmaxf(acc2[jt][1][reg], 0.0f), w3[jt][reg], part1);
+                }
+        }
         part0 += __shfl_xor(part0, 32);
         part1 += __shfl_xor(part1, 32);
         return tanh_fast((half ? part1 : part0) + b3);
