@@ -172,6 +172,83 @@ int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *policy, int64_t 
 int ssc_actor_forward(const ssc_actor_desc *actor, int64_t m, const float *d_obs, float *d_act,
                       ssc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * SmartStart navigator: NND_MB dynamics model + MPC (smartstart/RLAgents/NND_MB_agent.py)
+ * ------------------------------------------------------------------------------------- */
+
+/* feedforward_network (NN_Dynamics_Model/feedforward_network.py:3-23):
+ * h = relu(h @ W_i + b_i) for the num_fc_layers hidden layers, z = h @ W_out + b_out.
+ * n_layers = num_fc_layers + 1 weight matrices; dims = {in, depth, ..., out};
+ * W[l] is fp32 [dims[l]][dims[l+1]] (TensorFlow layout), device. */
+typedef struct ssc_mlp_desc {
+    int32_t n_layers;
+    int32_t dims[SSC_MAX_LAYERS + 1];
+    const float *W[SSC_MAX_LAYERS];
+    const float *b[SSC_MAX_LAYERS];
+} ssc_mlp_desc;
+
+/* z-score statistics of NND_MB_agent.__init__ (NND_MB_agent.py:302-315), by value. */
+typedef struct ssc_norm {
+    float mean_x[SSC_MAX_STATE], std_x[SSC_MAX_STATE];
+    float mean_y[SSC_MAX_ACT], std_y[SSC_MAX_ACT];
+    float mean_z[SSC_MAX_STATE], std_z[SSC_MAX_STATE];
+} ssc_norm;
+
+/* y[m][out] = feedforward_network(x[m][in]).  precision SSC_PREC_F32: every layer in fp32
+ * (VALU); SSC_PREC_BF16_MFMA: hidden-layer contractions on bf16 MFMA with fp32 accumulation
+ * (num_fc_layers 1 or 2, depth <= 512).  d_workspace: ssc_mlp_workspace_bytes() bytes. */
+size_t ssc_mlp_workspace_bytes(const ssc_mlp_desc *mlp, int64_t m, int precision);
+int ssc_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float *d_y, int precision,
+                    void *d_workspace, size_t workspace_bytes, ssc_stream_t stream);
+
+/* Dyn_Model.do_forward_sim, batched branch (NN_Dynamics_Model/dynamics_model.py:204-240):
+ *   S[0] = s0;  for t < H:  x = nan_to_num((S[t]-mean_x)/std_x) || nan_to_num((A[:,t]-mean_y)/std_y)
+ *                           S[t+1] = S[t] + net(x) * std_z + mean_z
+ * d_s0 is [s0_rows][state_dim] with s0_rows == m, or s0_rows == 1 (one start state tiled to all
+ * rows, :215-217).  d_A is [m][H][act_dim]; d_S is [H+1][m][state_dim]. */
+size_t ssc_dyn_workspace_bytes(const ssc_mlp_desc *mlp, int64_t m, int precision);
+int ssc_dyn_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m, int32_t H,
+                        int32_t state_dim, int32_t act_dim, const float *d_s0, int64_t s0_rows,
+                        const float *d_A, float *d_S, int precision, void *d_workspace,
+                        size_t workspace_bytes, ssc_stream_t stream);
+
+/* A set of P independent MPC problems (one per real env) with N candidate action sequences
+ * each; rows of every [P*N] array are problem-major.  Waypoints / distances_left come from
+ * NND_MB_agent.start_new_episode_plan (NND_MB_agent.py:375-423), packed back to back:
+ * problem p owns rows wp_off[p] .. wp_off[p+1]-1 (at least 2 waypoints each). */
+typedef struct ssc_mpc_problems {
+    int32_t n_problems, n_samples, horizon, state_dim;
+    const float *wp;        /* device [wp_off[P]][state_dim]  desired_states */
+    const float *left;      /* device [wp_off[P]]             distances_left (:411-418) */
+    const int32_t *wp_off;  /* device [P+1] */
+    const int32_t *cur_idx; /* device [P]  current_desired_state_index */
+    const float *radii;     /* device [P][state_dim] (numerical.py:61-62) */
+    float theta, gamma, horizontal_penalty_factor; /* :143, :62 */
+    int32_t per_row_projection; /* 0 = reference behaviour (batch-global np.sum, numerical.py:89-92);
+                                   1 = corrected per-sample projection (NOT the reference) */
+} ssc_mpc_problems;
+
+/* all_samples = npr.uniform(low, high, (N, H, act)) (NND_MB_agent.py:500-501) for P problems:
+ * d_A [P*N][H][act_dim], Philox(seed; (problem_id0+p) << 32 | n, t, TAG_MPC). */
+int ssc_mpc_sample_actions(int32_t n_problems, int32_t n_samples, int32_t horizon, int32_t act_dim,
+                           const float *low, const float *high, uint64_t seed, uint64_t problem_id0,
+                           uint64_t t, float *d_A, ssc_stream_t stream);
+
+/* generate_scores_add_delta (NND_MB_agent.py:566-628) + argmax (:625-626) per problem.
+ * d_S [H+1][P*N][state_dim] (output of ssc_dyn_forward_sim); d_scores [P*N]; d_best_idx [P]
+ * (index within the problem, lowest index on ties like np.argmax); d_best_score [P]. */
+size_t ssc_mpc_score_workspace_bytes(int32_t n_problems, int32_t n_samples, int32_t horizon);
+int ssc_mpc_score(const ssc_mpc_problems *prob, const float *d_S, float *d_scores, int32_t *d_best_idx,
+                  float *d_best_score, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream);
+
+/* get_action_with_predicted_states (NND_MB_agent.py:339-358): action[p] = A[best][0] +
+ * noise_amount * N(0,1) (no clip, :353-356); also copies the predicted path
+ * S[:, best] -> d_best_path [P][H+1][state_dim] (may be NULL). */
+int ssc_mpc_select_action(int32_t n_problems, int32_t n_samples, int32_t horizon, int32_t state_dim,
+                          int32_t act_dim, const float *d_A, const float *d_S, const int32_t *d_best_idx,
+                          float noise_amount, uint64_t seed, uint64_t problem_id0, uint64_t t,
+                          float *d_action, float *d_best_path, ssc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,8 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, \
-    c_uint32, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libssc.so")
@@ -67,6 +66,24 @@ class EpisodeRing(Structure):
                 ("capacity", c_int32)]
 
 
+class MlpDesc(Structure):
+    _fields_ = [("n_layers", c_int32), ("dims", c_int32 * (SSC_MAX_LAYERS + 1)),
+                ("W", c_void_p * SSC_MAX_LAYERS), ("b", c_void_p * SSC_MAX_LAYERS)]
+
+
+class Norm(Structure):
+    _fields_ = [("mean_x", c_float * SSC_MAX_STATE), ("std_x", c_float * SSC_MAX_STATE),
+                ("mean_y", c_float * SSC_MAX_ACT), ("std_y", c_float * SSC_MAX_ACT),
+                ("mean_z", c_float * SSC_MAX_STATE), ("std_z", c_float * SSC_MAX_STATE)]
+
+
+class MpcProblems(Structure):
+    _fields_ = [("n_problems", c_int32), ("n_samples", c_int32), ("horizon", c_int32), ("state_dim", c_int32),
+                ("wp", c_void_p), ("left", c_void_p), ("wp_off", c_void_p), ("cur_idx", c_void_p),
+                ("radii", c_void_p), ("theta", c_float), ("gamma", c_float),
+                ("horizontal_penalty_factor", c_float), ("per_row_projection", c_int32)]
+
+
 # symbol -> (restype, argtypes); every function include/ssc.h declares must be listed here
 # (tests/test_abi.py cross-checks the header against this table and the built library).
 _SIGNATURES = {
@@ -84,6 +101,18 @@ _SIGNATURES = {
                             POINTER(TransitionLog), POINTER(EpisodeRing), c_void_p, c_uint64, c_uint64,
                             c_uint64, c_void_p]),
     "ssc_actor_forward": (c_int, [POINTER(ActorDesc), c_int64, c_void_p, c_void_p, c_void_p]),
+    "ssc_mlp_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),
+    "ssc_mlp_forward": (c_int, [POINTER(MlpDesc), c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "ssc_dyn_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),
+    "ssc_dyn_forward_sim": (c_int, [POINTER(MlpDesc), POINTER(Norm), c_int64, c_int32, c_int32, c_int32, c_void_p,
+                                    c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "ssc_mpc_sample_actions": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float),
+                                       c_uint64, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "ssc_mpc_score_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "ssc_mpc_score": (c_int, [POINTER(MpcProblems), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                              c_void_p]),
+    "ssc_mpc_select_action": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                      c_float, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,259 @@
+// dyn_model.hip -- NND_MB dynamics model, fp32 path: feedforward_network
+// (NN_Dynamics_Model/feedforward_network.py:3-23) and Dyn_Model.do_forward_sim
+// (NN_Dynamics_Model/dynamics_model.py:204-240).
+//
+// This is the exact-fp32 (VALU) path for ANY layer sizes: the parity reference on the GPU and
+// the fallback for shapes the bf16-MFMA kernel (dyn_mfma.hip) does not cover.  One launch per
+// layer; activations ping-pong through a caller-provided workspace.
+//
+// NOTE: compiled WITHOUT -fno-honor-nans -- np.nan_to_num semantics need real NaN/Inf tests.
+#include <float.h>
+
+#include "ssc_device.h"
+#include "ssc_host.h"
+
+namespace ssc {
+
+constexpr int kRows = 16;     // rows per block in the layer kernel
+constexpr int kKChunk = 512;  // K staged through LDS per pass
+
+// Y[m][N] = act(X[m][K] @ W[K][N] + b).  Block = 256 threads = kRows rows x all N columns
+// (thread -> columns tid, tid+256, ...).  The X tile is staged transposed in LDS ([k][row]) so that
+// the 16 row values of one k are four broadcast ds_read_b128; W rows are read coalesced from
+// L2 (each W element is used for 16 rows).  fp32 FMA chain in k order.
+template <bool RELU>
+__global__ __launch_bounds__(256) void mlp_layer_f32_kernel(int64_t m, int K, int N, const float *__restrict__ X,
+                                                            const float *__restrict__ W,
+                                                            const float *__restrict__ b, float *__restrict__ Y) {
+    __shared__ __attribute__((aligned(16))) float xs[kKChunk][kRows];
+    const int64_t row0 = (int64_t)blockIdx.x * kRows;
+    const int tid = threadIdx.x;
+    for (int c0 = 0; c0 < N; c0 += 256) {
+        const int c = c0 + tid;
+        float acc[kRows];
+        const float bias = (c < N) ? b[c] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) acc[r] = bias;
+        for (int k0 = 0; k0 < K; k0 += kKChunk) {
+            const int kc = min(kKChunk, K - k0);
+            __syncthreads();
+            for (int e = tid; e < kc * kRows; e += 256) {
+                const int r = e / kc, k = e - r * kc;  // coalesced along k within a row
+                const int64_t row = row0 + r;
+                xs[k][r] = (row < m) ? X[row * K + k0 + k] : 0.0f;
+            }
+            __syncthreads();
+            if (c < N) {
+                for (int k = 0; k < kc; ++k) {
+                    const float w = W[(int64_t)(k0 + k) * N + c];
+                    const float4 x0 = *reinterpret_cast<const float4 *>(&xs[k][0]);
+                    const float4 x1 = *reinterpret_cast<const float4 *>(&xs[k][4]);
+                    const float4 x2 = *reinterpret_cast<const float4 *>(&xs[k][8]);
+                    const float4 x3 = *reinterpret_cast<const float4 *>(&xs[k][12]);
+                    acc[0] = fmaf(x0.x, w, acc[0]);   acc[1] = fmaf(x0.y, w, acc[1]);
+                    acc[2] = fmaf(x0.z, w, acc[2]);   acc[3] = fmaf(x0.w, w, acc[3]);
+                    acc[4] = fmaf(x1.x, w, acc[4]);   acc[5] = fmaf(x1.y, w, acc[5]);
+                    acc[6] = fmaf(x1.z, w, acc[6]);   acc[7] = fmaf(x1.w, w, acc[7]);
+                    acc[8] = fmaf(x2.x, w, acc[8]);   acc[9] = fmaf(x2.y, w, acc[9]);
+                    acc[10] = fmaf(x2.z, w, acc[10]); acc[11] = fmaf(x2.w, w, acc[11]);
+                    acc[12] = fmaf(x3.x, w, acc[12]); acc[13] = fmaf(x3.y, w, acc[13]);
+                    acc[14] = fmaf(x3.z, w, acc[14]); acc[15] = fmaf(x3.w, w, acc[15]);
+                }
+            }
+        }
+        if (c < N) {
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const int64_t row = row0 + r;
+                if (row < m) Y[row * N + c] = RELU ? fmaxf(acc[r], 0.0f) : acc[r];  // feedforward_network.py:19
+            }
+        }
+    }
+}
+
+// np.nan_to_num(np.divide(x - mean, std)) (dynamics_model.py:228-229): NaN -> 0, +-Inf -> +-max.
+__device__ __forceinline__ float normalise_one(float x, float mean, float stdv) {
+    const float v = (x - mean) / stdv;
+    if (isnan(v)) return 0.0f;
+    if (isinf(v)) return v > 0.0f ? FLT_MAX : -FLT_MAX;
+    return v;
+}
+
+struct DynDims {
+    int32_t state_dim, act_dim, H;
+};
+
+// S[0] = s0 (tiled when s0_rows == 1, dynamics_model.py:215-217)
+__global__ __launch_bounds__(256) void dyn_init_kernel(int64_t m, int d, const float *__restrict__ s0,
+                                                       int64_t s0_rows, float *__restrict__ S0) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * d) return;
+    const int64_t row = e / d;
+    const int k = (int)(e - row * d);
+    S0[e] = s0[(s0_rows == 1 ? 0 : row) * d + k];
+}
+
+// x[m][d+a] = normalised (S_t, A[:, t])   (dynamics_model.py:228-230)
+__global__ __launch_bounds__(256) void dyn_prepare_kernel(int64_t m, DynDims dd, int t, ssc_norm nm,
+                                                          const float *__restrict__ St,
+                                                          const float *__restrict__ A, float *__restrict__ x) {
+    const int in = dd.state_dim + dd.act_dim;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * in) return;
+    const int64_t row = e / in;
+    const int k = (int)(e - row * in);
+    float v;
+    if (k < dd.state_dim)
+        v = normalise_one(St[row * dd.state_dim + k], nm.mean_x[k], nm.std_x[k]);
+    else {
+        const int a = k - dd.state_dim;
+        v = normalise_one(A[(row * dd.H + t) * dd.act_dim + a], nm.mean_y[a], nm.std_y[a]);
+    }
+    x[e] = v;
+}
+
+// S[t+1] = S[t] + z * std_z + mean_z   (dynamics_model.py:234-237)
+__global__ __launch_bounds__(256) void dyn_update_kernel(int64_t m, int d, ssc_norm nm, const float *__restrict__ St,
+                                                         const float *__restrict__ z, float *__restrict__ Sn) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * d) return;
+    const int k = (int)(e % d);
+    Sn[e] = St[e] + (z[e] * nm.std_z[k] + nm.mean_z[k]);
+}
+
+int validate_mlp(const ssc_mlp_desc *mlp, const char *who) {
+    if (mlp == nullptr) return set_error(SSC_EINVAL, "%s: mlp NULL", who);
+    if (mlp->n_layers < 1 || mlp->n_layers > SSC_MAX_LAYERS)
+        return set_error(SSC_EINVAL, "%s: n_layers %d not in [1, %d]", who, mlp->n_layers, SSC_MAX_LAYERS);
+    for (int l = 0; l <= mlp->n_layers; ++l)
+        if (mlp->dims[l] < 1 || mlp->dims[l] > 65536) return set_error(SSC_EINVAL, "%s: bad dims[%d]", who, l);
+    for (int l = 0; l < mlp->n_layers; ++l)
+        if (!mlp->W[l] || !mlp->b[l]) return set_error(SSC_EINVAL, "%s: NULL weight pointer (layer %d)", who, l);
+    return SSC_OK;
+}
+
+static int max_width(const ssc_mlp_desc *mlp) {
+    int w = 0;
+    for (int l = 0; l <= mlp->n_layers; ++l) w = mlp->dims[l] > w ? mlp->dims[l] : w;
+    return w;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// fp32 path: y = net(x); act buffers a0/a1 of m*maxw floats each.
+int mlp_forward_f32(const ssc_mlp_desc *mlp, int64_t m, const float *x, float *y, float *a0, float *a1,
+                    hipStream_t s) {
+    const float *cur = x;
+    const unsigned grid = (unsigned)((m + kRows - 1) / kRows);
+    for (int l = 0; l < mlp->n_layers; ++l) {
+        const bool last = (l == mlp->n_layers - 1);
+        float *dst = last ? y : ((l & 1) ? a1 : a0);
+        if (last)
+            hipLaunchKernelGGL(mlp_layer_f32_kernel<false>, dim3(grid), dim3(256), 0, s, m, mlp->dims[l],
+                               mlp->dims[l + 1], cur, mlp->W[l], mlp->b[l], dst);
+        else
+            hipLaunchKernelGGL(mlp_layer_f32_kernel<true>, dim3(grid), dim3(256), 0, s, m, mlp->dims[l],
+                               mlp->dims[l + 1], cur, mlp->W[l], mlp->b[l], dst);
+        cur = dst;
+    }
+    return check_launch("mlp_forward_f32");
+}
+
+// bf16-MFMA path (dyn_mfma.hip)
+bool dyn_mfma_supported(const ssc_mlp_desc *mlp, int state_dim, int act_dim);
+size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp);
+int dyn_mfma_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m, int32_t H, int32_t state_dim,
+                         int32_t act_dim, const float *d_s0, int64_t s0_rows, const float *d_A, float *d_S,
+                         void *ws, hipStream_t s);
+int dyn_mfma_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float *d_y, void *ws, hipStream_t s);
+
+}  // namespace ssc
+
+using namespace ssc;
+
+extern "C" {
+
+size_t ssc_mlp_workspace_bytes(const ssc_mlp_desc *mlp, int64_t m, int precision) {
+    if (mlp == nullptr || m < 0 || mlp->n_layers < 1 || mlp->n_layers > SSC_MAX_LAYERS) return 0;
+    if (precision == SSC_PREC_BF16_MFMA) return dyn_mfma_workspace_bytes(mlp);
+    return 2 * align256((size_t)m * max_width(mlp) * sizeof(float));
+}
+
+int ssc_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float *d_y, int precision,
+                    void *d_workspace, size_t workspace_bytes, ssc_stream_t stream) {
+    if (int rc = validate_mlp(mlp, "ssc_mlp_forward")) return rc;
+    SSC_REQUIRE(m >= 0, "ssc_mlp_forward: m < 0");
+    if (m == 0) return SSC_OK;
+    SSC_REQUIRE(d_x && d_y, "ssc_mlp_forward: NULL device pointer");
+    const size_t need = ssc_mlp_workspace_bytes(mlp, m, precision);
+    SSC_REQUIRE(d_workspace != nullptr && workspace_bytes >= need, "ssc_mlp_forward: workspace %zu < %zu bytes",
+                workspace_bytes, need);
+    if (precision == SSC_PREC_BF16_MFMA) {
+        if (!dyn_mfma_supported(mlp, mlp->dims[0], 0))
+            return set_error(SSC_EUNSUPPORTED, "ssc_mlp_forward: MFMA path needs 1-2 hidden layers of equal depth "
+                                               "<= 512, in <= 12, out <= 8");
+        return dyn_mfma_mlp_forward(mlp, m, d_x, d_y, d_workspace, as_stream(stream));
+    }
+    SSC_REQUIRE(precision == SSC_PREC_F32, "ssc_mlp_forward: unknown precision %d", precision);
+    float *a0 = static_cast<float *>(d_workspace);
+    float *a1 = reinterpret_cast<float *>(static_cast<char *>(d_workspace) + need / 2);
+    return mlp_forward_f32(mlp, m, d_x, d_y, a0, a1, as_stream(stream));
+}
+
+size_t ssc_dyn_workspace_bytes(const ssc_mlp_desc *mlp, int64_t m, int precision) {
+    if (mlp == nullptr || m < 0 || mlp->n_layers < 1 || mlp->n_layers > SSC_MAX_LAYERS) return 0;
+    if (precision == SSC_PREC_BF16_MFMA) return dyn_mfma_workspace_bytes(mlp);
+    // x [m][in] + z [m][out] + two activation buffers
+    return align256((size_t)m * mlp->dims[0] * 4) + align256((size_t)m * mlp->dims[mlp->n_layers] * 4) +
+           2 * align256((size_t)m * max_width(mlp) * 4);
+}
+
+int ssc_dyn_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m, int32_t H, int32_t state_dim,
+                        int32_t act_dim, const float *d_s0, int64_t s0_rows, const float *d_A, float *d_S,
+                        int precision, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream) {
+    if (int rc = validate_mlp(mlp, "ssc_dyn_forward_sim")) return rc;
+    SSC_REQUIRE(norm != nullptr, "ssc_dyn_forward_sim: norm NULL");
+    SSC_REQUIRE(m >= 0 && H >= 0, "ssc_dyn_forward_sim: m = %lld, H = %d", (long long)m, H);
+    SSC_REQUIRE(state_dim >= 1 && state_dim <= SSC_MAX_STATE && act_dim >= 1 && act_dim <= SSC_MAX_ACT,
+                "ssc_dyn_forward_sim: state_dim %d / act_dim %d out of range", state_dim, act_dim);
+    SSC_REQUIRE(mlp->dims[0] == state_dim + act_dim && mlp->dims[mlp->n_layers] == state_dim,
+                "ssc_dyn_forward_sim: network is %d -> %d, expected %d -> %d", mlp->dims[0],
+                mlp->dims[mlp->n_layers], state_dim + act_dim, state_dim);
+    SSC_REQUIRE(s0_rows == 1 || s0_rows == m, "ssc_dyn_forward_sim: s0_rows must be 1 or m");
+    if (m == 0) return SSC_OK;
+    SSC_REQUIRE(d_s0 && d_S && (H == 0 || d_A), "ssc_dyn_forward_sim: NULL device pointer");
+    const size_t need = ssc_dyn_workspace_bytes(mlp, m, precision);
+    SSC_REQUIRE(d_workspace != nullptr && workspace_bytes >= need,
+                "ssc_dyn_forward_sim: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = as_stream(stream);
+    if (precision == SSC_PREC_BF16_MFMA) {
+        if (!dyn_mfma_supported(mlp, state_dim, act_dim))
+            return set_error(SSC_EUNSUPPORTED, "ssc_dyn_forward_sim: MFMA path needs 1-2 hidden layers of equal "
+                                               "depth <= 512");
+        return dyn_mfma_forward_sim(mlp, norm, m, H, state_dim, act_dim, d_s0, s0_rows, d_A, d_S, d_workspace, s);
+    }
+    SSC_REQUIRE(precision == SSC_PREC_F32, "ssc_dyn_forward_sim: unknown precision %d", precision);
+    char *w = static_cast<char *>(d_workspace);
+    float *x = reinterpret_cast<float *>(w);
+    w += align256((size_t)m * mlp->dims[0] * 4);
+    float *z = reinterpret_cast<float *>(w);
+    w += align256((size_t)m * state_dim * 4);
+    float *a0 = reinterpret_cast<float *>(w);
+    w += align256((size_t)m * max_width(mlp) * 4);
+    float *a1 = reinterpret_cast<float *>(w);
+    const DynDims dd{state_dim, act_dim, H};
+    const int in = state_dim + act_dim;
+    hipLaunchKernelGGL(dyn_init_kernel, dim3(blocks_for(m * state_dim)), dim3(256), 0, s, m, state_dim, d_s0,
+                       s0_rows, d_S);
+    for (int t = 0; t < H; ++t) {
+        const float *St = d_S + (size_t)t * m * state_dim;
+        float *Sn = d_S + (size_t)(t + 1) * m * state_dim;
+        hipLaunchKernelGGL(dyn_prepare_kernel, dim3(blocks_for(m * in)), dim3(256), 0, s, m, dd, t, *norm, St, d_A, x);
+        if (int rc = mlp_forward_f32(mlp, m, x, z, a0, a1, s)) return rc;
+        hipLaunchKernelGGL(dyn_update_kernel, dim3(blocks_for(m * state_dim)), dim3(256), 0, s, m, state_dim, *norm,
+                           St, z, Sn);
+    }
+    return check_launch("ssc_dyn_forward_sim");
+}
+
+}  // extern "C"

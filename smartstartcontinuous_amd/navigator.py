@@ -1,0 +1,193 @@
+"""Device-side pieces of the SmartStart navigator (smartstart/RLAgents/NND_MB_agent.py):
+the learned dynamics model (``Dyn_Model``: ``feedforward_network`` + ``do_forward_sim``) and the
+MPC over it (action sampling, ``generate_scores_add_delta``, action selection).
+
+Everything here is a thin wrapper over the C ABI (include/ssc.h): tensors in, tensors out, on
+``torch.cuda.current_stream()``; weights are fp32 tensors in TensorFlow layout ``W[in][out]``.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_PREC = {"f32": _ffi.SSC_PREC_F32, "bf16_mfma": _ffi.SSC_PREC_BF16_MFMA}
+
+
+class DynamicsModel:
+    """``Dyn_Model`` forward parts (NN_Dynamics_Model/dynamics_model.py:14-50, 199-240).
+
+    weights/biases: lists of fp32 arrays/tensors, ``weights[l]`` of shape [dims[l], dims[l+1]]
+    (num_fc_layers hidden layers + the output layer, feedforward_network.py:3-23).
+    norm: dict(mean_x, std_x, mean_y, std_y, mean_z, std_z) -- NND_MB_agent.py:302-315.
+    """
+
+    def __init__(self, weights, biases, norm, state_dim, act_dim, device="cuda", precision="f32"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DynamicsModel runs on the GPU only; there is no CPU fallback")
+        self.lib = _ffi.lib()
+        self.state_dim, self.act_dim = int(state_dim), int(act_dim)
+        self.precision = precision
+        self.set_weights(weights, biases)
+        self.set_norm(norm)
+        self._ws = None
+
+    def set_weights(self, weights, biases):
+        """Weights are kernel ARGUMENTS, not baked in: the navigator retrains the model every
+        few episodes (NND_MB_agent.py:421-423) and the next call must see the new values."""
+        self.W = [torch.as_tensor(w, dtype=torch.float32).to(self.device).contiguous() for w in weights]
+        self.b = [torch.as_tensor(b, dtype=torch.float32).to(self.device).contiguous() for b in biases]
+        if len(self.W) != len(self.b) or not 1 <= len(self.W) <= _ffi.SSC_MAX_LAYERS:
+            raise ValueError("need 1..%d layers" % _ffi.SSC_MAX_LAYERS)
+        d = _ffi.MlpDesc()
+        d.n_layers = len(self.W)
+        d.dims[0] = self.W[0].shape[0]
+        for l, (w, b) in enumerate(zip(self.W, self.b)):
+            if w.shape[0] != d.dims[l] or b.shape != (w.shape[1],):
+                raise ValueError(f"layer {l}: inconsistent shapes {tuple(w.shape)} / {tuple(b.shape)}")
+            d.dims[l + 1] = w.shape[1]
+            d.W[l], d.b[l] = w.data_ptr(), b.data_ptr()
+        self.desc = d
+        self.in_dim, self.out_dim = d.dims[0], d.dims[d.n_layers]
+
+    def set_norm(self, norm):
+        nm = _ffi.Norm()
+        for key, n in (("mean_x", self.state_dim), ("std_x", self.state_dim), ("mean_y", self.act_dim),
+                       ("std_y", self.act_dim), ("mean_z", self.state_dim), ("std_z", self.state_dim)):
+            v = np.asarray(norm[key], np.float32).reshape(-1)
+            if v.size != n:
+                raise ValueError(f"norm[{key}] has {v.size} entries, expected {n}")
+            arr = getattr(nm, key)
+            for i in range(n):
+                arr[i] = float(v[i])
+        self.norm = nm
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, x, precision=None):
+        """z = feedforward_network(x): x [m, in] -> [m, out]."""
+        prec = _PREC[precision or self.precision]
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
+        m = x.shape[0]
+        y = torch.empty((m, self.out_dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.ssc_mlp_workspace_bytes(ctypes.byref(self.desc), m, prec))
+            _ffi.check(self.lib.ssc_mlp_forward(ctypes.byref(self.desc), m, _ffi.ptr(x), _ffi.ptr(y), prec,
+                                                _ffi.ptr(ws), ws.numel(), _stream()))
+        return y
+
+    def do_forward_sim(self, state0, actions, precision=None, out=None):
+        """``Dyn_Model.do_forward_sim(..., many_in_parallel=True)``: state0 [d] (tiled, :215-217) or
+        [m, d]; actions [m, H, act] -> states [H+1, m, d]."""
+        prec = _PREC[precision or self.precision]
+        A = torch.as_tensor(actions, dtype=torch.float32, device=self.device).contiguous()
+        m, H = A.shape[0], A.shape[1]
+        s0 = torch.as_tensor(state0, dtype=torch.float32, device=self.device).contiguous()
+        s0_rows = 1 if s0.dim() == 1 else s0.shape[0]
+        S = out if out is not None else torch.empty((H + 1, m, self.state_dim), dtype=torch.float32,
+                                                    device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.ssc_dyn_workspace_bytes(ctypes.byref(self.desc), m, prec))
+            _ffi.check(self.lib.ssc_dyn_forward_sim(ctypes.byref(self.desc), ctypes.byref(self.norm), m, H,
+                                                    self.state_dim, self.act_dim, _ffi.ptr(s0), s0_rows,
+                                                    _ffi.ptr(A), _ffi.ptr(S), prec, _ffi.ptr(ws), ws.numel(),
+                                                    _stream()))
+        return S
+
+
+class MpcProblemSet:
+    """Waypoint data of P navigation problems, packed for the scorer
+    (NND_MB_agent.start_new_episode_plan, NND_MB_agent.py:375-423)."""
+
+    def __init__(self, waypoints, lefts, radii, cur_idx, device="cuda", theta=1.0, gamma=0.75,
+                 horizontal_penalty_factor=0.5, per_row_projection=False):
+        self.device = torch.device(device)
+        P = len(waypoints)
+        d = np.asarray(waypoints[0]).shape[1]
+        off = np.zeros(P + 1, np.int32)
+        for p, w in enumerate(waypoints):
+            if len(w) < 2:
+                raise ValueError("every problem needs at least 2 waypoints (the reference indexes wp[b+1])")
+            off[p + 1] = off[p] + len(w)
+        if max(off[p + 1] - off[p] for p in range(P)) * (d + 1) * 4 > 48 * 1024:
+            raise ValueError("too many waypoints for one problem (LDS carve of the scorer is 48 KB)")
+        self.P, self.d = P, d
+        self.wp = torch.as_tensor(np.concatenate([np.asarray(w, np.float32) for w in waypoints]), device=self.device)
+        self.left = torch.as_tensor(np.concatenate([np.asarray(l, np.float32) for l in lefts]), device=self.device)
+        self.wp_off = torch.as_tensor(off, device=self.device)
+        self.cur_idx = torch.as_tensor(np.asarray(cur_idx, np.int32), device=self.device)
+        self.radii = torch.as_tensor(np.asarray(radii, np.float32).reshape(P, d), device=self.device).contiguous()
+        self.theta, self.gamma, self.hpf = float(theta), float(gamma), float(horizontal_penalty_factor)
+        self.per_row = bool(per_row_projection)
+
+    def as_struct(self, n_samples, horizon):
+        s = _ffi.MpcProblems()
+        s.n_problems, s.n_samples, s.horizon, s.state_dim = self.P, n_samples, horizon, self.d
+        s.wp, s.left, s.wp_off = self.wp.data_ptr(), self.left.data_ptr(), self.wp_off.data_ptr()
+        s.cur_idx, s.radii = self.cur_idx.data_ptr(), self.radii.data_ptr()
+        s.theta, s.gamma, s.horizontal_penalty_factor = self.theta, self.gamma, self.hpf
+        s.per_row_projection = int(self.per_row)
+        return s
+
+
+def mpc_sample_actions(P, N, H, low, high, seed, problem_id0=0, t=0, device="cuda"):
+    """``npr.uniform(low, high, (N, H, act))`` per problem (NND_MB_agent.py:500-501) -> [P*N, H, act]."""
+    low = np.asarray(low, np.float32).reshape(-1)
+    high = np.asarray(high, np.float32).reshape(-1)
+    act = low.size
+    A = torch.empty((P * N, H, act), dtype=torch.float32, device=device)
+    lo = (ctypes.c_float * act)(*low.tolist())
+    hi = (ctypes.c_float * act)(*high.tolist())
+    with torch.cuda.device(A.device):
+        _ffi.check(_ffi.lib().ssc_mpc_sample_actions(P, N, H, act, lo, hi, int(seed), int(problem_id0), int(t),
+                                                     _ffi.ptr(A), _stream()))
+    return A
+
+
+def mpc_score(problems, S):
+    """``generate_scores_add_delta`` + argmax (NND_MB_agent.py:566-628) for P problems.
+    S: [H+1, P*N, d].  Returns (scores [P, N], best_idx [P] int32, best_score [P])."""
+    S = S.contiguous()
+    H1, M, d = S.shape
+    P = problems.P
+    N = M // P
+    if N * P != M or d != problems.d:
+        raise ValueError("S has the wrong shape for this problem set")
+    lib = _ffi.lib()
+    scores = torch.empty(M, dtype=torch.float32, device=S.device)
+    best_idx = torch.empty(P, dtype=torch.int32, device=S.device)
+    best_score = torch.empty(P, dtype=torch.float32, device=S.device)
+    st = problems.as_struct(N, H1 - 1)
+    with torch.cuda.device(S.device):
+        nbytes = lib.ssc_mpc_score_workspace_bytes(P, N, H1 - 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=S.device)
+        _ffi.check(lib.ssc_mpc_score(ctypes.byref(st), _ffi.ptr(S), _ffi.ptr(scores), _ffi.ptr(best_idx),
+                                     _ffi.ptr(best_score), _ffi.ptr(ws), nbytes, _stream()))
+    return scores.view(P, N), best_idx, best_score
+
+
+def mpc_select_action(A, S, best_idx, P, noise_amount, seed, problem_id0=0, t=0, want_path=True):
+    """``get_action_with_predicted_states`` tail (NND_MB_agent.py:339-358): first action of the best
+    sequence + ``noise_amount * N(0,1)`` (no clip) and the predicted path [P, H+1, d]."""
+    M, H, act = A.shape
+    N = M // P
+    d = S.shape[2]
+    action = torch.empty((P, act), dtype=torch.float32, device=A.device)
+    path = torch.empty((P, H + 1, d), dtype=torch.float32, device=A.device) if want_path else None
+    with torch.cuda.device(A.device):
+        _ffi.check(_ffi.lib().ssc_mpc_select_action(P, N, H, d, act, _ffi.ptr(A), _ffi.ptr(S), _ffi.ptr(best_idx),
+                                                    float(noise_amount), int(seed), int(problem_id0), int(t),
+                                                    _ffi.ptr(action), _ffi.ptr(path), _stream()))
+    return action, path

@@ -1,0 +1,181 @@
+"""GPU parity tests of the SmartStart navigator kernels through the C ABI: dynamics-MLP
+forward, forward simulation, MPC action sampling, trajectory scoring (incl. the batch-global
+projection quirk) and action selection -- BASELINE config 4 at test sizes."""
+import numpy as np
+import pytest
+
+from oracle import ssc_oracle as O
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nav():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no fallback")
+    from smartstartcontinuous_amd import navigator
+    from smartstartcontinuous_amd import _ffi
+    _ffi.lib()
+    return navigator
+
+
+def make_mlp(rng, dims):
+    """xavier-normal weights AND biases (feedforward_network.py:8,14-23)."""
+    Ws = [rng.normal(size=(dims[i], dims[i + 1])) * np.sqrt(2.0 / (dims[i] + dims[i + 1])) for i in range(len(dims) - 1)]
+    bs = [rng.normal(size=dims[i + 1]) * np.sqrt(2.0 / (1 + dims[i + 1])) for i in range(len(dims) - 1)]
+    return [w.astype(np.float32) for w in Ws], [b.astype(np.float32) for b in bs]
+
+
+def make_norm(rng, d, a):
+    return dict(mean_x=rng.normal(size=d) * 0.3, std_x=rng.uniform(0.05, 1.0, d), mean_y=rng.normal(size=a) * 0.1,
+                std_y=rng.uniform(0.3, 1.2, a), mean_z=rng.normal(size=d) * 0.01, std_z=rng.uniform(0.005, 0.05, d))
+
+
+@pytest.mark.parametrize("dims", [(3, 32, 2), (4, 500, 500, 3), (3, 500, 2), (12, 64, 48, 40, 8)])
+def test_mlp_forward_f32(nav, dims):
+    rng = np.random.default_rng(sum(dims))
+    Ws, bs = make_mlp(rng, dims)
+    model = nav.DynamicsModel(Ws, bs, make_norm(rng, dims[-1], dims[0] - dims[-1] if dims[0] > dims[-1] else 1),
+                              state_dim=dims[-1], act_dim=max(1, dims[0] - dims[-1]))
+    for m in (1, 15, 16, 17, 1000, 4099):
+        x = rng.normal(size=(m, dims[0])).astype(np.float32)
+        ref = O.mlp_forward(x, Ws, bs)
+        got = model.forward(x, precision="f32").cpu().numpy()
+        scale = np.maximum(1.0, np.abs(ref).max())
+        assert np.max(np.abs(got - ref)) <= 1e-4 * scale, (dims, m)       # 1e-4 rel (fp32)
+
+
+@pytest.mark.parametrize("dims,H", [((3, 32, 2), 4), ((4, 500, 500, 3), 4), ((3, 500, 2), 20)])
+def test_forward_sim_f32(nav, dims, H):
+    rng = np.random.default_rng(7 + H)
+    d, a = dims[-1], dims[0] - dims[-1]
+    Ws, bs = make_mlp(rng, dims)
+    norm = make_norm(rng, d, a)
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=a)
+    m = 777
+    A = rng.uniform(-1, 1, size=(m, H, a)).astype(np.float32)
+    s0 = rng.normal(size=d).astype(np.float32) * 0.3
+    S = model.do_forward_sim(s0, A).cpu().numpy()
+    ref = O.dyn_forward_sim(s0, A, norm32(norm), Ws, bs)
+    assert S.shape == (H + 1, m, d) and np.array_equal(S[0], np.tile(s0, (m, 1)))
+    assert np.max(np.abs(S - ref)) <= 1e-4 * np.maximum(1.0, np.abs(ref).max())
+    # per-row start states
+    s0m = rng.normal(size=(m, d)).astype(np.float32) * 0.3
+    S = model.do_forward_sim(s0m, A).cpu().numpy()
+    ref = O.dyn_forward_sim(s0m, A, norm32(norm), Ws, bs)
+    assert np.max(np.abs(S - ref)) <= 1e-4 * np.maximum(1.0, np.abs(ref).max())
+
+
+def norm32(norm):
+    """the kernel receives fp32 statistics; give the oracle the same values"""
+    return {k: np.asarray(v, np.float32).astype(np.float64) for k, v in norm.items()}
+
+
+def test_forward_sim_zero_std_quirk(nav):
+    """std == 0 (e.g. the velocity column of a data set that never moved): nan_to_num gives 0 for 0/0
+    and +-max for x/0 (dynamics_model.py:228-229)."""
+    rng = np.random.default_rng(3)
+    Ws, bs = make_mlp(rng, (3, 32, 2))
+    Ws[0][1, :] = 0.0     # the second input is multiplied by 0 so the +-max never reaches the output as inf
+    norm = make_norm(rng, 2, 1)
+    norm["std_x"] = np.array([0.3, 0.0])
+    norm["mean_x"] = np.array([0.0, 0.0])
+    norm["mean_z"] = np.array([0.001, 0.0])
+    norm["std_z"] = np.array([0.01, 0.0])
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=2, act_dim=1)
+    A = rng.uniform(-1, 1, size=(64, 3, 1)).astype(np.float32)
+    S = model.do_forward_sim(np.array([0.1, 0.0], np.float32), A).cpu().numpy()
+    ref = O.dyn_forward_sim(np.array([0.1, 0.0], np.float32), A, norm32(norm), Ws, bs)
+    assert np.isfinite(S).all() and np.max(np.abs(S - ref)) <= 1e-5
+
+
+def test_mpc_sample_actions_bit_exact(nav):
+    for (P, N, H, low, high) in [(3, 50, 4, [-1.0], [1.0]), (2, 17, 5, [-2.0, 0.0], [2.0, 1.0]), (1, 5000, 20, [-1.0], [1.0])]:
+        A = nav.mpc_sample_actions(P, N, H, low, high, seed=99, problem_id0=7, t=11).cpu().numpy()
+        assert A.shape == (P * N, H, len(low))
+        for p in range(P):
+            ref = O.mpc_action_samples(99, 7 + p, N, H, len(low), 11, low, high)
+            assert np.array_equal(A[p * N:(p + 1) * N], ref)
+
+
+def _score_case(nav, S, wps, lefts, radii, cur, per_row=False, **kw):
+    """S [H+1, P, N, d] fp64 -> kernel scores / best vs oracle per problem"""
+    H1, P, N, d = S.shape
+    ps = nav.MpcProblemSet(wps, lefts, radii, cur, per_row_projection=per_row, **kw)
+    S32 = torch.as_tensor(S.reshape(H1, P * N, d), dtype=torch.float32, device="cuda")
+    scores, best, best_score = nav.mpc_score(ps, S32)
+    scores, best, best_score = scores.cpu().numpy(), best.cpu().numpy(), best_score.cpu().numpy()
+    for p in range(P):
+        Sp = S32[:, p * N:(p + 1) * N].cpu().numpy().astype(np.float64)
+        ref, ref_best_score, ref_best, _ = O.mpc_scores_add_delta(
+            Sp, np.asarray(wps[p], np.float32), np.asarray(lefts[p], np.float32), np.asarray(radii[p], np.float32),
+            cur[p], per_row_projection=per_row, **{k: v for k, v in kw.items() if k in ("theta", "gamma")},
+            hpf=kw.get("horizontal_penalty_factor", 0.5))
+        tol = 1e-3 * np.maximum(1.0, np.abs(ref).max())          # scores <= 1e-3 rel
+        assert np.max(np.abs(scores[p] - ref)) <= tol, p
+        # the chosen sample's reference score is within tolerance of the reference max (not index equality)
+        assert ref[best[p]] >= ref_best_score - tol
+        assert abs(best_score[p] - scores[p, best[p]]) == 0 and scores[p, best[p]] == scores[p].max()
+        assert best[p] == int(np.argmax(scores[p]))              # lowest index on ties
+    return scores
+
+
+def test_mpc_score_reference_kats(nav, golden_dir):
+    """Scores produced by the reference's own numerical.py helpers (tests/golden/make_goldens.py)."""
+    kats = np.load(f"{golden_dir}/numerical_kats.npz")
+    for c in range(int(kats["n_mpc"])):
+        S, wp, left, radii = (kats[f"m{c}_{k}"] for k in ("S", "wp", "left", "radii"))
+        H1, N, d = S.shape
+        scores = _score_case(nav, S.reshape(H1, 1, N, d), [wp], [left], [radii], [int(kats[f"m{c}_cur"])])
+        ref = kats[f"m{c}_scores"]
+        assert np.max(np.abs(scores[0] - ref)) <= 1e-3 * np.maximum(1.0, np.abs(ref).max())
+        assert ref[int(np.argmax(scores[0]))] >= ref.max() - 1e-3 * np.maximum(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("per_row", [False, True])
+def test_mpc_score_multi_problem(nav, per_row):
+    rng = np.random.default_rng(11)
+    P, N, H, d = 5, 1000, 4, 2
+    wps, lefts, radii, cur = [], [], [], []
+    S = np.empty((H + 1, P, N, d))
+    for p in range(P):
+        W = int(rng.integers(2, 60))
+        wp = np.cumsum(rng.normal(scale=[0.02, 0.004], size=(W, d)), axis=0) + [-0.5, 0.0]
+        stds, means = O.path_deltas_stds_and_means_per_dim(wp) if W > 2 else (np.array([0.01, 0.002]), np.array([0.02, 0.004]))
+        r = O.radii_calc(means, stds, 1, 1, 1) + 1e-4
+        wps.append(wp); radii.append(r); lefts.append(O.distances_left(wp, O.distance_func(r)))
+        c = int(rng.integers(0, W)); cur.append(c)
+        s = wp[c] + rng.normal(scale=r * 0.7)
+        S[0, p] = s
+        for t in range(H):
+            S[t + 1, p] = S[t, p] + rng.normal(scale=r * 0.9, size=(N, d))
+    _score_case(nav, S, wps, lefts, radii, cur, per_row=per_row, theta=1.0, gamma=0.75, horizontal_penalty_factor=0.5)
+
+
+def test_mpc_pipeline_select_action(nav):
+    """sample -> forward sim -> score -> select: the navigator's get_action for P envs at once."""
+    rng = np.random.default_rng(21)
+    P, N, H, d, a = 4, 500, 4, 2, 1
+    Ws, bs = make_mlp(rng, (3, 32, 2))
+    norm = dict(mean_x=[-0.5, 0.0], std_x=[0.2, 0.02], mean_y=[0.0], std_y=[0.6], mean_z=[0.0, 0.0], std_z=[0.01, 0.002])
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=a)
+    A = nav.mpc_sample_actions(P, N, H, [-1.0], [1.0], seed=5, problem_id0=100, t=3)
+    states = rng.normal(size=(P, d)).astype(np.float32) * [0.1, 0.01] + [-0.5, 0.0]
+    s0 = torch.as_tensor(np.repeat(states, N, axis=0), dtype=torch.float32, device="cuda")
+    S = model.do_forward_sim(s0, A)
+    wps = [np.cumsum(rng.normal(scale=[0.02, 0.004], size=(12, d)), axis=0) + states[p] for p in range(P)]
+    radii = [np.array([0.03, 0.006])] * P
+    lefts = [O.distances_left(w, O.distance_func(radii[0])) for w in wps]
+    ps = nav.MpcProblemSet(wps, lefts, radii, [0] * P)
+    scores, best, _ = nav.mpc_score(ps, S)
+    action, path = nav.mpc_select_action(A, S, best, P, noise_amount=0.005, seed=5, problem_id0=100, t=3)
+    action, path, best = action.cpu().numpy(), path.cpu().numpy(), best.cpu().numpy()
+    An, Sn = A.cpu().numpy(), S.cpu().numpy()
+    for p in range(P):
+        row = p * N + best[p]
+        g = O.mpc_noise_gaussian(5, np.array([100 + p], np.uint64), 3, 0)[0]
+        assert abs(action[p, 0] - (An[row, 0, 0] + 0.005 * g)) <= 1e-6
+        assert np.array_equal(path[p], Sn[:, row])
+    clean, _ = nav.mpc_select_action(A, S, torch.as_tensor(best, device="cuda"), P, 0.0, 5, 100, 3, want_path=False)
+    assert np.array_equal(clean.cpu().numpy()[:, 0], An[np.arange(P) * N + best, 0, 0])
