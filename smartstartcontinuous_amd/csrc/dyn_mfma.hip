@@ -1,18 +1,475 @@
-// dyn_mfma.hip -- bf16-MFMA path of the NND_MB dynamics model (placeholder until the fused
-// kernel lands: reports "unsupported" so that callers fall back to SSC_PREC_F32 explicitly).
+// dyn_mfma.hip -- bf16-MFMA path of the NND_MB dynamics model: the H-step forward simulation
+// Dyn_Model.do_forward_sim (NN_Dynamics_Model/dynamics_model.py:204-240) over
+// feedforward_network (feedforward_network.py:3-23) as ONE persistent kernel.
+//
+// Shape of the work (BASELINE config 4: in 4, 2x500 hidden, out 3): 507 kflop per row-step, of
+// which 500 k are the [rows,500]x[500,500] hidden contraction -> MFMA-bound (bf16 dense peak
+// ~2.5 PFLOP/s).  The state feeds back every step, so the H loop lives inside the kernel and
+// NOTHING but the [H+1][m][d] trajectory (the result) and the per-step actions touch HBM.
+//
+// Mapping to CDNA4:
+//   * one wave owns two 32-row tiles (64 rows); a block = 4 waves = 256 rows = one CU's worth at
+//     one wave per SIMD (the 512-entry register file holds the first hidden layer of both tiles as
+//     bf16 fragments); the waves of a block share the weight fragments through LDS and every
+//     fragment read from LDS feeds two MFMAs.
+//   * every layer is computed TRANSPOSED: D[unit][row] = W^T[unit][k] * H[k][row], i.e. the
+//     weights are the MFMA A operand and the activations the B operand.  The 32x32 accumulator
+//     tile of a layer (unit on the register index, row on the lane) is therefore already in the
+//     B-operand layout of the next layer: ReLU + v_cvt_pk_bf16_f32 in registers and it is fed
+//     straight back -- no LDS round trip for activations, no lane movement
+//     (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand").
+//   * layer 1 (K = state+action <= 12) runs on the exact-fp32 MFMA v_mfma_f32_32x32x2_f32 with the
+//     bias as C-in; hidden and output layers on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+//   * layer-2 output tiles are consumed immediately by the output layer (2 more MFMAs per tile),
+//     so the second hidden activation is never materialised: live registers = first hidden layer
+//     as bf16 B fragments (UT*8 VGPRs) + two accumulator tiles.
+//   * W2 is pre-packed once per call into fragment order (bf16, k order matched to the accumulator
+//     layout) and streamed L2 -> registers -> LDS one 32-unit output tile (UT*2 KB) at a time,
+//     double buffered, one barrier per tile.
+#include <float.h>
+
 #include "ssc_device.h"
 #include "ssc_host.h"
 
 namespace ssc {
 
-bool dyn_mfma_supported(const ssc_mlp_desc *, int, int) { return false; }
-size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *) { return 256; }
-int dyn_mfma_forward_sim(const ssc_mlp_desc *, const ssc_norm *, int64_t, int32_t, int32_t, int32_t, const float *,
-                         int64_t, const float *, float *, void *, hipStream_t) {
-    return set_error(SSC_EUNSUPPORTED, "bf16 MFMA dynamics path not built");
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kDynThreads = 256;  // 4 waves x 64 rows (2 tiles of 32)
+constexpr int kDynRows = 256;
+constexpr int kMaxKS1 = 6;        // layer-1 k-steps of 2: inputs <= 12
+
+__device__ __forceinline__ int acc_row32(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+// hidden unit carried by k slot (8*half + j) of bf16 k-step (ut, s) when the B operand is a converted
+// 32x32 accumulator tile: registers 8s..8s+7 of unit tile ut
+__device__ __forceinline__ int frag_unit(int ut, int s, int half, int j) {
+    return ut * 32 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
 }
-int dyn_mfma_mlp_forward(const ssc_mlp_desc *, int64_t, const float *, float *, void *, hipStream_t) {
-    return set_error(SSC_EUNSUPPORTED, "bf16 MFMA dynamics path not built");
+
+// Packed weight image in the workspace (all offsets in bytes, 256-aligned)
+struct DynPack {
+    size_t a2;   // bf16 [UT jt][UT ut][2 s][64 lane][8]   W2^T fragments (NFC == 2)
+    size_t a3;   // bf16 [UT ut][2 s][64 lane][8]          Wout^T fragments, rows >= out are 0
+    size_t w1;   // f32  [KS1][UT][64 lane]                 W1[2ks+half][ut*32 + lane&31]
+    size_t b1;   // f32  [UT][2 half][16]                   b1 in accumulator layout
+    size_t b2;   // f32  [UT][2][16]
+    size_t b3;   // f32  [2][16]
+    size_t nm;   // f32  [6][8]  mean_x std_x mean_y std_y mean_z std_z
+    size_t total;
+};
+
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static DynPack make_pack(int UT, int nfc) {
+    DynPack p;
+    size_t o = 0;
+    p.a2 = o; o += al256(nfc == 2 ? (size_t)UT * UT * 2 * 64 * 8 * 2 : 0);
+    p.a3 = o; o += al256((size_t)UT * 2 * 64 * 8 * 2);
+    p.w1 = o; o += al256((size_t)kMaxKS1 * UT * 64 * 4);
+    p.b1 = o; o += al256((size_t)UT * 32 * 4);
+    p.b2 = o; o += al256((size_t)UT * 32 * 4);
+    p.b3 = o; o += al256(32 * 4);
+    p.nm = o; o += al256(48 * 4);
+    p.total = o;
+    return p;
+}
+
+struct DynNet {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;  // W3/b3 = output layer; W2/b2 unused when nfc == 1
+    int in, depth, out, nfc;
+};
+
+__global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack pk, ssc_norm nm,
+                                                       unsigned char *__restrict__ ws) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid < 48) {
+        const int q = (int)gid >> 3, k = (int)gid & 7;
+        float v = 0.0f;
+        if (q == 0) v = nm.mean_x[k]; else if (q == 1) v = nm.std_x[k];
+        else if (q == 2) v = nm.mean_y[k & 3]; else if (q == 3) v = nm.std_y[k & 3];
+        else if (q == 4) v = nm.mean_z[k]; else v = nm.std_z[k];
+        reinterpret_cast<float *>(ws + pk.nm)[gid] = v;
+    }
+    const int64_t n_a2 = (n.nfc == 2) ? (int64_t)UT * UT * 2 * 64 * 8 : 0;
+    const int64_t n_a3 = (int64_t)UT * 2 * 64 * 8;
+    const int64_t n_w1 = (int64_t)kMaxKS1 * UT * 64;
+    const int64_t n_b = (int64_t)UT * 32;
+    int64_t e = gid;
+    if (e < n_a2) {
+        const int j = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 1;
+        const int ut = (int)((e >> 10) % UT), jt = (int)((e >> 10) / UT);
+        const int u = frag_unit(ut, s, lane >> 5, j), col = jt * 32 + (lane & 31);
+        const float v = (u < n.depth && col < n.depth) ? n.W2[(int64_t)u * n.depth + col] : 0.0f;
+        reinterpret_cast<__bf16 *>(ws + pk.a2)[e] = (__bf16)v;
+        return;
+    }
+    e -= n_a2;
+    if (e < n_a3) {
+        const int j = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 1, ut = (int)(e >> 10);
+        const int u = frag_unit(ut, s, lane >> 5, j), o = lane & 31;
+        const float v = (u < n.depth && o < n.out) ? n.W3[(int64_t)u * n.out + o] : 0.0f;
+        reinterpret_cast<__bf16 *>(ws + pk.a3)[e] = (__bf16)v;
+        return;
+    }
+    e -= n_a3;
+    if (e < n_w1) {
+        const int lane = e & 63, ut = (int)((e >> 6) % UT), ks = (int)((e >> 6) / UT);
+        const int k = 2 * ks + (lane >> 5), unit = ut * 32 + (lane & 31);
+        reinterpret_cast<float *>(ws + pk.w1)[e] = (k < n.in && unit < n.depth) ? n.W1[(int64_t)k * n.depth + unit] : 0.0f;
+        return;
+    }
+    e -= n_w1;
+    if (e < n_b) {  // b1: [ut][half][reg]
+        const int reg = e & 15, half = (e >> 4) & 1, ut = (int)(e >> 5);
+        const int u = ut * 32 + acc_row32(reg, half);
+        reinterpret_cast<float *>(ws + pk.b1)[e] = (u < n.depth) ? n.b1[u] : 0.0f;
+        return;
+    }
+    e -= n_b;
+    if (e < n_b) {
+        const int reg = e & 15, half = (e >> 4) & 1, ut = (int)(e >> 5);
+        const int u = ut * 32 + acc_row32(reg, half);
+        reinterpret_cast<float *>(ws + pk.b2)[e] = (n.nfc == 2 && u < n.depth) ? n.b2[u] : 0.0f;
+        return;
+    }
+    e -= n_b;
+    if (e < 32) {
+        const int reg = e & 15, half = (e >> 4) & 1;
+        const int o = acc_row32(reg, half);
+        reinterpret_cast<float *>(ws + pk.b3)[e] = (o < n.out) ? n.b3[o] : 0.0f;
+    }
+}
+
+struct DynSimArgs {
+    int64_t m;
+    int32_t H, d, a;        // horizon, state dim, action dim (forward mode: H = 1)
+    int32_t in, out, ks1;   // network input / output width, layer-1 k-steps
+    int32_t fwd_mode;       // 1: plain y = net(x) (ssc_mlp_forward); 0: forward simulation
+    const float *s0;
+    int64_t s0_rows;
+    const float *A;         // sim: [m][H][a]; fwd: x [m][in]
+    float *S;               // sim: [H+1][m][d]; fwd: y [m][out]
+    const unsigned char *a2, *a3;       // packed weight image (workspace)
+    const float *w1, *b1, *b2, *b3, *nm;
+};
+
+__device__ __forceinline__ float nan_to_num_div(float x, float mean, float stdv) {
+    const float v = (x - mean) / stdv;  // dynamics_model.py:228-229
+    if (isnan(v)) return 0.0f;
+    if (isinf(v)) return v > 0.0f ? FLT_MAX : -FLT_MAX;
+    return v;
+}
+
+__device__ __forceinline__ f32x16 lds_tile16(const float *p) {  // 16 consecutive floats -> accumulator init
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
+    const f32x4 c = *reinterpret_cast<const f32x4 *>(p + 8), d = *reinterpret_cast<const f32x4 *>(p + 12);
+    f32x16 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    r[8] = c[0]; r[9] = c[1]; r[10] = c[2]; r[11] = c[3]; r[12] = d[0]; r[13] = d[1]; r[14] = d[2]; r[15] = d[3];
+    return r;
+}
+
+__device__ __forceinline__ void relu_to_frags(const f32x16 &acc, bf16x8 &f0, bf16x8 &f1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f0[j] = (__bf16)fmaxf(acc[j], 0.0f);      // feedforward_network.py:19
+        f1[j] = (__bf16)fmaxf(acc[8 + j], 0.0f);
+    }
+}
+
+constexpr int ET = 2;  // 32-row tiles per wave
+
+// LDS carve (bytes): [a2 buffers 2 x UT*2048 (NFC==2)] [a3 UT*2048] [w1 6*UT*256] [b1 UT*128] [b2 UT*128] [b3 128] [nm 192]
+template <int UT, int NFC>
+__global__ __launch_bounds__(kDynThreads, 1) void dyn_mfma_sim_kernel(DynSimArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int A2_TILE = UT * 2048;  // one output tile of W2^T fragments
+    unsigned char *l_a2 = lds;
+    unsigned char *l_a3 = l_a2 + (NFC == 2 ? 2 * A2_TILE : 0);
+    float *l_w1 = reinterpret_cast<float *>(l_a3 + UT * 2048);
+    float *l_b1 = l_w1 + kMaxKS1 * UT * 64;
+    float *l_b2 = l_b1 + UT * 32;
+    float *l_b3 = l_b2 + UT * 32;
+    float *l_nm = l_b3 + 32;  // [6][8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, half = lane >> 5;
+
+    // ---- stage the resident weights: a3, w1, biases, normalisation ----------------------------
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(g.a3);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(l_a3);
+        for (int e = tid; e < UT * 2048 / 16; e += kDynThreads) dst[e] = src[e];
+        for (int e = tid; e < kMaxKS1 * UT * 64; e += kDynThreads) l_w1[e] = g.w1[e];
+        for (int e = tid; e < UT * 32; e += kDynThreads) { l_b1[e] = g.b1[e]; l_b2[e] = g.b2[e]; }
+        if (tid < 32) l_b3[tid] = g.b3[tid];
+        if (tid < 48) l_nm[tid] = g.nm[tid];
+    }
+    // W2^T tile 0 -> buffer 0
+    constexpr int STAGE = (A2_TILE / 16 + kDynThreads - 1) / kDynThreads;  // f32x4 per thread per tile
+    f32x4 stage[NFC == 2 ? STAGE : 1];
+    const f32x4 *a2_src = reinterpret_cast<const f32x4 *>(g.a2);
+    if (NFC == 2) {
+#pragma unroll
+        for (int q = 0; q < STAGE; ++q) {
+            const int e = q * kDynThreads + tid;
+            if (e < A2_TILE / 16) reinterpret_cast<f32x4 *>(l_a2)[e] = a2_src[e];
+        }
+    }
+    __syncthreads();
+
+    // ---- this lane's rows (one per tile) -------------------------------------------------------
+    int64_t row[ET], rowc[ET];
+    bool valid[ET];
+    float st[ET][SSC_MAX_STATE];
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+        row[et] = (int64_t)blockIdx.x * kDynRows + wave * (32 * ET) + et * 32 + r;
+        valid[et] = row[et] < g.m;
+        rowc[et] = valid[et] ? row[et] : g.m - 1;
+        if (!g.fwd_mode) {
+#pragma unroll
+            for (int k = 0; k < SSC_MAX_STATE; ++k)
+                st[et][k] = (k < g.d) ? g.s0[(g.s0_rows == 1 ? 0 : rowc[et]) * g.d + k] : 0.0f;
+        }
+    }
+
+    for (int t = 0; t < g.H; ++t) {
+        // ---- inputs: record S[t]; x = normalised (state, action) ------------------------------
+        float xs[ET][2 * kMaxKS1];
+#pragma unroll
+        for (int et = 0; et < ET; ++et) {
+            if (g.fwd_mode) {
+#pragma unroll
+                for (int k = 0; k < 2 * kMaxKS1; ++k) xs[et][k] = (k < g.in) ? g.A[rowc[et] * g.in + k] : 0.0f;
+            } else {
+                if (valid[et] && half == 0) {
+#pragma unroll
+                    for (int k = 0; k < SSC_MAX_STATE; ++k)
+                        if (k < g.d) g.S[((int64_t)t * g.m + row[et]) * g.d + k] = st[et][k];  // dynamics_model.py:225
+                }
+#pragma unroll
+                for (int k = 0; k < 2 * kMaxKS1; ++k) {
+                    float v = 0.0f;
+                    if (k < g.d) {
+                        v = nan_to_num_div(st[et][k < SSC_MAX_STATE ? k : 0], l_nm[0 * 8 + (k & 7)], l_nm[1 * 8 + (k & 7)]);
+                    } else if (k < g.in) {
+                        const int ai = (k - g.d) & 3;
+                        v = nan_to_num_div(g.A[(rowc[et] * g.H + t) * g.a + ai], l_nm[2 * 8 + ai], l_nm[3 * 8 + ai]);
+                    }
+                    xs[et][k] = v;
+                }
+            }
+        }
+        // ---- layer 1 on fp32 MFMA: D[unit][row] = W1^T x + b1 -> ReLU -> bf16 B fragments --------
+        bf16x8 h1f[ET][UT][2];
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            const f32x16 c1 = lds_tile16(l_b1 + (ut * 2 + half) * 16);
+            f32x16 acc[ET];
+#pragma unroll
+            for (int et = 0; et < ET; ++et) acc[et] = c1;
+#pragma unroll
+            for (int ks = 0; ks < kMaxKS1; ++ks)
+                if (ks < g.ks1) {  // block-uniform
+                    const float w = l_w1[(ks * UT + ut) * 64 + lane];
+#pragma unroll
+                    for (int et = 0; et < ET; ++et) {
+                        const float bop = half ? xs[et][2 * ks + 1] : xs[et][2 * ks];
+                        acc[et] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bop, acc[et], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+                relu_to_frags(acc[et], h1f[et][ut][0], h1f[et][ut][1]);
+                // Pin the conversion HERE.  The fragments are first used inside the jt loop, so the
+                // optimiser otherwise sinks ReLU+convert down to that loop's preheader and keeps all
+                // 2*UT fp32 accumulator tiles (32 VGPRs each) alive until then -> hundreds of spills.
+                asm volatile("" : "+v"(h1f[et][ut][0]), "+v"(h1f[et][ut][1]));
+            }
+            __builtin_amdgcn_sched_barrier(0);  // and one unit tile at a time in the machine scheduler
+        }
+        // ---- hidden layer 2 (+ output layer fused per tile) -------------------------------------
+        f32x16 acc3[ET];
+#pragma unroll
+        for (int et = 0; et < ET; ++et) acc3[et] = lds_tile16(l_b3 + half * 16);
+        if (NFC == 2) {
+#pragma unroll 1
+            for (int jt = 0; jt < UT; ++jt) {
+                const unsigned char *buf = l_a2 + (UT > 1 ? (jt & 1) * A2_TILE : 0);
+                // prefetch the next W2^T tile (next jt, or tile 0 of the next step) into registers
+                const bool more = (UT > 1) && (jt + 1 < UT || t + 1 < g.H);
+                const int jn = (jt + 1 < UT) ? jt + 1 : 0;
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < STAGE; ++q) {
+                        const int e = q * kDynThreads + tid;
+                        if (e < A2_TILE / 16) stage[q] = a2_src[(size_t)jn * (A2_TILE / 16) + e];
+                    }
+                }
+                const f32x16 c2 = lds_tile16(l_b2 + (jt * 2 + half) * 16);
+                f32x16 acc2[ET];
+#pragma unroll
+                for (int et = 0; et < ET; ++et) acc2[et] = c2;
+                // software-pipelined fragment reads, two k-steps ahead; the fences pin the order so
+                // that the prefetch depth (and with it the register footprint) stays what is written
+                constexpr int NK = UT * 2;
+                bf16x8 ring[2];
+                ring[0] = *reinterpret_cast<const bf16x8 *>(buf + (0 * 64 + lane) * 16);
+                ring[1] = *reinterpret_cast<const bf16x8 *>(buf + (1 * 64 + lane) * 16);
+#pragma unroll
+                for (int i = 0; i < NK; ++i) {
+                    const bf16x8 a = ring[i & 1];
+                    if (i + 2 < NK) ring[i & 1] = *reinterpret_cast<const bf16x8 *>(buf + ((i + 2) * 64 + lane) * 16);
+#pragma unroll
+                    for (int et = 0; et < ET; ++et)
+                        acc2[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[et][i >> 1][i & 1], acc2[et], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const bf16x8 a30 = *reinterpret_cast<const bf16x8 *>(l_a3 + ((jt * 2 + 0) * 64 + lane) * 16);
+                const bf16x8 a31 = *reinterpret_cast<const bf16x8 *>(l_a3 + ((jt * 2 + 1) * 64 + lane) * 16);
+#pragma unroll
+                for (int et = 0; et < ET; ++et) {
+                    bf16x8 f0, f1;
+                    relu_to_frags(acc2[et], f0, f1);
+                    acc3[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, f0, acc3[et], 0, 0, 0);
+                    acc3[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, f1, acc3[et], 0, 0, 0);
+                }
+                if (UT > 1) {
+                    // the other buffer's last readers (tile jt-1) all passed the previous barrier
+                    if (more) {
+                        unsigned char *nb = l_a2 + ((jt + 1) & 1) * A2_TILE;
+#pragma unroll
+                        for (int q = 0; q < STAGE; ++q) {
+                            const int e = q * kDynThreads + tid;
+                            if (e < A2_TILE / 16) reinterpret_cast<f32x4 *>(nb)[e] = stage[q];
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < UT * 2; ++i) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a3 + (i * 64 + lane) * 16);
+#pragma unroll
+                for (int et = 0; et < ET; ++et)
+                    acc3[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[et][i >> 1][i & 1], acc3[et], 0, 0, 0);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- z[o]: rows 0..3 sit in regs 0..3 of half 0, rows 4..7 in regs 0..3 of half 1 ------------
+#pragma unroll
+        for (int et = 0; et < ET; ++et) {
+            float z[SSC_MAX_STATE];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float mine = acc3[et][o], other = __shfl_xor(acc3[et][o], 32);
+                z[o] = half ? other : mine;
+                z[4 + o] = half ? mine : other;
+            }
+            if (g.fwd_mode) {
+                if (valid[et] && half == 0) {
+#pragma unroll
+                    for (int o = 0; o < SSC_MAX_STATE; ++o)
+                        if (o < g.out) g.S[row[et] * g.out + o] = z[o];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < SSC_MAX_STATE; ++k)
+                    if (k < g.d) st[et][k] = st[et][k] + (z[k] * l_nm[5 * 8 + k] + l_nm[4 * 8 + k]);  // :234-237
+            }
+        }
+    }
+    if (!g.fwd_mode) {
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+            if (valid[et] && half == 0) {
+#pragma unroll
+                for (int k = 0; k < SSC_MAX_STATE; ++k)
+                    if (k < g.d) g.S[((int64_t)g.H * g.m + row[et]) * g.d + k] = st[et][k];  // :240
+            }
+    }
+}
+
+static int tiles_for(int depth) { return depth <= 32 ? 1 : (depth <= 128 ? 4 : 16); }
+
+bool dyn_mfma_supported(const ssc_mlp_desc *mlp, int state_dim, int act_dim) {
+    (void)state_dim; (void)act_dim;
+    const int nfc = mlp->n_layers - 1;
+    if (nfc != 1 && nfc != 2) return false;
+    const int depth = mlp->dims[1];
+    if (depth > 512 || (nfc == 2 && mlp->dims[2] != depth)) return false;
+    if (mlp->dims[0] > 2 * kMaxKS1 || mlp->dims[mlp->n_layers] > SSC_MAX_STATE) return false;
+    return true;
+}
+
+size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp) {
+    const int nfc = mlp->n_layers - 1;
+    if (nfc != 1 && nfc != 2) return 256;
+    return make_pack(tiles_for(mlp->dims[1]), nfc).total;
+}
+
+template <int UT, int NFC>
+static int launch_sim(const DynSimArgs &g, hipStream_t s) {
+    const size_t lds = (size_t)(NFC == 2 ? 2 * UT * 2048 : 0) + (size_t)UT * 2048 + (size_t)kMaxKS1 * UT * 256 +
+                       (size_t)UT * 128 * 2 + 128 + 192;
+    auto kern = dyn_mfma_sim_kernel<UT, NFC>;
+    if (lds > 64 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "hipFuncSetAttribute(dyn_mfma_sim_kernel)");
+        if (rc) return rc;
+    }
+    const unsigned grid = (unsigned)((g.m + kDynRows - 1) / kDynRows);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDynThreads), lds, s, g);
+    return check_launch("dyn_mfma_sim_kernel");
+}
+
+static int run_mfma(const ssc_mlp_desc *mlp, const ssc_norm *norm, DynSimArgs &g, void *wsv, hipStream_t s) {
+    const int nfc = mlp->n_layers - 1;
+    const int depth = mlp->dims[1];
+    const int UT = tiles_for(depth);
+    const DynPack pk = make_pack(UT, nfc);
+    DynNet n;
+    n.in = mlp->dims[0]; n.depth = depth; n.out = mlp->dims[mlp->n_layers]; n.nfc = nfc;
+    n.W1 = mlp->W[0]; n.b1 = mlp->b[0];
+    n.W2 = (nfc == 2) ? mlp->W[1] : nullptr; n.b2 = (nfc == 2) ? mlp->b[1] : nullptr;
+    n.W3 = mlp->W[nfc]; n.b3 = mlp->b[nfc];
+    unsigned char *ws = static_cast<unsigned char *>(wsv);
+    const int64_t n_pack = (nfc == 2 ? (int64_t)UT * UT * 1024 : 0) + (int64_t)UT * 1024 + (int64_t)kMaxKS1 * UT * 64 +
+                           2 * (int64_t)UT * 32 + 32;
+    ssc_norm nm{};
+    if (norm) nm = *norm;
+    hipLaunchKernelGGL(dyn_pack_kernel, dim3(blocks_for(n_pack)), dim3(256), 0, s, n, UT, pk, nm, ws);
+    g.in = n.in; g.out = n.out; g.ks1 = (n.in + 1) / 2;
+    g.a2 = ws + pk.a2; g.a3 = ws + pk.a3;
+    g.w1 = reinterpret_cast<const float *>(ws + pk.w1); g.b1 = reinterpret_cast<const float *>(ws + pk.b1);
+    g.b2 = reinterpret_cast<const float *>(ws + pk.b2); g.b3 = reinterpret_cast<const float *>(ws + pk.b3);
+    g.nm = reinterpret_cast<const float *>(ws + pk.nm);
+#define SSC_DYN_CASE(U, F) if (UT == U && nfc == F) return launch_sim<U, F>(g, s)
+    SSC_DYN_CASE(1, 1); SSC_DYN_CASE(4, 1); SSC_DYN_CASE(16, 1);
+    SSC_DYN_CASE(1, 2); SSC_DYN_CASE(4, 2); SSC_DYN_CASE(16, 2);
+#undef SSC_DYN_CASE
+    return set_error(SSC_EUNSUPPORTED, "dyn_mfma: no kernel for UT=%d nfc=%d", UT, nfc);
+}
+
+int dyn_mfma_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m, int32_t H, int32_t state_dim,
+                         int32_t act_dim, const float *d_s0, int64_t s0_rows, const float *d_A, float *d_S,
+                         void *ws, hipStream_t s) {
+    DynSimArgs g{};
+    g.m = m; g.H = H; g.d = state_dim; g.a = act_dim; g.fwd_mode = 0;
+    g.s0 = d_s0; g.s0_rows = s0_rows; g.A = d_A; g.S = d_S;
+    return run_mfma(mlp, norm, g, ws, s);
+}
+
+int dyn_mfma_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float *d_y, void *ws, hipStream_t s) {
+    DynSimArgs g{};
+    g.m = m; g.H = 1; g.d = 0; g.a = 0; g.fwd_mode = 1;
+    g.s0 = nullptr; g.s0_rows = 1; g.A = d_x; g.S = d_y;
+    return run_mfma(mlp, nullptr, g, ws, s);
 }
 
 }  // namespace ssc

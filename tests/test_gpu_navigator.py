@@ -179,3 +179,68 @@ def test_mpc_pipeline_select_action(nav):
         assert np.array_equal(path[p], Sn[:, row])
     clean, _ = nav.mpc_select_action(A, S, torch.as_tensor(best, device="cuda"), P, 0.0, 5, 100, 3, want_path=False)
     assert np.array_equal(clean.cpu().numpy()[:, 0], An[np.arange(P) * N + best, 0, 0])
+
+
+# ------------------------------------------------------------------ bf16 MFMA path --
+MFMA_SHAPES = [(3, 32, 2), (4, 500, 500, 3), (3, 500, 2), (4, 100, 100, 3), (12, 64, 8), (5, 20, 20, 2)]
+
+
+@pytest.mark.parametrize("dims", MFMA_SHAPES)
+def test_mlp_forward_mfma(nav, dims):
+    rng = np.random.default_rng(sum(dims) + 1)
+    Ws, bs = make_mlp(rng, dims)
+    d = dims[-1]
+    model = nav.DynamicsModel(Ws, bs, make_norm(rng, d, max(1, dims[0] - d)), state_dim=d, act_dim=max(1, dims[0] - d))
+    for m in (1, 31, 64, 255, 257, 3000):
+        x = rng.normal(size=(m, dims[0])).astype(np.float32)
+        got = model.forward(x, precision="bf16_mfma").cpu().numpy()
+        ref = O.mlp_forward(x, Ws, bs)
+        emu = O.mlp_forward_bf16emu(x, Ws, bs)
+        scale = np.maximum(1.0, np.abs(ref).max())
+        assert np.max(np.abs(got - ref)) <= 3e-2 * scale, (dims, m)      # 3e-2 rel (bf16)
+        assert np.max(np.abs(got - emu)) <= 2e-3 * scale, (dims, m)      # same roundings, different sum order
+        assert np.mean(np.abs(got - emu)) <= 1e-4 * scale, (dims, m)
+
+
+def test_mfma_weight_layout_one_hot(nav):
+    """Exact check of the fragment packing: one-hot weights route a single input through chosen hidden
+    units; any row/column or k-permutation mix-up shows up as an exact mismatch."""
+    rng = np.random.default_rng(0)
+    for trial in range(6):
+        depth, in_dim, out_dim = 500, 4, 3
+        Ws = [np.zeros((in_dim, depth), np.float32), np.zeros((depth, depth), np.float32), np.zeros((depth, out_dim), np.float32)]
+        bs = [np.zeros(depth, np.float32), np.zeros(depth, np.float32), np.zeros(out_dim, np.float32)]
+        i, u, v, o = int(rng.integers(in_dim)), int(rng.integers(depth)), int(rng.integers(depth)), int(rng.integers(out_dim))
+        Ws[0][i, u] = 1.0
+        Ws[1][u, v] = 0.5
+        Ws[2][v, o] = 2.0
+        bs[2][:] = [0.25, -0.5, 1.0]
+        model = nav.DynamicsModel(Ws, bs, make_norm(rng, 3, 1), state_dim=3, act_dim=1)
+        x = rng.uniform(0.1, 2.0, size=(300, in_dim)).astype(np.float32)
+        got = model.forward(x, precision="bf16_mfma").cpu().numpy()
+        ref = np.tile(bs[2], (300, 1)).astype(np.float64)
+        ref[:, o] += 2.0 * O.round_bf16(0.5 * O.round_bf16(x[:, i]).astype(np.float64)).astype(np.float64)
+        assert np.max(np.abs(got - ref)) < 1e-6, (trial, i, u, v, o)
+
+
+@pytest.mark.parametrize("dims,H", [((3, 32, 2), 4), ((4, 500, 500, 3), 4), ((3, 500, 2), 20), ((4, 128, 128, 3), 7)])
+def test_forward_sim_mfma(nav, dims, H):
+    rng = np.random.default_rng(17 + H)
+    d, a = dims[-1], dims[0] - dims[-1]
+    Ws, bs = make_mlp(rng, dims)
+    norm = make_norm(rng, d, a)
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=a, precision="bf16_mfma")
+    for m in (1, 300, 1000):
+        A = rng.uniform(-1, 1, size=(m, H, a)).astype(np.float32)
+        for s0 in (rng.normal(size=d).astype(np.float32) * 0.3, rng.normal(size=(m, d)).astype(np.float32) * 0.3):
+            S = model.do_forward_sim(s0, A).cpu().numpy()
+            ref = O.dyn_forward_sim(s0, A, norm32(norm), Ws, bs)
+            emu = O.dyn_forward_sim(s0, A, norm32(norm), Ws, bs, forward=O.mlp_forward_bf16emu)
+            scale = np.maximum(1.0, np.abs(ref).max())
+            assert S.shape == (H + 1, m, d)
+            assert np.array_equal(S[0], np.broadcast_to(s0, (m, d)))
+            assert np.max(np.abs(S - ref)) <= 3e-2 * scale, (dims, H, m)
+            assert np.max(np.abs(S - emu)) <= 3e-3 * scale, (dims, H, m)
+    # fp32 and MFMA paths agree on the same inputs
+    Sf = model.do_forward_sim(s0, A, precision="f32").cpu().numpy()
+    assert np.max(np.abs(Sf - S)) <= 3e-2 * np.maximum(1.0, np.abs(Sf).max())
