@@ -1,0 +1,378 @@
+"""Agent-side drop-in surface: the ``RLAgent`` family of
+smartstart/reinforcementLearningCore/agents_abstract_classes.py and GPU-backed counterparts of
+``DDPG_Baselines_agent`` (action path) and ``NND_MB_agent`` (the SmartStart navigator).
+
+Constructor keyword names follow the reference classes so existing call sites keep working; the
+TensorFlow session argument ``sess`` is accepted and ignored.  Learning (DDPG / dynamics-model
+training) is NOT part of the accelerated path (SURVEY.md section 8f "next"): weights are plain torch
+tensors that a trainer may overwrite through ``set_weights``; ``train()`` raises.
+"""
+from __future__ import annotations
+
+import abc
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _ffi, navigator
+from .numerical import (distances_left, elliptical_euclidean_distance_function_generator,
+                        get_start_waypoints_final_states_steps, path_deltas_stds_and_means_per_dim,
+                        path_shortcutter, radii_calc)
+from .replay_buffer import ReplayBuffer
+from .vec_env import ActorPolicy
+
+
+# --------------------------------------------------------------------------------- ABCs --
+class RLAgent(metaclass=abc.ABCMeta):
+    """agents_abstract_classes.py:6-53"""
+
+    @abc.abstractmethod
+    def get_action(self, state):
+        """state -> action appropriate for the environment"""
+
+    @abc.abstractmethod
+    def observe(self, state, action, reward, new_state, done):
+        """called after every env.step"""
+
+    @abc.abstractmethod
+    def render(self, env, **kwargs):
+        """render the environment the agent is in"""
+
+    def start_new_episode(self, state):
+        pass
+
+    def end_episode(self):
+        pass
+
+    def get_param_dict(self):
+        raise NotImplementedError("Agent hasn't overridden get_param_dict, if you don't wish to implement it "
+                                  "just return None")
+
+
+class NavigationRLAgent(RLAgent):
+    """agents_abstract_classes.py:55-65"""
+
+    def start_new_episode_plan(self, state, path_to_follow):
+        raise NotImplementedError
+
+
+class ValueFuncRLAgent(RLAgent):
+    """agents_abstract_classes.py:68-80"""
+
+    @abc.abstractmethod
+    def get_state_value(self, state):
+        """value of ``state`` (max over actions)"""
+
+
+class ReplayBufferRLAgent(RLAgent):
+    """agents_abstract_classes.py:82-91"""
+
+    def __init__(self):
+        self.replay_buffer = None
+
+    def set_replay_buffer_main_agent(self, new_main_agent):
+        self.replay_buffer.set_main_agent(new_main_agent)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# --------------------------------------------------------------------------------- DDPG --
+class DecayingOrnsteinUhlenbeckActionNoise:
+    """DDPG_Baselines_agent.py:52-78 over baselines' OrnsteinUhlenbeckActionNoise [third-party]:
+    x <- x + theta (mu - x) dt + sigma sqrt(dt) N(0,1); output x * max(epsilon, 0)."""
+
+    def __init__(self, epsilon, min_epsilon, epsilon_decay_factor, mu, sigma, theta=.15, dt=1e-2, x0=None):
+        self.mu, self.sigma, self.theta, self.dt, self.x0 = np.asarray(mu, np.float64), sigma, theta, dt, x0
+        self.epsilon, self.min_epsilon, self.epsilon_decay_factor = epsilon, min_epsilon, epsilon_decay_factor
+        self.reset()
+
+    def __call__(self):
+        x = self.x_prev + self.theta * (self.mu - self.x_prev) * self.dt + \
+            self.sigma * np.sqrt(self.dt) * np.random.normal(size=self.mu.shape)
+        self.x_prev = x
+        return x * max(self.epsilon, 0)
+
+    def reset(self):
+        self.x_prev = self.x0 if self.x0 is not None else np.zeros_like(self.mu)
+
+    def reduce_epsilon(self):
+        self.epsilon = max(self.epsilon * self.epsilon_decay_factor, self.min_epsilon)
+
+
+def init_actor_weights(obs_dim, h1, h2, nb_actions, generator=None):
+    """tf.layers.dense defaults in Actor_Editted (models_editted.py:44-59): glorot-uniform kernels,
+    zero biases; last layer U(-3e-3, 3e-3)."""
+    g = generator
+
+    def glorot(i, o):
+        lim = float(np.sqrt(6.0 / (i + o)))
+        return (torch.rand((i, o), generator=g) * 2 - 1) * lim
+    return dict(W1=glorot(obs_dim, h1), b1=torch.zeros(h1), W2=glorot(h1, h2), b2=torch.zeros(h2),
+                W3=(torch.rand((h2, nb_actions), generator=g) * 2 - 1) * 3e-3, b3=torch.zeros(nb_actions))
+
+
+class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
+    """Action path of smartstart/RLAgents/DDPG_Baselines_agent.py (:86-273): actor forward on the GPU
+    (``ssc_actor_forward``), decaying OU noise, clip, double ``scale``; transitions go to the shared
+    ReplayBuffer.  ``as_policy()`` hands the same actor to the fused rollout kernel."""
+
+    def __init__(self, env, sess=None, replay_buffer=None, buffer_size=10000, batch_size=64, num_train_iterations=50,
+                 num_steps_before_train=40, ou_epsilon=1.0, ou_min_epsilon=0.01, ou_epsilon_decay_factor=.99,
+                 ou_mu=0.4, ou_sigma=0.2, ou_theta=.15, actor_lr=1e-4, actor_h1=64, actor_h2=64, critic_lr=1e-3,
+                 critic_h1=64, critic_h2=64, gamma=0.99, tau=0.001, layer_norm=False, normalize_observations=False,
+                 normalize_returns=False, critic_l2_reg=0, enable_popart=False, clip_norm=None, reward_scale=1.,
+                 lastLayerTanh=False, finalizeGraph=True, device="cuda", precision="f32", seed=None):
+        args = dict(locals())
+        self.param_dict = {k: (v if isinstance(v, (int, float, bool, str, type(None))) else "Not serializable")
+                           for k, v in args.items() if k not in ("self", "__class__")}   # :135-137
+        if layer_norm or normalize_observations or normalize_returns or enable_popart:
+            raise NotImplementedError("layer_norm / observation & return normalisation / popart are not on the "
+                                      "accelerated path (every shipped run uses False)")
+        self.env = env
+        self.device = torch.device(device)
+        self.lib = _ffi.lib()
+        self.batch_size = batch_size
+        self.num_train_iterations = num_train_iterations
+        self.num_steps_before_train = num_steps_before_train
+        self.remaining_steps_before_train = num_steps_before_train
+        self.reward_scale = reward_scale
+        self.lastLayerTanh = bool(lastLayerTanh)
+        self.precision = precision
+        self.replay_buffer = replay_buffer if replay_buffer is not None else ReplayBuffer(self, buffer_size)
+        nb_actions = env.action_space.shape[-1]
+        obs_dim = env.observation_space.shape[-1]
+        gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
+        self.set_weights(init_actor_weights(obs_dim, actor_h1, actor_h2, nb_actions, gen))
+        self.decaying_ou_action_noise = DecayingOrnsteinUhlenbeckActionNoise(
+            ou_epsilon, ou_min_epsilon, ou_epsilon_decay_factor, mu=ou_mu * np.ones(nb_actions),
+            sigma=float(ou_sigma) * np.ones(nb_actions), theta=ou_theta)   # :152-157
+        self.ou = dict(mu=ou_mu, sigma=ou_sigma, theta=ou_theta)
+
+    # ---- weights ---------------------------------------------------------------------------
+    def set_weights(self, weights):
+        """weights: dict W1[obs,h1] b1 W2[h1,h2] b2 W3[h2,act] b3 (TensorFlow layout)."""
+        self.weights = {k: torch.as_tensor(v, dtype=torch.float32).to(self.device).contiguous()
+                        for k, v in weights.items()}
+        w = self.weights
+        self.obs_dim, self.h1 = w["W1"].shape
+        self.h2, self.act_dim = w["W3"].shape
+        d = _ffi.ActorDesc()
+        d.obs_dim, d.h1, d.h2, d.act_dim = self.obs_dim, self.h1, self.h2, self.act_dim
+        d.W1, d.b1, d.W2, d.b2, d.W3, d.b3 = (w[k].data_ptr() for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
+        d.last_layer_tanh = int(self.lastLayerTanh)
+        d.precision = _ffi.SSC_PREC_F32 if self.precision == "f32" else _ffi.SSC_PREC_BF16_MFMA
+        self._desc = d
+
+    def actor(self, obs):
+        """Actor_Editted forward (models_editted.py:38-61) on a batch: obs [m, obs_dim] -> [m, act_dim]."""
+        o = torch.as_tensor(obs, dtype=torch.float32, device=self.device).reshape(-1, self.obs_dim).contiguous()
+        out = torch.empty((o.shape[0], self.act_dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.ssc_actor_forward(ctypes.byref(self._desc), o.shape[0], _ffi.ptr(o), _ffi.ptr(out),
+                                                  _stream()))
+        return out
+
+    # ---- RLAgent ---------------------------------------------------------------------------
+    def scale(self, actions):
+        """:236-240"""
+        actions = np.clip(actions, -1, 1)
+        low, high = self.env.action_space.low, self.env.action_space.high
+        return (((actions + 1) / 2) * (high - low)) + low
+
+    def get_action(self, state):
+        """:206-234 -> DDPG_editted.pi (ddpg_editted.py:255-272)"""
+        action = self.actor(np.asarray(state, np.float32)[None, :])[0].cpu().numpy()   # fp32, like sess.run
+        noise = self.decaying_ou_action_noise()
+        action = action + noise.astype(np.float32)             # in-place add keeps fp32 (:266-270)
+        action = np.clip(action, -1.0, 1.0)                    # :271
+        return self.scale(self.scale(action))
+
+    def as_policy(self, precision=None):
+        """The same action path as a fused-rollout policy (current epsilon)."""
+        n = self.decaying_ou_action_noise
+        return ActorPolicy(self.weights, last_layer_tanh=self.lastLayerTanh, precision=precision or "bf16_mfma",
+                           ou_mu=float(self.ou["mu"]), ou_sigma=float(self.ou["sigma"]), ou_theta=float(self.ou["theta"]),
+                           ou_dt=n.dt, ou_epsilon=float(max(n.epsilon, 0)))
+
+    def get_state_value(self, state):
+        raise NotImplementedError("critic forward / Q-values belong to the DDPG training step (SURVEY.md 8f, next)")
+
+    def observe(self, state, action, reward, new_state, done):
+        """:242-247 (store_transition, ddpg_editted.py:281-285); training is not on this path."""
+        self.replay_buffer.add(self, state, action, reward * self.reward_scale, done, new_state)
+        self.remaining_steps_before_train -= 1
+
+    def start_new_episode(self, state):
+        self.replay_buffer.start_new_episode(self)
+
+    def render(self, env, **kwargs):
+        return env.render()
+
+    def end_episode(self):
+        """:255-258"""
+        self.decaying_ou_action_noise.reset()
+        self.decaying_ou_action_noise.reduce_epsilon()
+
+    def get_param_dict(self):
+        return self.param_dict
+
+    def train(self):
+        raise NotImplementedError("DDPG training is outside the accelerated path (SURVEY.md section 8f)")
+
+
+# ---------------------------------------------------------------------------- navigator --
+def init_dynamics_weights(in_dim, out_dim, num_fc_layers, depth_fc_layers, generator=None):
+    """xavier-NORMAL weights and biases (feedforward_network.py:8, 14-23)."""
+    dims = [in_dim] + [depth_fc_layers] * num_fc_layers + [out_dim]
+    Ws, bs = [], []
+    for i in range(len(dims) - 1):
+        Ws.append(torch.randn((dims[i], dims[i + 1]), generator=generator) * float(np.sqrt(2.0 / (dims[i] + dims[i + 1]))))
+        bs.append(torch.randn(dims[i + 1], generator=generator) * float(np.sqrt(2.0 / (1 + dims[i + 1]))))
+    return Ws, bs
+
+
+class NND_MB_agent(NavigationRLAgent):
+    """The SmartStart navigator (smartstart/RLAgents/NND_MB_agent.py): MPC over a learned dynamics
+    model -- sample ``num_control_samples`` action sequences of length ``horizon``, forward-simulate
+    them (``ssc_dyn_forward_sim``), score waypoint progress (``ssc_mpc_score``), execute the first action
+    of the best sequence plus small Gaussian noise (``ssc_mpc_select_action``)."""
+
+    noiseToSignal = 0.01
+    actions_ag = 'nc'
+
+    def __init__(self, env, sess=None, replay_buffer=None, BUFFER_SIZE=10000,
+                 final_steps=10, steps_per_waypoint=1, mean_per_stepsize=1, std_per_stepsize=1,
+                 stepsizes_in_waypoint_radii=1,
+                 gamma=.75, horizontal_penalty_factor=.5, horizon=20, num_control_samples=5000, path_shortcutting=True,
+                 steps_before_giving_up_on_waypoint=5,
+                 num_fc_layers=1, depth_fc_layers=500,
+                 training_data=None, weights=None, biases=None, norm=None,
+                 device="cuda", precision="bf16_mfma", seed=1234, per_row_projection=False, **unused):
+        self.env = env
+        self.device = torch.device(device)
+        self.replay_buffer = replay_buffer if replay_buffer is not None else ReplayBuffer(self, BUFFER_SIZE)
+        self.final_steps, self.steps_per_waypoint = final_steps, steps_per_waypoint
+        self.mean_per_stepsize, self.std_per_stepsize = mean_per_stepsize, std_per_stepsize
+        self.stepsizes_in_waypoint_radii = stepsizes_in_waypoint_radii
+        self.gamma, self.horizontal_penalty_factor = gamma, horizontal_penalty_factor
+        self.horizon, self.N = horizon, num_control_samples
+        self.path_shortcutting = path_shortcutting
+        self.steps_before_giving_up_on_waypoint = steps_before_giving_up_on_waypoint
+        self.theta = 1                      # NND_MB_agent.py:143
+        self.noise_amount = 0.005           # :188-191
+        self.per_row_projection = per_row_projection
+        self.seed, self._t = int(seed), 0
+        state_dim = env.observation_space.shape[0]
+        act_dim = env.action_space.shape[0]
+        if norm is None:
+            if training_data is None:
+                raise ValueError("NND_MB_agent needs `training_data` (dataX, dataY, dataZ) or `norm` statistics")
+            norm = self.normalisation_from_data(training_data["dataX"], training_data["dataY"], training_data["dataZ"])
+        if weights is None:
+            gen = torch.Generator().manual_seed(self.seed)
+            weights, biases = init_dynamics_weights(state_dim + act_dim, state_dim, num_fc_layers, depth_fc_layers, gen)
+        self.dyn_model = navigator.DynamicsModel(weights, biases, norm, state_dim, act_dim, device=device,
+                                                 precision=precision)
+        self.state_dim, self.act_dim = state_dim, act_dim
+        self.desired_states = None
+        self.param_dict = None
+
+    @staticmethod
+    def normalisation_from_data(dataX, dataY, dataZ):
+        """NND_MB_agent.py:302-315 (mean / std per column)."""
+        X, Y, Z = (np.asarray(v, np.float64) for v in (dataX, dataY, dataZ))
+        return dict(mean_x=X.mean(0), std_x=(X - X.mean(0)).std(0), mean_y=Y.mean(0), std_y=(Y - Y.mean(0)).std(0),
+                    mean_z=Z.mean(0), std_z=(Z - Z.mean(0)).std(0))
+
+    # ---- planning (host, once per episode) -----------------------------------------------------
+    def start_new_episode_plan(self, starting_state, path_to_follow):
+        """NND_MB_agent.py:375-423 (without the dynamics-model retraining trigger :421-423)."""
+        self.current_desired_state_index = 0
+        self.actions_done_for_current_waypoint = 0
+        stds, means = path_deltas_stds_and_means_per_dim(path_to_follow)
+        self.stds = stds
+        self.radii = radii_calc(means, stds, self.mean_per_stepsize, self.std_per_stepsize,
+                                self.stepsizes_in_waypoint_radii)
+        self.distance_function = elliptical_euclidean_distance_function_generator(self.radii)
+        if self.path_shortcutting:
+            self.path_to_follow = path_shortcutter(path_to_follow, self.distance_function, self.theta)
+        else:
+            self.path_to_follow = np.asarray(path_to_follow, np.float64)
+        self.desired_states = np.asarray(get_start_waypoints_final_states_steps(self.path_to_follow,
+                                                                                self.steps_per_waypoint))
+        self.distances_left = distances_left(self.desired_states, self.distance_function)
+        self._problems = None
+
+    @property
+    def current_desired_state(self):
+        return self.desired_states[self.current_desired_state_index]
+
+    @property
+    def next_desired_state(self):
+        return self.desired_states[min(self.current_desired_state_index + 1, len(self.desired_states) - 1)]
+
+    def move_to_next(self, pt, desired_state_index, distance_to_curr, distance_to_next):
+        """:491-496"""
+        return np.logical_and(np.logical_or(distance_to_curr <= self.theta, distance_to_next <= distance_to_curr),
+                              desired_state_index != len(self.desired_states) - 1)
+
+    def close_enough_to_goal(self, current_state):
+        """:425-432"""
+        if self.distance_function(current_state, self.desired_states[-1]) <= self.theta:
+            return True
+        return self.current_desired_state_index == len(self.desired_states) - 1 and \
+            self.final_steps <= self.actions_done_for_current_waypoint
+
+    # ---- acting (GPU, every step) --------------------------------------------------------------
+    def get_action(self, state):
+        return self.get_action_with_predicted_states(state)[0]
+
+    def get_best_sim_actions(self, curr_nn_state):
+        """:498-520 -> (best_action, best_sim_number, best_sequence, best_path) and the device tensors."""
+        low, high = self.env.action_space.low, self.env.action_space.high
+        A = navigator.mpc_sample_actions(1, self.N, self.horizon, low, high, self.seed, 0, self._t, self.device)
+        S = self.dyn_model.do_forward_sim(np.asarray(curr_nn_state, np.float32), A)
+        wp = self.desired_states
+        if len(wp) < 2:   # the reference would raise IndexError at desired_states[b + 1]
+            wp = np.concatenate([wp, wp], axis=0)
+            left = np.asarray([0.0, 0.0])
+        else:
+            left = self.distances_left
+        ps = navigator.MpcProblemSet([wp], [left], [self.radii], [self.current_desired_state_index],
+                                     device=self.device, theta=self.theta, gamma=self.gamma,
+                                     horizontal_penalty_factor=self.horizontal_penalty_factor,
+                                     per_row_projection=self.per_row_projection)
+        scores, best, _ = navigator.mpc_score(ps, S)
+        return A, S, scores, best
+
+    def get_action_with_predicted_states(self, state):
+        """:339-358"""
+        self.actions_done_for_current_waypoint += 1
+        A, S, scores, best = self.get_best_sim_actions(state)
+        noise = self.noise_amount if self.actions_ag in ('nn', 'nc') else 0.0
+        action, path = navigator.mpc_select_action(A, S, best, 1, noise, self.seed, 0, self._t)
+        self._t += 1
+        return action[0].double().cpu().numpy(), path[0].double().cpu().numpy()
+
+    def observe(self, state, action, reward, new_state, done):
+        """:360-373"""
+        self.replay_buffer.add(self, state, action, reward, done, new_state)
+        distance_to_current = self.distance_function(new_state, self.current_desired_state)
+        distance_to_next = self.distance_function(new_state, self.next_desired_state)
+        if self.move_to_next(new_state, self.current_desired_state_index, distance_to_current, distance_to_next) or \
+                (self.actions_done_for_current_waypoint > self.steps_before_giving_up_on_waypoint and
+                 self.current_desired_state_index != len(self.desired_states) - 1):
+            self.current_desired_state_index += 1
+            self.actions_done_for_current_waypoint = 0
+
+    def render(self, env, **kwargs):
+        env.render()
+
+    def get_param_dict(self):
+        return self.param_dict
+
+    def train_dynamics_model(self):
+        raise NotImplementedError("dynamics-model training is outside the accelerated path (SURVEY.md 8f)")

@@ -1,0 +1,108 @@
+"""Host-side geometry / path utilities of the navigator -- the per-episode, O(path length)
+quantities that ``NND_MB_agent.start_new_episode_plan`` computes once per SmartStart episode
+(smartstart/RLAgents/NND_MB_agent.py:375-423) and uploads as kernel arguments (SURVEY.md
+Appendix A).  Counterparts of smartstart/utilities/numerical.py; numpy fp64 like the reference.
+
+These run on the host by design: they are tiny, sequential and executed once per episode; the
+per-step work (forward simulation, scoring) is on the GPU (csrc/dyn_*.hip, csrc/mpc.hip).
+"""
+from __future__ import annotations
+
+import bisect
+
+import numpy as np
+
+
+def path_deltas_stds_and_means_per_dim(path):
+    """numerical.py:30-59: per state dimension, std and mean of |path[i+1] - path[i]|."""
+    p = np.asarray(path, dtype=np.float64)
+    if len(p) <= 1:
+        raise ValueError("path needs at least two states")
+    deltas = np.abs(np.diff(p, axis=0))
+    return deltas.std(axis=0), deltas.mean(axis=0)
+
+
+def radii_calc(means, stds, num_means, num_stds, num_steps):
+    """numerical.py:61-62"""
+    return ((num_means * np.asarray(means)) + (num_stds * np.asarray(stds))) * num_steps
+
+
+def elliptical_euclidean_distance_function_generator(radii):
+    """numerical.py:101-126: d(x, y) = || (x - y) / radii ||_2 over the last axis."""
+    radii = np.asarray(radii, dtype=np.float64)
+    if not (radii > 0).all():
+        raise AssertionError("radii must be positive")
+
+    def distance_func(state, other_state):
+        state = np.asarray(state, dtype=np.float64)
+        other_state = np.asarray(other_state, dtype=np.float64)
+        return np.sqrt(np.sum(((state - other_state) / radii) ** 2, axis=max(state.ndim, other_state.ndim) - 1))
+
+    return distance_func
+
+
+def volume_of_n_dimensional_hyperellipsoid(radii):
+    """numerical.py:157-164 (the reference's ``np.product`` is gone in numpy 2)."""
+    from math import gamma, pi
+    dim = len(radii)
+    return ((pi ** (dim / 2.0)) / gamma((dim / 2.0) + 1)) * float(np.prod(radii))
+
+
+def length_weighted_activities_solver(activities, sub_extra=0):
+    """numerical.py:189-222: weighted interval scheduling, weight = end - start - sub_extra, touching
+    intervals compatible, ties resolved in favour of taking the later-ending interval; the first
+    interval (by end time) is seeded without ``sub_extra`` exactly like the reference."""
+    acts = sorted((tuple(int(v) for v in a) for a in activities), key=lambda a: a[1])
+    if not acts:
+        return 0, []
+    ends = [0, acts[0][1]]                       # row end times (strictly increasing)
+    best = [0, acts[0][1] - acts[0][0]]          # best weight using intervals ending <= ends[i]
+    take = [None, acts[0]]                       # interval taken at row i (or None)
+    back = [0, 0]                                # previous row
+    for a in acts[1:]:
+        j = bisect.bisect_right(ends, a[0]) - 1  # last row with end <= start
+        inc = best[j] + (a[1] - a[0] - sub_extra)
+        if a[1] == ends[-1]:
+            if inc >= best[-1]:
+                best[-1], take[-1], back[-1] = inc, a, j
+        else:
+            ends.append(a[1])
+            if inc >= best[-1]:
+                best.append(inc); take.append(a); back.append(j)
+            else:
+                best.append(best[-1]); take.append(None); back.append(len(ends) - 2)
+    chosen, i = [], len(ends) - 1
+    while True:
+        if take[i] is not None:
+            chosen.append(list(take[i]))
+        if back[i] == i:
+            break
+        i = back[i]
+    chosen.reverse()
+    return best[-1], chosen
+
+
+def path_shortcutter(path, distance_func, theta):
+    """numerical.py:226-246: drop interior states between any two states (>= 2 apart) that are within
+    ``theta`` of each other, choosing the non-overlapping shortcuts that delete the most states."""
+    a = np.asarray(path, dtype=np.float64)
+    dist = distance_func(a[:, None, :], a[None, :, :])
+    pairs = np.transpose(np.where(np.triu(dist <= theta, k=2)))
+    _, chosen = length_weighted_activities_solver(pairs.tolist(), sub_extra=1)
+    drop = [k for i, j in chosen for k in range(i + 1, j)]
+    return np.delete(a, drop, axis=0)
+
+
+def get_start_waypoints_final_states_steps(path, steps_per_waypoint):
+    """smartstart/utilities/utilities.py:59-71: path[:-1:steps] + [path[-1]]."""
+    p = np.asarray(path, dtype=np.float64)
+    return np.concatenate([p[:-1:steps_per_waypoint], p[-1:]], axis=0)
+
+
+def distances_left(desired_states, distance_func):
+    """NND_MB_agent.py:411-418: remaining path length from each waypoint (last entry 0)."""
+    wp = np.asarray(desired_states, dtype=np.float64)
+    if len(wp) < 2:
+        return np.asarray([0.0])
+    seg = distance_func(wp[:-1], wp[1:])
+    return np.concatenate([np.cumsum(seg[::-1])[::-1], [0.0]])

@@ -1,0 +1,133 @@
+"""The training-loop driver: ``rlTrain`` with the reference's signature and control flow
+(smartstart/reinforcementLearningCore/rlTrain.py:13-133) for any ``gym.Env``-shaped env and any
+``RLAgent``, plus ``rl_train_vec`` -- the same loop over N device envs in fused chunks.
+``Episode`` / ``Summary`` keep the per-episode quantities of smartstart/utilities/datacontainers.py
+(:41-49, :61-80, :173-193); the JSON/GCS persistence of the reference is out of scope."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+
+class Episode:
+    """datacontainers.py:16-80"""
+
+    def __init__(self):
+        self.obs, self.action, self.reward, self.obs_tp1, self.done = [], [], [], [], []
+
+    def append(self, obs, action, reward, obs_tp1, done):
+        self.obs.append(np.ravel(obs).tolist())
+        self.action.append(np.ravel(action).tolist())
+        self.reward.append(float(reward))
+        self.obs_tp1.append(np.ravel(obs_tp1).tolist())
+        self.done.append(bool(done))
+
+    def total_reward(self):
+        return sum(self.reward)
+
+    def average_reward(self):
+        return sum(self.reward) / max(len(self.reward), 1)
+
+    def path(self):
+        return self.obs + [self.obs_tp1[-1]] if self.obs else []
+
+    def __len__(self):
+        return len(self.reward)
+
+
+class Summary:
+    """datacontainers.py:85-193: per-episode (steps, total_reward), best path, last ``last_x`` paths."""
+
+    def __init__(self, name=None, last_x=5):
+        self.name = name
+        self.episodes = []
+        self.best_path, self.best_reward = None, None
+        self.last_x, self.last_paths, self.last_rewards = last_x, [], []
+        self.smart_start_episodes = []
+        self.agent = None
+
+    def set_agent(self, agent):
+        self.agent = agent
+
+    def start_smart_start_episode(self):
+        self.smart_start_episodes.append(len(self.episodes))
+
+    def append(self, episode):
+        total = episode.total_reward()
+        self.episodes.append((len(episode), total))
+        if self.best_reward is None or total > self.best_reward:
+            self.best_reward, self.best_path = total, episode.path()
+        self.last_paths.append(episode.path())
+        self.last_rewards.append(total)
+        if len(self.last_paths) > self.last_x:
+            self.last_paths.pop(0)
+            self.last_rewards.pop(0)
+
+    def append_record(self, length, total_reward):
+        """A finished episode reported by the fused rollout kernel's episode ring (no path)."""
+        self.episodes.append((int(length), float(total_reward)))
+        if self.best_reward is None or total_reward > self.best_reward:
+            self.best_reward = float(total_reward)
+
+    def __len__(self):
+        return len(self.episodes)
+
+
+def rlTrain(agent, env, render=False, render_episode=False, print_results=True, print_steps=True,
+            num_episodes=500, max_steps=1000, progress_bar=False, id=None, num_ticks=100, print_time=False):
+    """rlTrain.py:13-133, minus the console plotting."""
+    name = agent.get_summary_name() if hasattr(agent, 'get_summary_name') else agent.__class__.__name__
+    spec_id = env.spec.id if getattr(env, "spec", None) is not None else type(env).__name__
+    summary = Summary(name + "_" + spec_id)                      # :50-55
+    summary.set_agent(agent)
+    times = [time.time()]
+    for i_episode in range(num_episodes):                        # :63
+        episode = Episode()
+        observation = env.reset()                                # :68
+        agent.start_new_episode(observation)                     # :71
+        if getattr(agent, "smart_start_pathing", False):
+            summary.start_smart_start_episode()
+        for step in range(max_steps):                            # :75
+            if render:
+                render = agent.render(env)
+            action = agent.get_action(observation)               # :81
+            new_observation, reward, done, _ = env.step(action)  # :84
+            if print_steps:
+                print("        Step: {}, State: {}, Action: {}, New_State: {}, Reward: {}".format(
+                    step, observation, action, new_observation, reward))
+            agent.observe(observation, action, reward, new_observation, done)   # :91
+            episode.append(observation, action, reward, new_observation, done)  # :94
+            if done:
+                break
+            observation = new_observation
+        agent.end_episode()                                      # :101
+        if print_results:
+            print("Episode: %d, steps: %d, reward: %.2f" % (i_episode, len(episode), episode.average_reward()))
+        summary.append(episode)                                  # :114
+        if print_time:
+            times.append(time.time())
+            print("took: " + str(times[-1] - times[-2]))
+    return summary
+
+
+def rl_train_vec(env, policy, num_chunks, chunk_steps=1024, ring_capacity=1 << 20, on_chunk=None):
+    """The rlTrain loop for N parallel device envs: ``num_chunks`` fused rollouts of ``chunk_steps``
+    steps each (auto-reset on done); every finished episode lands in the Summary as (len, return).
+    ``on_chunk(chunk, env)`` -- if given -- sees each TransitionChunk (e.g. to feed a replay buffer)."""
+    from .vec_env import EpisodeRing, TransitionChunk
+    summary = Summary("vec_" + env.spec.id)
+    ring = EpisodeRing(ring_capacity, env.device)
+    chunk = TransitionChunk(env.obs_dim, chunk_steps, env.n, env.device) if on_chunk is not None else None
+    pd = env.policy_desc(policy)
+    dropped = 0
+    for _ in range(num_chunks):
+        out = env.rollout(chunk_steps, out=chunk, ring=ring, log=on_chunk is not None, policy_desc=pd)
+        if on_chunk is not None:
+            on_chunk(out, env)
+        (ids, lens, rets), d = ring.drain()
+        dropped += d
+        for length, ret in zip(lens.tolist(), rets.tolist()):
+            summary.append_record(length, ret)
+    summary.dropped_episode_records = dropped
+    return summary

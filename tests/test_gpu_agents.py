@@ -1,0 +1,123 @@
+"""GPU end-to-end tests of the host drop-in layer: rlTrain with the GPU-backed agents, the
+navigator's get_action against the oracle pipeline, and the vectorised loop."""
+import numpy as np
+import pytest
+
+from oracle import ssc_oracle as O
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ssc():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no fallback")
+    import smartstartcontinuous_amd as pkg
+    pkg._ffi.lib()
+    return pkg
+
+
+def test_rltrain_with_ddpg_agent(ssc):
+    """The reference's DDPG_Baselines_example flow (examples/continuous/DDPG_Baselines_example.py:28-80)
+    with unchanged call structure: make_timed_env -> agent -> rlTrain."""
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    env = ssc.Continuous_MountainCarEnv_Editted.make_timed_env(0.33, max_episode_steps=60)
+    assert env.spec.id == "MountainCarContinuousActionX0.33-v0"
+    agent = DDPG_Baselines_agent(env, None, buffer_size=100000, batch_size=64, num_train_iterations=1,
+                                 num_steps_before_train=1, ou_epsilon=1.0, ou_min_epsilon=0.01,
+                                 ou_epsilon_decay_factor=.99, ou_mu=0.4, ou_sigma=0.6, ou_theta=.15, actor_lr=0.001,
+                                 actor_h1=64, actor_h2=32, critic_lr=0.001, critic_h1=64, critic_h2=32,
+                                 lastLayerTanh=True, seed=3)
+    np.random.seed(0)
+    summary = ssc.rlTrain(agent, env, print_results=False, print_steps=False, num_episodes=3, max_steps=1000)
+    assert [e[0] for e in summary.episodes] == [60, 60, 60]          # TimeLimit(60)
+    assert len(agent.replay_buffer) == 180 and len(agent.replay_buffer.episode_starting_indices) == 3
+    assert abs(agent.decaying_ou_action_noise.epsilon - 0.99 ** 3) < 1e-12
+    s, a, r, t, s2 = agent.replay_buffer.all_batch()
+    assert np.all(np.abs(a) <= 1.0) and t.sum() == 3 and np.allclose(r, -0.1 * a[:, 0] ** 2, atol=1e-6)
+    # the stored transitions obey the reference dynamics (power_scalar 0.33)
+    p2, v2, rr, _ = O.mc_step(s[:, 0], s[:, 1], a[:, 0], O.mc_power(0.33))
+    assert np.max(np.abs(p2 - s2[:, 0])) <= 2.4e-7 and np.max(np.abs(v2 - s2[:, 1])) <= 1e-8
+    # noise-free action == actor forward == oracle
+    agent.decaying_ou_action_noise.epsilon = 0.0
+    obs = np.array([-0.5, 0.01])
+    w = {k: v.cpu().numpy() for k, v in agent.weights.items()}
+    ref = O.actor_forward(obs[None, :].astype(np.float32), **w)[0]
+    assert np.max(np.abs(agent.get_action(obs) - ref)) <= 1e-5
+    # the same agent drives the fused kernel
+    venv = ssc.VecEnv("MountainCarContinuous-v0", 256, seed=1)
+    chunk = venv.rollout(8, agent.as_policy(precision="f32"))
+    torch.cuda.synchronize()
+    o = chunk.obs.cpu().numpy().transpose(1, 2, 0).reshape(-1, 2)
+    assert np.max(np.abs(chunk.act.cpu().numpy().reshape(-1) - np.clip(O.actor_forward(o, **w)[:, 0], -1, 1))) <= 1e-5
+    with pytest.raises(NotImplementedError):
+        agent.train()
+
+
+def test_navigator_get_action_matches_oracle_pipeline(ssc, golden_dir):
+    from smartstartcontinuous_amd.agents import NND_MB_agent
+    g = np.load(f"{golden_dir}/mc_reference_rollouts.npz")
+    env = ssc.make("MountainCarContinuous-v0", seed=2)
+    agent = NND_MB_agent(env, None, horizon=4, num_control_samples=5000, num_fc_layers=1, depth_fc_layers=32,
+                         training_data=dict(dataX=g["dataX"], dataY=g["dataY"], dataZ=g["dataZ"]),
+                         precision="f32", seed=77)
+    # plan along one of the reference's recorded rollouts
+    path = g["states_val"][3, :120]
+    start = path[0] + [0.002, 0.0005]
+    agent.start_new_episode_plan(start, path)
+    assert len(agent.desired_states) >= 2 and agent.distances_left[-1] == 0
+    stds, means = O.path_deltas_stds_and_means_per_dim(path)
+    assert np.allclose(agent.radii, O.radii_calc(means, stds, 1, 1, 1))
+    assert np.array_equal(agent.desired_states, O.waypoints_from_path(O.path_shortcutter(path, O.distance_func(agent.radii), 1)))
+    action, best_path = agent.get_action_with_predicted_states(start)
+    assert action.shape == (1,) and best_path.shape == (5, 2) and np.allclose(best_path[0], start, atol=1e-7)
+    # oracle pipeline on the same samples / weights
+    A = O.mpc_action_samples(77, 0, 5000, 4, 1, 0, [-1.0], [1.0])
+    Ws = [w.cpu().numpy() for w in agent.dyn_model.W]
+    bs = [b.cpu().numpy() for b in agent.dyn_model.b]
+    nm = NND_MB_agent.normalisation_from_data(g["dataX"], g["dataY"], g["dataZ"])
+    nm32 = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in nm.items()}
+    S = O.dyn_forward_sim(start.astype(np.float32), A, nm32, Ws, bs)
+    ref_scores, ref_best_score, ref_best, _ = O.mpc_scores_add_delta(
+        S, agent.desired_states, agent.distances_left, agent.radii, 0, theta=1, gamma=.75, hpf=.5)
+    # the path the kernel predicted is the oracle's path for SOME sample whose reference score is within tol of the max
+    d = np.max(np.abs(S - best_path[:, None, :]), axis=(0, 2))
+    chosen = int(np.argmin(d))
+    assert d[chosen] <= 1e-4 * max(1.0, np.abs(S).max())
+    assert ref_scores[chosen] >= ref_best_score - 1e-3 * max(1.0, abs(ref_best_score))
+    g0 = O.mpc_noise_gaussian(77, np.array([0], np.uint64), 0, 0)[0]
+    assert abs(action[0] - (float(A[chosen, 0, 0]) + 0.005 * g0)) <= 1e-6
+    # waypoint bookkeeping (NND_MB_agent.observe, :360-373)
+    idx0 = agent.current_desired_state_index
+    agent.observe(start, action, 0.0, agent.desired_states[min(idx0 + 1, len(agent.desired_states) - 1)], False)
+    assert agent.current_desired_state_index == idx0 + 1 and agent.actions_done_for_current_waypoint == 0
+    assert not agent.close_enough_to_goal(start) and agent.close_enough_to_goal(agent.desired_states[-1])
+
+
+def test_rl_train_vec_summary(ssc):
+    env = ssc.VecEnv("MountainCarContinuous-v0", 512, seed=9, max_episode_steps=50)
+    seen = []
+    summ = ssc.rl_train_vec(env, ssc.RandomPolicy(), num_chunks=3, chunk_steps=40,
+                            on_chunk=lambda chunk, e: seen.append(int(chunk.done.sum().item())))
+    stats = env.stats.cpu().numpy()
+    assert len(summ) == int(stats[3]) == sum(seen) and summ.dropped_episode_records == 0
+    assert len(summ) == 512 * 2                                 # 120 steps with a 50-step limit
+    assert all(l == 50 or r > 0 for l, r in summ.episodes)      # timed out, or ended by the +100 goal reward
+    assert abs(sum(r for _, r in summ.episodes) + float(env.ep_ret.sum()) - stats[0]) < 1.0
+
+
+def test_replay_buffer_ingests_chunk(ssc):
+    from smartstartcontinuous_amd.replay_buffer import ReplayBuffer
+    env = ssc.VecEnv("MountainCarContinuous-v0", 8, seed=4, max_episode_steps=10)
+    chunk = env.rollout(25, ssc.RandomPolicy())
+    owner = object()
+    rb = ReplayBuffer(owner, 1000)
+    rb.start_new_episode(owner)
+    rb.add_chunk(owner, chunk, env_index=5)
+    assert len(rb) == 25 and list(rb.episode_starting_indices) == [0, 10, 20]
+    s, a, r, t, s2 = rb.all_batch()
+    assert np.array_equal(np.nonzero(t)[0], [9, 19])
+    assert np.allclose(s[:, 0], chunk.obs[0, :, 5].cpu().numpy()) and np.allclose(a[:, 0], chunk.act[:, 5].cpu().numpy())
+    path = np.asarray(rb.get_episodic_path_to_buffer_index(14))
+    assert path.shape == (6, 2) and np.allclose(path[0], s[10])
