@@ -100,6 +100,123 @@ def cpu_baseline(budget_s=24.0):
     return out
 
 
+def bench_config3(args, torch):
+    """BASELINE configs[2]: 65 536 MountainCar envs + DDPG actor 64-32 (bf16 MFMA) + OU noise, fused."""
+    import numpy as np
+
+    from oracle import ssc_oracle as O
+    from smartstartcontinuous_amd import ActorPolicy, TransitionChunk, VecEnv
+    from smartstartcontinuous_amd.agents import init_actor_weights
+    n, K = args.envs_per_gpu, 256
+    w = init_actor_weights(2, 64, 32, 1, torch.Generator().manual_seed(1234))
+    env = VecEnv("MountainCarContinuous-v0", n, seed=1234)
+    env.reset()
+    chunk = TransitionChunk(2, K, n, env.device)
+    pd = env.policy_desc(ActorPolicy(w, precision="bf16_mfma", ou_mu=0.4, ou_sigma=0.6, ou_theta=0.15))
+    for _ in range(args.warmup):
+        env.rollout(K, out=chunk, policy_desc=pd)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(); env.rollout(K, out=chunk, policy_desc=pd); b.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    kms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
+    rate = n * K * args.steps / el
+    mfma_flops = 2.0 * 64 * 32 + 2.0 * 2 * 64          # hidden GEMM (bf16 MFMA) + layer 1 (fp32 MFMA) per env-step
+    res = {"metric": "env-steps/sec, 65 536 MountainCar envs + DDPG actor 64-32 fwd (bf16 MFMA) + OU noise", "value": rate,
+           "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (hidden GEMM), f32 elsewhere",
+           "data": "synthetic", "config": {"workload": "BASELINE configs[2]: MountainCarContinuous-v0, %d envs, actor 64-32 "
+                                          "lastLayerTanh, OU mu0.4 sigma0.6 theta0.15, %d env-steps per launch, full log" % (n, K)},
+           "roofline": {"bound": "mfma", "achieved": mfma_flops * n * K / (kms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": mfma_flops * n * K / (kms * 1e-3) / 1e12 / 2500.0, "traffic": None, "kernel_ms": kms,
+                        "note": "VALU/transcendental-bound (33 tanh + 96 relu/convert per env-step); MFMA is ~15%% of issue; "
+                                "log traffic %.0f GB/s" % (25.0 * n * K / (kms * 1e-3) / 1e9)}}
+    if not args.no_cpu_baseline:
+        wn = {k: v.numpy() for k, v in w.items()}
+        obs = np.random.default_rng(0).uniform(-1, 1, (n, 2)).astype(np.float32)
+        pos, vel = obs[:, 0].astype(np.float64) * 0.5 - 0.5, obs[:, 1].astype(np.float64) * 0.05
+        x = np.zeros(n)
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < args.cpu_budget / 2:
+            a = O.actor_forward(np.stack([pos, vel], 1), **wn)[:, 0]
+            x = O.ou_step(x, np.random.standard_normal(n), 0.4, 0.6)
+            pos, vel, r, d = O.mc_step(pos, vel, O.ddpg_action(a, x, 1.0))
+            k += 1
+        res["cpu_baseline"] = {"value": n * k / (time.perf_counter() - t0), "unit": "env-steps/s", "cores": 1, "kind": "port",
+                               "sample": "numpy fp64 oracle (actor + OU + step), %d envs x %d steps" % (n, k)}
+    print(json.dumps(res), flush=True)
+
+
+def bench_config4(args, torch):
+    """BASELINE configs[3]: NND_MB dynamics MLP 2x500 (Pendulum: in 4, out 3), M = 65 536 rows, H = 4:
+    MPC sampling + forward simulation (bf16 MFMA) + trajectory scoring."""
+    import numpy as np
+
+    from oracle import ssc_oracle as O
+    from smartstartcontinuous_amd import navigator as nav
+    from smartstartcontinuous_amd.agents import init_dynamics_weights
+    P, N, H, d, a = 16, 4096, 4, 3, 1
+    M = P * N
+    Ws, bs = init_dynamics_weights(d + a, d, 2, 500, torch.Generator().manual_seed(1234))
+    norm = dict(mean_x=np.zeros(d), std_x=np.ones(d), mean_y=np.zeros(a), std_y=np.full(a, 1.2), mean_z=np.zeros(d),
+                std_z=np.full(d, 0.05))
+    model = nav.DynamicsModel(Ws, bs, norm, d, a, precision="bf16_mfma")
+    rng = np.random.default_rng(0)
+    wps = [np.cumsum(rng.normal(scale=0.05, size=(200, d)), axis=0) for _ in range(P)]
+    radii = [np.full(d, 0.06)] * P
+    lefts = [np.arange(200, 0, -1, dtype=np.float64) - 1 for _ in range(P)]
+    ps = nav.MpcProblemSet(wps, lefts, radii, [0] * P)
+    s0 = torch.as_tensor(np.repeat(np.stack([w[0] for w in wps]), N, axis=0), dtype=torch.float32, device="cuda")
+    S = torch.empty((H + 1, M, d), device="cuda")
+
+    def step(t):
+        A = nav.mpc_sample_actions(P, N, H, [-2.0], [2.0], 1234, 0, t)
+        model.do_forward_sim(s0, A, out=S)
+        scores, best, _ = nav.mpc_score(ps, S)
+        return nav.mpc_select_action(A, S, best, P, 0.005, 1234, 0, t, want_path=False)
+
+    def sim_only(A):
+        model.do_forward_sim(s0, A, out=S)
+    for t in range(args.warmup):
+        step(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        step(t)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    A = nav.mpc_sample_actions(P, N, H, [-2.0], [2.0], 1234, 0, 0)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for e0, e1 in evs:
+        e0.record(); sim_only(A); e1.record()
+    torch.cuda.synchronize()
+    kms = sum(x.elapsed_time(y) for x, y in evs) / args.steps
+    flop_row = 2.0 * ((d + a) * 500 + 500 * 500 + 500 * d)         # 507 000, SURVEY 8d
+    res = {"metric": "row-steps/sec, NND_MB dynamics MLP 2x500 forward sim + MPC scoring, 65 536 rows", "value": M * H * args.steps / el,
+           "unit": "row-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (hidden/output GEMMs, fp32 accumulate), f32 layer 1",
+           "data": "synthetic", "config": {"workload": "BASELINE configs[3]: Pendulum dims (in 4, out 3), num_fc_layers 2, depth 500, "
+                                          "%d MPC problems x %d samples = %d rows, horizon %d; sample + forward sim + score + select" % (P, N, M, H)},
+           "roofline": {"bound": "mfma", "achieved": flop_row * M * H / (kms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": flop_row * M * H / (kms * 1e-3) / 1e12 / 2500.0, "traffic": None, "kernel_ms": kms,
+                        "kernel": "ssc::dyn_mfma_sim_kernel<16,2> (+ 5 us weight pack)", "algorithmic_flop_per_launch": flop_row * M * H}}
+    if not args.no_cpu_baseline:
+        Wn, bn = [w.numpy() for w in Ws], [b.numpy() for b in bs]
+        m_cpu = 2048
+        An = rng.uniform(-2, 2, (m_cpu, H, a))
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < args.cpu_budget / 2:
+            Sn = O.dyn_forward_sim(np.zeros((m_cpu, d)), An, norm, Wn, bn)
+            O.mpc_scores_add_delta(Sn, wps[0], lefts[0], radii[0], 0)
+            k += 1
+        res["cpu_baseline"] = {"value": m_cpu * H * k / (time.perf_counter() - t0), "unit": "row-steps/s", "cores": 1, "kind": "port",
+                               "sample": "numpy fp64 oracle forward sim + scoring, %d rows x H=%d x %d repeats" % (m_cpu, H, k)}
+    print(json.dumps(res), flush=True)
+
+
 def profiled_traffic():
     """HBM bytes per launch of the rollout kernel from the committed rocprofv3 PMC passes
     (profiles/<tag>/traffic.json: WRITE_SIZE*1024 + 2*FETCH_SIZE*1024, gfx950 correction) -- the
@@ -126,10 +243,20 @@ def main():
     ap.add_argument("--gather", choices=["bounded", "full", "none"], default="bounded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=24.0)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
+                    help="BASELINE.json config (1-based): 2 = headline random-policy rollout (default), "
+                         "3 = + DDPG actor MFMA, 4 = NND_MB 2x500 forward sim + MPC")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
+
+    if args.config != 2:
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            sys.exit("--config 3/4 are single-GPU measurements")
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        return (bench_config3 if args.config == 3 else bench_config4)(args, torch)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -37,9 +37,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kDynThreads = 256;  // 4 waves x 64 rows (2 tiles of 32)
-constexpr int kDynRows = 256;
+constexpr int kDynRows = 256;     // rows per block
+#ifndef SSC_DYN_ET
+#define SSC_DYN_ET 1               // 32-row tiles per wave: 2 -> 4 waves/block (1 per SIMD), 1 -> 8 waves/block (2 per SIMD)
+#endif
+constexpr int ET = SSC_DYN_ET;
+constexpr int kDynThreads = 64 * (kDynRows / (32 * ET));
 constexpr int kMaxKS1 = 6;        // layer-1 k-steps of 2: inputs <= 12
+
+// LDS-DMA: one wave-instruction copies 64 x 16 B = 1 KiB global -> LDS with no VGPR staging
+// (global_load_lds_dwordx4).  The LDS destination is wave-uniform base + lane*16; the global source
+// is per lane.  Completion is tracked by vmcnt (the __syncthreads() that follows drains it).
+__device__ __forceinline__ void glds_1k(const unsigned char *gsrc_lane, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(gsrc_lane)),
+        reinterpret_cast<__attribute__((address_space(3))) void *>(
+            static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_wave_base))),
+        16, 0, 0);
+}
 
 __device__ __forceinline__ int acc_row32(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 // hidden unit carried by k slot (8*half + j) of bf16 k-step (ut, s) when the B operand is a converted
@@ -179,11 +194,9 @@ __device__ __forceinline__ void relu_to_frags(const f32x16 &acc, bf16x8 &f0, bf1
     }
 }
 
-constexpr int ET = 2;  // 32-row tiles per wave
-
 // LDS carve (bytes): [a2 buffers 2 x UT*2048 (NFC==2)] [a3 UT*2048] [w1 6*UT*256] [b1 UT*128] [b2 UT*128] [b3 128] [nm 192]
 template <int UT, int NFC>
-__global__ __launch_bounds__(kDynThreads, 1) void dyn_mfma_sim_kernel(DynSimArgs g) {
+__global__ __launch_bounds__(kDynThreads, ET == 2 ? 1 : 2) void dyn_mfma_sim_kernel(DynSimArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int A2_TILE = UT * 2048;  // one output tile of W2^T fragments
     unsigned char *l_a2 = lds;
@@ -207,16 +220,13 @@ __global__ __launch_bounds__(kDynThreads, 1) void dyn_mfma_sim_kernel(DynSimArgs
         if (tid < 32) l_b3[tid] = g.b3[tid];
         if (tid < 48) l_nm[tid] = g.nm[tid];
     }
-    // W2^T tile 0 -> buffer 0
-    constexpr int STAGE = (A2_TILE / 16 + kDynThreads - 1) / kDynThreads;  // f32x4 per thread per tile
-    f32x4 stage[NFC == 2 ? STAGE : 1];
-    const f32x4 *a2_src = reinterpret_cast<const f32x4 *>(g.a2);
+    // W2^T tile 0 -> buffer 0 (LDS-DMA, 1 KiB per wave-instruction)
+    constexpr int NW = kDynThreads / 64;
+    constexpr int A2_CHUNKS = A2_TILE / 1024;
+    const unsigned char *a2_src = g.a2;
     if (NFC == 2) {
 #pragma unroll
-        for (int q = 0; q < STAGE; ++q) {
-            const int e = q * kDynThreads + tid;
-            if (e < A2_TILE / 16) reinterpret_cast<f32x4 *>(l_a2)[e] = a2_src[e];
-        }
+        for (int c = wave; c < A2_CHUNKS; c += NW) glds_1k(a2_src + c * 1024 + lane * 16, l_a2 + c * 1024);
     }
     __syncthreads();
 
@@ -299,15 +309,15 @@ __global__ __launch_bounds__(kDynThreads, 1) void dyn_mfma_sim_kernel(DynSimArgs
 #pragma unroll 1
             for (int jt = 0; jt < UT; ++jt) {
                 const unsigned char *buf = l_a2 + (UT > 1 ? (jt & 1) * A2_TILE : 0);
-                // prefetch the next W2^T tile (next jt, or tile 0 of the next step) into registers
+                // prefetch the next W2^T tile (next jt, or tile 0 of the next step) straight into the other
+                // LDS buffer: its last readers (tile jt-1) all passed the previous barrier
                 const bool more = (UT > 1) && (jt + 1 < UT || t + 1 < g.H);
                 const int jn = (jt + 1 < UT) ? jt + 1 : 0;
                 if (more) {
+                    unsigned char *nb = l_a2 + ((jt + 1) & 1) * A2_TILE;
 #pragma unroll
-                    for (int q = 0; q < STAGE; ++q) {
-                        const int e = q * kDynThreads + tid;
-                        if (e < A2_TILE / 16) stage[q] = a2_src[(size_t)jn * (A2_TILE / 16) + e];
-                    }
+                    for (int c = wave; c < A2_CHUNKS; c += NW)
+                        glds_1k(a2_src + (size_t)jn * A2_TILE + c * 1024 + lane * 16, nb + c * 1024);
                 }
                 const f32x16 c2 = lds_tile16(l_b2 + (jt * 2 + half) * 16);
                 f32x16 acc2[ET];
@@ -316,13 +326,15 @@ __global__ __launch_bounds__(kDynThreads, 1) void dyn_mfma_sim_kernel(DynSimArgs
                 // software-pipelined fragment reads, two k-steps ahead; the fences pin the order so
                 // that the prefetch depth (and with it the register footprint) stays what is written
                 constexpr int NK = UT * 2;
-                bf16x8 ring[2];
-                ring[0] = *reinterpret_cast<const bf16x8 *>(buf + (0 * 64 + lane) * 16);
-                ring[1] = *reinterpret_cast<const bf16x8 *>(buf + (1 * 64 + lane) * 16);
+                constexpr int RING = (NK >= 4) ? 4 : 2;   // fragment reads in flight per wave
+                bf16x8 ring[RING];
+#pragma unroll
+                for (int q = 0; q < RING; ++q) ring[q] = *reinterpret_cast<const bf16x8 *>(buf + (q * 64 + lane) * 16);
 #pragma unroll
                 for (int i = 0; i < NK; ++i) {
-                    const bf16x8 a = ring[i & 1];
-                    if (i + 2 < NK) ring[i & 1] = *reinterpret_cast<const bf16x8 *>(buf + ((i + 2) * 64 + lane) * 16);
+                    const bf16x8 a = ring[i % RING];
+                    if (i + RING < NK)
+                        ring[i % RING] = *reinterpret_cast<const bf16x8 *>(buf + ((i + RING) * 64 + lane) * 16);
 #pragma unroll
                     for (int et = 0; et < ET; ++et)
                         acc2[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[et][i >> 1][i & 1], acc2[et], 0, 0, 0);
@@ -337,18 +349,7 @@ __global__ __launch_bounds__(kDynThreads, 1) void dyn_mfma_sim_kernel(DynSimArgs
                     acc3[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, f0, acc3[et], 0, 0, 0);
                     acc3[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, f1, acc3[et], 0, 0, 0);
                 }
-                if (UT > 1) {
-                    // the other buffer's last readers (tile jt-1) all passed the previous barrier
-                    if (more) {
-                        unsigned char *nb = l_a2 + ((jt + 1) & 1) * A2_TILE;
-#pragma unroll
-                        for (int q = 0; q < STAGE; ++q) {
-                            const int e = q * kDynThreads + tid;
-                            if (e < A2_TILE / 16) reinterpret_cast<f32x4 *>(nb)[e] = stage[q];
-                        }
-                    }
-                    __syncthreads();
-                }
+                if (UT > 1) __syncthreads();  // drains the LDS-DMA (vmcnt) and publishes the next tile
             }
         } else {
 #pragma unroll
