@@ -11,14 +11,16 @@ namespace ssc {
 template <int OBS, int H1, int H2>
 __global__ __launch_bounds__(kBlock) void actor_f32_kernel(ActorWeights w, int64_t m, const float *__restrict__ obs,
                                                            float *__restrict__ act) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= m) return;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = gi < m;
+    const int64_t i = active ? gi : m - 1;
     float o[OBS];
 #pragma unroll
     for (int c = 0; c < OBS; ++c) o[c] = obs[i * OBS + c];
     ActorF32<OBS, H1, H2> net;
-    net.init(w);
-    act[i] = net.forward(o);
+    net.init(w);  // block-cooperative LDS staging: no thread may have exited
+    const float a = net.forward(o);
+    if (active) act[i] = a;
 }
 
 // one wave = 64 rows, hidden GEMM on bf16 MFMA

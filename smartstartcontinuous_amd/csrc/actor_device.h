@@ -31,27 +31,62 @@ struct ActorWeights {
 // ---------------------------------------------------------------------------------------
 template <int OBS, int H1, int H2>
 struct ActorF32 {
-    ActorWeights w;
+    // The weights (9.2 KB for 64-32) are staged ONCE per block into LDS and read back as broadcast
+    // ds_read_b128: reading them through the kernel-argument pointers inside the step loop forces
+    // hipcc to re-issue ~300 global loads per env-step (the log stores may alias them).
+    static constexpr int OFF_B1 = OBS * H1, OFF_W2 = OFF_B1 + H1, OFF_B2 = OFF_W2 + H1 * H2;
+    static constexpr int OFF_W3 = OFF_B2 + H2, OFF_B3 = OFF_W3 + H2, TOTAL = OFF_B3 + 4;
+    const float *lw;  // LDS image: W1[OBS][H1] | b1 | W2[H1][H2] | b2 | W3[H2] | b3
+    int last_tanh;
 
-    __device__ void init(const ActorWeights &aw) { w = aw; }
+    // block-cooperative: every thread of the block must call it
+    __device__ void init(const ActorWeights &w) {
+        __shared__ __attribute__((aligned(16))) float image[TOTAL];
+        for (int e = threadIdx.x; e < OBS * H1; e += blockDim.x) image[e] = w.W1[e];
+        for (int e = threadIdx.x; e < H1; e += blockDim.x) image[OFF_B1 + e] = w.b1[e];
+        for (int e = threadIdx.x; e < H1 * H2; e += blockDim.x) image[OFF_W2 + e] = w.W2[e];
+        for (int e = threadIdx.x; e < H2; e += blockDim.x) {
+            image[OFF_B2 + e] = w.b2[e];
+            image[OFF_W3 + e] = w.W3[e];
+        }
+        if (threadIdx.x == 0) image[OFF_B3] = w.b3[0];
+        __syncthreads();
+        lw = image;
+        last_tanh = w.last_layer_tanh;
+    }
 
     __device__ float forward(const float (&obs)[OBS]) const {
+        static_assert(H1 % 4 == 0 && H2 % 4 == 0, "hidden sizes must be multiples of 4");
+        typedef float f4 __attribute__((ext_vector_type(4)));
         float h1[H1];
 #pragma unroll
-        for (int j = 0; j < H1; ++j) {
-            float acc = w.b1[j];
+        for (int j = 0; j < H1; j += 4) {
+            f4 acc = *reinterpret_cast<const f4 *>(lw + OFF_B1 + j);
 #pragma unroll
-            for (int i = 0; i < OBS; ++i) acc = fmaf(obs[i], w.W1[i * H1 + j], acc);
-            h1[j] = fmaxf(acc, 0.0f);  // models_editted.py:47
+            for (int i = 0; i < OBS; ++i) {
+                const f4 wv = *reinterpret_cast<const f4 *>(lw + i * H1 + j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(obs[i], wv[q], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h1[j + q] = fmaxf(acc[q], 0.0f);  // models_editted.py:47
         }
-        float out = w.b3[0];
-#pragma unroll 4
-        for (int j = 0; j < H2; ++j) {
-            float acc = w.b2[j];
+        float out = lw[OFF_B3];
+#pragma unroll 2
+        for (int j = 0; j < H2; j += 4) {
+            f4 acc = *reinterpret_cast<const f4 *>(lw + OFF_B2 + j);
 #pragma unroll
-            for (int i = 0; i < H1; ++i) acc = fmaf(h1[i], w.W2[i * H2 + j], acc);
-            const float h2 = w.last_layer_tanh ? tanh_fast(acc) : fmaxf(acc, 0.0f);  // :53-56
-            out = fmaf(h2, w.W3[j], out);
+            for (int i = 0; i < H1; ++i) {  // k order 0..H1-1 per output unit: a plain fp32 FMA chain
+                const f4 wv = *reinterpret_cast<const f4 *>(lw + OFF_W2 + i * H2 + j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(h1[i], wv[q], acc[q]);
+            }
+            const f4 w3 = *reinterpret_cast<const f4 *>(lw + OFF_W3 + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float h2 = last_tanh ? tanh_fast(acc[q]) : fmaxf(acc[q], 0.0f);  // :53-56
+                out = fmaf(h2, w3[q], out);
+            }
         }
         return tanh_fast(out);  // :60
     }
