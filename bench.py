@@ -242,6 +242,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=CHUNK)
     ap.add_argument("--gather", choices=["bounded", "full", "none"], default="bounded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the gather path even at world size 1 "
+                         "(single-GPU rehearsal of the N>1 code path)")
     ap.add_argument("--cpu-budget", type=float, default=24.0)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
                     help="BASELINE.json config (1-based): 2 = headline random-policy rollout (default), "
@@ -269,8 +272,10 @@ def main():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from smartstartcontinuous_amd import RandomPolicy, TransitionChunk, VecEnv
@@ -282,13 +287,13 @@ def main():
     chunks = [TransitionChunk(env.obs_dim, K, n, dev) for _ in range(2)]   # double buffer
     pd = env.policy_desc(RandomPolicy())
     gather = None
-    if world > 1 and args.gather != "none":
+    if use_dist and args.gather != "none":
         g_steps = K if args.gather == "full" else max(1, min(K, GATHER_RECORDS // (n * world)))
         gather = TransitionGather(env.obs_dim, g_steps, n, world, rank, dev)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -317,7 +322,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, args.steps)
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -348,7 +353,7 @@ def main():
                              "%d env-steps per launch, full transition log to HBM" % (n, K)),
                 "envs_per_gpu": n, "chunk_steps": K, "global_envs": n * world,
                 "parallelism": "env-sharded x%d" % world,
-                "gather": (args.gather if world > 1 else "none"),
+                "gather": (args.gather if use_dist else "none"),
                 "gather_steps_per_chunk": (gather.g_steps if gather is not None else 0),
             },
             "roofline": {
@@ -365,7 +370,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
+        if gather is not None and rank == 0:
+            # the learner rank really received every rank's last steps
+            obs, act, rew, obs2, done = gather.unpack(world - 1)
+            assert obs.shape == (env.obs_dim, gather.g_steps, n) and bool(torch.isfinite(act).all())
         dist.barrier()
         dist.destroy_process_group()
 

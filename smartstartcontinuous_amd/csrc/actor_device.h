@@ -108,14 +108,20 @@ struct ActorMfma {
     f32x16 c1[UT];         // b1 broadcast in accumulator layout
     bf16x8 a2[JT][UT][2];  // layer-2 A fragments (W2^T, k order matched to the layer-1 accumulator)
     f32x16 c2[JT];         // b2 in accumulator layout
-    float w3[JT][16];      // W3[jt*32 + acc_row(reg)]
-    float b3;
+    float w3[JT][16];      // W3[jt*32 + acc_row(reg)]; premultiplied by -2 when last_tanh (see forward)
+    float b3;              // b3 (+ sum_j W3[j] when last_tanh)
     int last_tanh;
 
     __device__ void init(const ActorWeights &w) {
         const int lane = threadIdx.x & 63;
         const int r = lane & 31, half = lane >> 5;
         const int H1 = w.h1, H2 = w.h2;
+        last_tanh = w.last_layer_tanh;
+        // tanh(x) = 1 - 2 / (2^(c x) + 1), c = 2 log2(e).  With last_tanh the constant c is folded
+        // into W2 / b2 (so the MFMA output is already c*x), and  sum_j w3_j tanh_j  is evaluated as
+        // (sum_j w3_j) + sum_j (-2 w3_j) r_j  with r_j = 1 / (2^(c x_j) + 1): per hidden unit that
+        // is v_exp_f32, v_add, v_rcp_f32, v_fma -- 4 VALU ops instead of 6.
+        const float cs = last_tanh ? 2.88539008177792681472f : 1.0f;
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
             const int unit = ut * 32 + r;
@@ -141,34 +147,32 @@ struct ActorMfma {
                     for (int j = 0; j < 8; ++j) {
                         // k slot (8*half + j) of k-step (ut, s) carries hidden unit u
                         const int u = ut * 32 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
-                        const float v = (u < H1 && col < H2) ? w.W2[u * H2 + col] : 0.0f;
+                        const float v = (u < H1 && col < H2) ? w.W2[u * H2 + col] * cs : 0.0f;
                         a2[jt][ut][s][j] = (__bf16)v;
                     }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int o = jt * 32 + acc_row(reg, half);
-                c2[jt][reg] = (o < H2) ? w.b2[o] : 0.0f;
-                w3[jt][reg] = (o < H2) ? w.W3[o] : 0.0f;
+                c2[jt][reg] = (o < H2) ? w.b2[o] * cs : 0.0f;
+                w3[jt][reg] = (o < H2) ? w.W3[o] * (last_tanh ? -2.0f : 1.0f) : 0.0f;
             }
         }
         b3 = w.b3[0];
-        last_tanh = w.last_layer_tanh;
+        if (last_tanh)
+            for (int j = 0; j < H2; ++j) b3 += w.W3[j];
     }
 
     // obs: this lane's env observation.  Returns the actor output for this lane's env.
     // Wave-collective: every lane of the wave must call it.
     __device__ float forward(const float (&obs)[OBS]) const {
-        const int half = (threadIdx.x & 63) >> 5;
-        // layer-1 B operands for the two 32-env tiles
+        // layer-1 B operands for the two 32-env tiles: tile 0 needs [v0.lo | v1.lo], tile 1 [v0.hi | v1.hi]
+        // (v0/v1 = obs components 2ks / 2ks+1 of this lane's env) -- exactly one v_permlane32_swap
         float bop[2][KS1];
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
             const float v0 = obs[2 * ks];
             const float v1 = (2 * ks + 1 < OBS) ? obs[2 * ks + 1] : 0.0f;
-            const float x0 = __shfl_xor(v0, 32);
-            const float x1 = __shfl_xor(v1, 32);
-            bop[0][ks] = half ? x1 : v0;  // tile 0: env = lane & 31
-            bop[1][ks] = half ? v1 : x0;  // tile 1: env = 32 + (lane & 31)
+            half_swap(v0, v1, bop[0][ks], bop[1][ks]);
         }
         f32x16 acc2[JT][2];
 #pragma unroll
@@ -186,9 +190,11 @@ struct ActorMfma {
                     d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[ut][ks], bop[et][ks], d, 0, 0, 0);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    bf16x8 frag;
+                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+                    i32x4 packed;  // relu (models_editted.py:47) + bf16 convert, two values per 2 VALU ops
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) frag[j] = (__bf16)fmaxf(d[8 * s + j], 0.0f);  // relu :47
+                    for (int j = 0; j < 4; ++j) packed[j] = relu_pack_bf16(d[8 * s + 2 * j], d[8 * s + 2 * j + 1]);
+                    const bf16x8 frag = __builtin_bit_cast(bf16x8, packed);
 #pragma unroll
                     for (int jt = 0; jt < JT; ++jt)
                         acc2[jt][et] =
@@ -202,8 +208,10 @@ struct ActorMfma {
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    part0 = fmaf(tanh_fast(acc2[jt][0][reg]), w3[jt][reg], part0);
-                    part1 = fmaf(tanh_fast(acc2[jt][1][reg]), w3[jt][reg], part1);
+                    const float r0 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc2[jt][0][reg]) + 1.0f);
+                    const float r1 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc2[jt][1][reg]) + 1.0f);
+                    part0 = fmaf(r0, w3[jt][reg], part0);
+                    part1 = fmaf(r1, w3[jt][reg], part1);
                 }
         } else {
 #pragma unroll
@@ -214,9 +222,10 @@ struct ActorMfma {
                     part1 = fmaf(fmaxf(acc2[jt][1][reg], 0.0f), w3[jt][reg], part1);
                 }
         }
-        part0 += __shfl_xor(part0, 32);
-        part1 += __shfl_xor(part1, 32);
-        return tanh_fast((half ? part1 : part0) + b3);
+        // lanes 0-31 need full0 = part0.lo + part0.hi, lanes 32-63 full1 = part1.lo + part1.hi
+        float s_lo, s_hi;
+        half_swap(part0, part1, s_lo, s_hi);
+        return tanh_fast(s_lo + s_hi + b3);
     }
 };
 

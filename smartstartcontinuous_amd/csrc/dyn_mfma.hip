@@ -187,11 +187,15 @@ __device__ __forceinline__ f32x16 lds_tile16(const float *p) {  // 16 consecutiv
 }
 
 __device__ __forceinline__ void relu_to_frags(const f32x16 &acc, bf16x8 &f0, bf16x8 &f1) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 p0, p1;  // feedforward_network.py:19 (ReLU) fused with the bf16 convert: 2 values per 2 VALU ops
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        f0[j] = (__bf16)fmaxf(acc[j], 0.0f);      // feedforward_network.py:19
-        f1[j] = (__bf16)fmaxf(acc[8 + j], 0.0f);
+    for (int j = 0; j < 4; ++j) {
+        p0[j] = relu_pack_bf16(acc[2 * j], acc[2 * j + 1]);
+        p1[j] = relu_pack_bf16(acc[8 + 2 * j], acc[8 + 2 * j + 1]);
     }
+    f0 = __builtin_bit_cast(bf16x8, p0);
+    f1 = __builtin_bit_cast(bf16x8, p1);
 }
 
 // LDS carve (bytes): [a2 buffers 2 x UT*2048 (NFC==2)] [a3 UT*2048] [w1 6*UT*256] [b1 UT*128] [b2 UT*128] [b3 128] [nm 192]

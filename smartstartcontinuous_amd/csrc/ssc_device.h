@@ -201,4 +201,29 @@ SSC_HD float tanh_fast(float x) {
 #endif
 }
 
+// ReLU + fp32 -> bf16 for a PAIR of values in two instructions: v_cvt_pk_bf16_f32 then
+// v_pk_max_i16(x, 0) -- a negative bf16 has its sign bit set, i.e. is a negative int16, so the
+// integer max zeroes exactly the negative halves (and -0.0).  Half the VALU work of max+max+cvt.
+typedef __bf16 ssc_bf16x2 __attribute__((ext_vector_type(2)));
+typedef short ssc_s16x2 __attribute__((ext_vector_type(2)));
+typedef float ssc_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int relu_pack_bf16(float a, float b) {
+    const ssc_f32x2 v = {a, b};
+    const ssc_bf16x2 p = __builtin_convertvector(v, ssc_bf16x2);
+    ssc_s16x2 s = __builtin_bit_cast(ssc_s16x2, p);
+    s = __builtin_elementwise_max(s, (ssc_s16x2)(0));
+    return __builtin_bit_cast(int, s);
+}
+
+// The two cross-half exchanges of a 64-lane wave in ONE VALU op (v_permlane32_swap, gfx950):
+// given a, b returns lo_lo = [a.lo | b.lo] and hi_hi = [a.hi | b.hi] (lo = lanes 0-31, hi = 32-63).
+// Inline asm on purpose: ROCm 7.2's __builtin_amdgcn_permlane32_swap returns its FIRST result for
+// both elements of the pair (the second output register is dropped in instruction selection;
+// reproducer in DESIGN.md).  hipcc pads no hazards around asm, hence the s_nop brackets.
+__device__ __forceinline__ void half_swap(float a, float b, float &lo_lo, float &hi_hi) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    lo_lo = a;
+    hi_hi = b;
+}
+
 }  // namespace ssc
