@@ -167,6 +167,15 @@ int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *policy, int64_t 
                 const ssc_episode_ring *ring, double *d_stats, uint64_t seed, uint64_t env_id0,
                 uint64_t step0, ssc_stream_t stream);
 
+/* Packs the LAST g steps of a transition log into one contiguous buffer for the per-chunk exchange
+ * (the rollout gather of NN_Dynamics_Model/collect_samples_threaded.py:31-50 as ONE RCCL message):
+ *   d_out = [obs (obs_dim x g x n) f32 | act (g x n) | rew (g x n) | obs2 (obs_dim x g x n) | done (g x n) u8]
+ * followed, 8-byte aligned, by a snapshot of d_stats (4 doubles) when d_stats != NULL.
+ * d_out must hold ssc_pack_bytes(obs_dim, g, n) bytes. */
+size_t ssc_pack_bytes(int32_t obs_dim, int32_t g, int64_t n);
+int ssc_pack_transitions(const ssc_transition_log *log, int32_t obs_dim, int32_t K, int32_t g, int64_t n,
+                         const double *d_stats, void *d_out, ssc_stream_t stream);
+
 /* Batched actor forward, act[m][act_dim] = Actor_Editted(obs[m][obs_dim])
  * (models_editted.py:38-61); row-major in/out.  No noise, no clipping. */
 int ssc_actor_forward(const ssc_actor_desc *actor, int64_t m, const float *d_obs, float *d_act,

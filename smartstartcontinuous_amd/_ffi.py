@@ -101,6 +101,9 @@ _SIGNATURES = {
                             POINTER(TransitionLog), POINTER(EpisodeRing), c_void_p, c_uint64, c_uint64,
                             c_uint64, c_void_p]),
     "ssc_actor_forward": (c_int, [POINTER(ActorDesc), c_int64, c_void_p, c_void_p, c_void_p]),
+    "ssc_pack_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
+    "ssc_pack_transitions": (c_int, [POINTER(TransitionLog), c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p,
+                                     c_void_p]),
     "ssc_mlp_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),
     "ssc_mlp_forward": (c_int, [POINTER(MlpDesc), c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "ssc_dyn_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),

@@ -99,6 +99,31 @@ __global__ __launch_bounds__(kBlock) void env_observe_kernel(int kind, int64_t n
     }
 }
 
+// One launch instead of 2*obs_dim+3 strided copies: thread e of column c copies element e of the tail.
+__global__ __launch_bounds__(kBlock) void pack_tail_kernel(ssc_transition_log log, int obs_dim, int K, int g,
+                                                           int64_t n, const double *__restrict__ stats,
+                                                           unsigned char *__restrict__ out) {
+    const int64_t per = (int64_t)g * n;
+    const int ncol = 2 * obs_dim + 2;             // fp32 columns; the u8 done column follows
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int col = blockIdx.y;
+    const int64_t src = (int64_t)(K - g) * n + e;
+    if (e < per) {
+        if (col < ncol) {
+            const float *p = col < obs_dim ? log.obs[col]
+                             : col == obs_dim ? log.act
+                             : col == obs_dim + 1 ? log.rew : log.obs2[col - obs_dim - 2];
+            reinterpret_cast<float *>(out)[(int64_t)col * per + e] = p[src];
+        } else {
+            out[(int64_t)ncol * per * 4 + e] = log.done[src];
+        }
+    }
+    if (stats != nullptr && col == 0 && e < 4) {
+        const int64_t off = (((int64_t)ncol * per * 4 + per) + 7) & ~(int64_t)7;
+        reinterpret_cast<double *>(out + off)[e] = stats[e];
+    }
+}
+
 // |3*pos| must stay inside cos_bounded's domain.
 int validate_mc_params(const ssc_env_params *p, const char *who) {
     if (p->kind != SSC_ENV_MOUNTAINCAR) return set_error(SSC_EINVAL, "%s: params are not MountainCar", who);
@@ -151,6 +176,26 @@ int ssc_env_reset(const ssc_env_params *p, int64_t n, const uint8_t *d_mask, flo
     hipLaunchKernelGGL(env_reset_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream), p->kind,
                        make_mc_const(*p), n, d_mask, d_s0, d_s1, d_steps, d_ep_ret, d_ou_x, seed, env_id0, t);
     return check_launch("ssc_env_reset");
+}
+
+size_t ssc_pack_bytes(int32_t obs_dim, int32_t g, int64_t n) {
+    if (obs_dim < 1 || obs_dim > SSC_MAX_OBS || g < 0 || n < 0) return 0;
+    const size_t per = (size_t)g * (size_t)n;
+    return ((per * (8 * (size_t)obs_dim + 9) + 7) & ~(size_t)7) + 4 * sizeof(double);
+}
+
+int ssc_pack_transitions(const ssc_transition_log *log, int32_t obs_dim, int32_t K, int32_t g, int64_t n,
+                         const double *d_stats, void *d_out, ssc_stream_t stream) {
+    SSC_REQUIRE(log != nullptr && d_out != nullptr, "ssc_pack_transitions: NULL argument");
+    SSC_REQUIRE(obs_dim >= 1 && obs_dim <= SSC_MAX_OBS, "ssc_pack_transitions: obs_dim %d", obs_dim);
+    SSC_REQUIRE(g >= 0 && g <= K && n >= 0, "ssc_pack_transitions: need 0 <= g <= K, n >= 0");
+    if (g == 0 || n == 0) return SSC_OK;
+    for (int c = 0; c < obs_dim; ++c) SSC_REQUIRE(log->obs[c] && log->obs2[c], "ssc_pack_transitions: NULL column");
+    SSC_REQUIRE(log->act && log->rew && log->done, "ssc_pack_transitions: NULL column");
+    const dim3 grid(blocks_for((int64_t)g * n), 2 * obs_dim + 3);
+    hipLaunchKernelGGL(pack_tail_kernel, grid, dim3(kBlock), 0, as_stream(stream), *log, obs_dim, K, g, n, d_stats,
+                       static_cast<unsigned char *>(d_out));
+    return check_launch("ssc_pack_transitions");
 }
 
 int ssc_env_observe(const ssc_env_params *p, int64_t n, const float *d_s0, const float *d_s1,

@@ -37,18 +37,22 @@ def record_bytes(obs_dim):
 
 
 class TransitionGather:
-    """Packs the last ``g_steps`` steps of a TransitionChunk into one contiguous byte buffer and
-    gathers it to ``dst`` (one collective per chunk), then all-reduces the chunk statistics.
-    On CUDA the work runs on a side stream so that it overlaps the next chunk's rollout;
-    ``wait_buffer_free(slot)`` orders the next overwrite of a chunk buffer after its pack."""
+    """Packs the last ``g_steps`` steps of a TransitionChunk plus a snapshot of the chunk statistics
+    into one contiguous byte buffer and gathers it to ``dst`` -- ONE collective per chunk; the learner
+    sums the statistics out of the payload (``allreduce_stats=True`` adds an all-reduce so that every
+    rank knows them).  On CUDA the pack is a single kernel (``ssc_pack_transitions``) on the producing
+    stream and the collective runs on a side stream, overlapping the next chunk's rollout."""
 
-    def __init__(self, obs_dim, g_steps, n, world, rank, device, dst=0, group=None):
+    def __init__(self, obs_dim, g_steps, n, world, rank, device, dst=0, group=None, allreduce_stats=False):
+        self.allreduce_stats = allreduce_stats
         self.obs_dim, self.g_steps, self.n = obs_dim, int(g_steps), int(n)
         self.world, self.rank, self.dst, self.group = world, rank, dst, group
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
-        self.nbytes = self.g_steps * self.n * record_bytes(obs_dim)
-        self.send = [torch.empty(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        rec = self.g_steps * self.n * record_bytes(obs_dim)
+        self.stats_off = (rec + 7) & ~7
+        self.nbytes = self.stats_off + 32
+        self.send = [torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.recv = None
         if rank == dst:
             self.recv = [torch.empty(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(world)]
@@ -56,8 +60,13 @@ class TransitionGather:
         self.side = torch.cuda.Stream(self.device) if self.cuda else None
         self.packed = [None, None]
         self.chunks_gathered = 0
+        if self.cuda:
+            import ctypes
+            from . import _ffi
+            self._ffi, self._ct = _ffi, ctypes
+            assert _ffi.lib().ssc_pack_bytes(obs_dim, self.g_steps, self.n) == self.nbytes
 
-    # layout of the packed buffer: [obs(obs_dim x g x n) f32 | act | rew | obs2 | done(u8)]
+    # layout of the packed buffer: [obs(obs_dim x g x n) f32 | act | rew | obs2 | done(u8) | pad | stats f64[4]]
     def _views(self, buf):
         g, n, d = self.g_steps, self.n, self.obs_dim
         f = buf[: 4 * g * n * (2 * d + 2)].view(torch.float32)
@@ -66,48 +75,74 @@ class TransitionGather:
         act = f[o:o + g * n].view(g, n); o += g * n
         rew = f[o:o + g * n].view(g, n); o += g * n
         obs2 = f[o:o + d * g * n].view(d, g, n); o += d * g * n
-        done = buf[4 * o:].view(g, n)
+        done = buf[4 * o:4 * o + g * n].view(g, n)
         return obs, act, rew, obs2, done
 
-    def pack(self, chunk, slot):
+    def _stats_view(self, buf):
+        return buf[self.stats_off:self.stats_off + 32].view(torch.float64)
+
+    def pack(self, chunk, slot, stats):
         g = self.g_steps
+        if self.cuda:
+            log = chunk.as_struct()
+            ffi, ct = self._ffi, self._ct
+            ffi.check(ffi.lib().ssc_pack_transitions(ct.byref(log), self.obs_dim, chunk.K, g, self.n, ffi.ptr(stats),
+                                                     ffi.ptr(self.send[slot]),
+                                                     ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            return
         obs, act, rew, obs2, done = self._views(self.send[slot])
         obs.copy_(chunk.obs[:, chunk.K - g:, :])
         act.copy_(chunk.act[chunk.K - g:])
         rew.copy_(chunk.rew[chunk.K - g:])
         obs2.copy_(chunk.obs2[:, chunk.K - g:, :])
         done.copy_(chunk.done[chunk.K - g:])
+        self._stats_view(self.send[slot]).copy_(stats)
 
     def unpack(self, src_rank):
         """Views (obs, act, rew, obs2, done) of the records received from ``src_rank`` (dst only)."""
         return self._views(self.recv[src_rank])
 
-    def wait_buffer_free(self, slot):
-        ev = self.packed[slot]
-        if ev is not None and self.cuda:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+    def received_stats(self, src_rank):
+        return self._stats_view(self.recv[src_rank])
 
-    def _exchange(self, chunk, slot, stats):
-        self.pack(chunk, slot)
-        if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record()
-            self.packed[slot] = ev
+    def wait_buffer_free(self, slot):
+        """Kept for callers that overwrite a chunk from another stream; with ``submit`` the pack runs
+        in order on the producing stream, so the chunk buffer is free as soon as ``submit`` returns."""
+        return None
+
+    def _collective(self, slot):
         dist.gather(self.send[slot], self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
-        self.global_stats.copy_(stats)
-        dist.all_reduce(self.global_stats, op=dist.ReduceOp.SUM, group=self.group)
+        if self.allreduce_stats:
+            # every rank learns the global statistics (the analogue of training_editted.py:173)
+            self.global_stats.copy_(self._stats_view(self.send[slot]))
+            dist.all_reduce(self.global_stats, op=dist.ReduceOp.SUM, group=self.group)
+        elif self.rank == self.dst:
+            # the statistics ride in the gathered payload: the learner sums them, no second collective
+            self.global_stats.copy_(torch.stack([self._stats_view(r) for r in self.recv]).sum(dim=0))
         self.chunks_gathered += 1
 
     def submit(self, chunk, slot, stats):
-        """Call right after the rollout that filled ``chunk`` was enqueued."""
+        """Call right after the rollout that filled ``chunk`` was enqueued (same stream).
+
+        The pack (one small kernel, ~10 us) runs IN ORDER on the producing stream, so the rollout
+        stream never waits on another stream for its 1.7 GB chunk buffer; only the collective runs on
+        the side stream, double-buffered through the two send slots."""
         if not self.cuda:
-            self._exchange(chunk, slot, stats)
+            self.pack(chunk, slot, stats)
+            self._collective(slot)
             return
-        produced = torch.cuda.Event()
-        produced.record()
+        main = torch.cuda.current_stream(self.device)
+        if self.packed[slot] is not None:
+            main.wait_event(self.packed[slot])        # send[slot] was consumed by its collective
+        self.pack(chunk, slot, stats)
+        ready = torch.cuda.Event()
+        ready.record(main)
         with torch.cuda.stream(self.side):
-            self.side.wait_event(produced)
-            self._exchange(chunk, slot, stats)
+            self.side.wait_event(ready)
+            self._collective(slot)
+            sent = torch.cuda.Event()
+            sent.record(self.side)
+            self.packed[slot] = sent
 
     def finish(self):
         if self.cuda:

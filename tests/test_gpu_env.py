@@ -270,3 +270,20 @@ def test_single_env_view_plumbing_config1(ssc):
             obs = obs2
         assert ep_len == 999 or obs2[0] >= 0.45
         assert abs(ret - ret_ref) < 1e-2
+
+
+def test_pack_transitions_kernel_matches_layout(ssc):
+    """ssc_pack_transitions == the column-by-column pack of sharding.TransitionGather (the layout the
+    world-2 gloo test exercises on the CPU)."""
+    from smartstartcontinuous_amd.sharding import TransitionGather
+    for env_name, n, K, g in [("MountainCarContinuous-v0", 1000, 24, 5), ("Pendulum-v0", 257, 8, 8)]:
+        env = ssc.VecEnv(env_name, n, seed=3)
+        chunk = env.rollout(K, ssc.RandomPolicy())
+        tg = TransitionGather(env.obs_dim, g, n, 1, 0, "cuda")
+        tg.pack(chunk, 0, env.stats)
+        torch.cuda.synchronize()
+        obs, act, rew, obs2, done = tg._views(tg.send[0])
+        assert torch.equal(obs, chunk.obs[:, K - g:]) and torch.equal(obs2, chunk.obs2[:, K - g:])
+        assert torch.equal(act, chunk.act[K - g:]) and torch.equal(rew, chunk.rew[K - g:])
+        assert torch.equal(done, chunk.done[K - g:])
+        assert torch.equal(tg._stats_view(tg.send[0]), env.stats)

@@ -35,12 +35,12 @@ class FakeChunk:
         self.done = ((torch.arange(K * N).reshape(K, N) + rank) % 7 == 0).to(torch.uint8)
 
 
-def _worker(rank, world, port, obs_dim, g, tmp):
+def _worker(rank, world, port, obs_dim, g, tmp, allreduce=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     K, N = 12, 37
-    tg = TransitionGather(obs_dim, g, N, world, rank, "cpu")
+    tg = TransitionGather(obs_dim, g, N, world, rank, "cpu", allreduce_stats=allreduce)
     for it in range(3):
         chunk = FakeChunk(obs_dim, K, N, rank)
         chunk.act += it
@@ -59,18 +59,19 @@ def _worker(rank, world, port, obs_dim, g, tmp):
             ok &= torch.equal(done, ref.done[K - g:])
     exp = torch.tensor([1.5 * sum(r + 1 for r in range(world)), sum(range(world)), world * K * N, 2 * world],
                        dtype=torch.float64)
-    ok &= torch.equal(tg.global_stats, exp)
+    if allreduce or rank == 0:
+        ok &= torch.equal(tg.global_stats, exp)
     ok &= tg.chunks_gathered == 3
     open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("obs_dim,g", [(2, 3), (3, 12)])
-def test_gather_and_allreduce_world2_gloo(tmp_path, obs_dim, g):
+@pytest.mark.parametrize("obs_dim,g,allreduce", [(2, 3, True), (3, 12, False)])
+def test_gather_and_allreduce_world2_gloo(tmp_path, obs_dim, g, allreduce):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, obs_dim, g, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, obs_dim, g, str(tmp_path), allreduce), nprocs=2, join=True)
     assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
