@@ -109,6 +109,10 @@ typedef struct ssc_transition_log {
     float *rew;
     uint8_t *done;
     float *obs2[SSC_MAX_OBS];
+    int64_t row_stride;      /* elements between step k and k+1 of one fp32 column; 0 means n (dense [K][n]).
+                                A packed chunk puts all fp32 columns of a step side by side:
+                                row_stride = (2*obs_dim+2)*n, column c starts at base + c*n. */
+    int64_t done_row_stride; /* same for the u8 done column; 0 means n */
 } ssc_transition_log;
 
 /* Completed-episode records: what Summary.append keeps per episode

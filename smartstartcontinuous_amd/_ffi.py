@@ -58,7 +58,7 @@ class RolloutState(Structure):
 
 class TransitionLog(Structure):
     _fields_ = [("obs", c_void_p * SSC_MAX_OBS), ("act", c_void_p), ("rew", c_void_p), ("done", c_void_p),
-                ("obs2", c_void_p * SSC_MAX_OBS)]
+                ("obs2", c_void_p * SSC_MAX_OBS), ("row_stride", c_int64), ("done_row_stride", c_int64)]
 
 
 class EpisodeRing(Structure):

@@ -107,15 +107,17 @@ __global__ __launch_bounds__(kBlock) void pack_tail_kernel(ssc_transition_log lo
     const int ncol = 2 * obs_dim + 2;             // fp32 columns; the u8 done column follows
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int col = blockIdx.y;
-    const int64_t src = (int64_t)(K - g) * n + e;
+    const int64_t step = e / n, i = e - step * n;
+    const int64_t rs = log.row_stride ? log.row_stride : n, drs = log.done_row_stride ? log.done_row_stride : n;
     if (e < per) {
         if (col < ncol) {
+            const int64_t src = (int64_t)(K - g + step) * rs + i;
             const float *p = col < obs_dim ? log.obs[col]
                              : col == obs_dim ? log.act
                              : col == obs_dim + 1 ? log.rew : log.obs2[col - obs_dim - 2];
             reinterpret_cast<float *>(out)[(int64_t)col * per + e] = p[src];
         } else {
-            out[(int64_t)ncol * per * 4 + e] = log.done[src];
+            out[(int64_t)ncol * per * 4 + e] = log.done[(int64_t)(K - g + step) * drs + i];
         }
     }
     if (stats != nullptr && col == 0 && e < 4) {

@@ -198,13 +198,14 @@ struct Rollout {
         sum_r += rew;
         n_goal += goal ? 1 : 0;
         if (LOG) {
-            const int64_t row = (int64_t)k * ra.n;  // wave-uniform
+            const int64_t row = (int64_t)k * ra.log.row_stride;  // wave-uniform
+            const int64_t drow = (int64_t)k * ra.log.done_row_stride;
 #pragma unroll
             for (int c = 0; c < OBS; ++c)
                 __builtin_nontemporal_store(obs[c], (float *)((char *)(ra.log.obs[c] + row) + voff));
             __builtin_nontemporal_store(a, (float *)((char *)(ra.log.act + row) + voff));
             __builtin_nontemporal_store(rew, (float *)((char *)(ra.log.rew + row) + voff));
-            __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), ra.log.done + row + (voff >> 2));
+            __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), ra.log.done + drow + (voff >> 2));
 #pragma unroll
             for (int c = 0; c < OBS; ++c)
                 __builtin_nontemporal_store(obs2[c], (float *)((char *)(ra.log.obs2[c] + row) + voff));
@@ -385,6 +386,10 @@ extern "C" int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *polic
         for (int c = 0; c < obs_dim; ++c)
             SSC_REQUIRE(log->obs[c] && log->obs2[c], "ssc_rollout: NULL log obs column %d", c);
         SSC_REQUIRE(log->act && log->rew && log->done, "ssc_rollout: NULL log column");
+        SSC_REQUIRE(log->row_stride >= 0 && log->done_row_stride >= 0, "ssc_rollout: negative row stride");
+        if (ra.log.row_stride == 0) ra.log.row_stride = n;
+        if (ra.log.done_row_stride == 0) ra.log.done_row_stride = n;
+        SSC_REQUIRE(ra.log.row_stride >= n && ra.log.done_row_stride >= n, "ssc_rollout: row stride < n");
     } else {
         ra.log = ssc_transition_log{};
     }

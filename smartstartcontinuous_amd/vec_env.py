@@ -77,11 +77,22 @@ class TransitionChunk:
 
     obs, obs2: [obs_dim, K, N] fp32; act, rew: [K, N] fp32; done: [K, N] uint8."""
 
-    def __init__(self, obs_dim, K, N, device):
-        self.obs = torch.empty((obs_dim, K, N), dtype=torch.float32, device=device)
-        self.obs2 = torch.empty((obs_dim, K, N), dtype=torch.float32, device=device)
-        self.act = torch.empty((K, N), dtype=torch.float32, device=device)
-        self.rew = torch.empty((K, N), dtype=torch.float32, device=device)
+    def __init__(self, obs_dim, K, N, device, packed=True):
+        """``packed=True`` (default) stores the 2*obs_dim+2 fp32 columns of one step side by side
+        ([K][cols][N] -- one contiguous region per step, fewer concurrent HBM write streams); the
+        column attributes are then strided views.  ``packed=False`` gives dense [K][N] columns."""
+        ncol = 2 * obs_dim + 2
+        self.packed = bool(packed)
+        if self.packed:
+            self._buf = torch.empty((K, ncol, N), dtype=torch.float32, device=device)
+            cols = self._buf.permute(1, 0, 2)                      # [ncol, K, N] view, row stride ncol*N
+            self.obs, self.act, self.rew = cols[:obs_dim], cols[obs_dim], cols[obs_dim + 1]
+            self.obs2 = cols[obs_dim + 2:]
+        else:
+            self.obs = torch.empty((obs_dim, K, N), dtype=torch.float32, device=device)
+            self.obs2 = torch.empty((obs_dim, K, N), dtype=torch.float32, device=device)
+            self.act = torch.empty((K, N), dtype=torch.float32, device=device)
+            self.rew = torch.empty((K, N), dtype=torch.float32, device=device)
         self.done = torch.empty((K, N), dtype=torch.uint8, device=device)
         self.K, self.N, self.obs_dim = K, N, obs_dim
         self.step0 = 0
@@ -104,6 +115,8 @@ class TransitionChunk:
         log.act = self.act.data_ptr()
         log.rew = self.rew.data_ptr()
         log.done = self.done.data_ptr()
+        log.row_stride = self.act.stride(0)
+        log.done_row_stride = self.done.stride(0)
         return log
 
     def records(self):
