@@ -262,6 +262,38 @@ int ssc_mpc_select_action(int32_t n_problems, int32_t n_samples, int32_t horizon
                           float noise_amount, uint64_t seed, uint64_t problem_id0, uint64_t t,
                           float *d_action, float *d_best_path, ssc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * SmartStart selection (smartstart/smartexploration/smartexplorationcontinuous.py:223-305)
+ * ------------------------------------------------------------------------------------- */
+
+/* DDPG critic (Critic_Editted.__call__, DDPG_Baselines_editted/models_editted.py:78-100):
+ *   x = relu(obs @ W1 + b1); x = concat(x, action); x = tanh|relu(x @ W2 + b2); q = x @ W3 + b3
+ * W2 is [h1 + act_dim][h2]; weights fp32, TensorFlow layout, device. */
+typedef struct ssc_critic_desc {
+    int32_t obs_dim, act_dim, h1, h2;
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    int32_t last_layer_tanh;
+} ssc_critic_desc;
+
+/* q[m] = Critic(obs[m][obs_dim], act[m][act_dim]) -- the batched get_q_value of
+ * ddpg_editted.py:274-279 once act = Actor(obs) (ssc_actor_forward). */
+int ssc_critic_forward(const ssc_critic_desc *critic, int64_t m, const float *d_obs, const float *d_act,
+                       float *d_q, ssc_stream_t stream);
+
+/* scipy.stats.gaussian_kde(dataset).evaluate(points) [third-party, call site
+ * smartexplorationcontinuous.py:260,275] for a bandwidth matrix chosen by the caller:
+ *   pdf[i] = norm * sum_j exp(-0.5 * || Wh (points[i] - data[j]) ||^2)
+ * Wh is the d x d row-major whitening matrix (chol(inv(covariance))^T, host array), norm =
+ * 1 / (n * sqrt(det(2 pi covariance))).  data [n][d], points [m][d], pdf [m]; d <= SSC_MAX_STATE. */
+int ssc_kde_evaluate(int32_t d, int64_t n, const float *d_data, int64_t m, const float *d_points,
+                     const float *whitening, double norm, float *d_pdf, ssc_stream_t stream);
+
+/* UCB1 over the candidate smart-start states (smartexplorationcontinuous.py:275-280):
+ *   ucb[i] = alpha * value[i] + sqrt(beta * ln(D) / (D * pdf[i] * volume));  best = argmax (lowest
+ * index on ties).  d_ucb [m] may be NULL; d_best [1]. */
+int ssc_ucb_argmax(int64_t m, const float *d_value, const float *d_pdf, float alpha, float beta, double buffer_len,
+                   double volume, float *d_ucb, int32_t *d_best, ssc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

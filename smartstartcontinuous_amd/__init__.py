@@ -11,3 +11,4 @@ from .spaces import Box, EnvSpec  # noqa: F401
 from .vec_env import (ActorPolicy, Continuous_MountainCarEnv_Editted, EpisodeRing, RandomPolicy,  # noqa: F401
                       SingleEnvView, TransitionChunk, VecEnv, make)
 from .rl_train import Episode, Summary, rlTrain, rl_train_vec  # noqa: F401,E402
+from .smartstart import SmartStartContinuous  # noqa: F401,E402

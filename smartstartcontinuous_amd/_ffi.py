@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libssc.so")
@@ -84,6 +84,12 @@ class MpcProblems(Structure):
                 ("horizontal_penalty_factor", c_float), ("per_row_projection", c_int32)]
 
 
+class CriticDesc(Structure):
+    _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("h1", c_int32), ("h2", c_int32),
+                ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
+                ("W3", c_void_p), ("b3", c_void_p), ("last_layer_tanh", c_int32)]
+
+
 # symbol -> (restype, argtypes); every function include/ssc.h declares must be listed here
 # (tests/test_abi.py cross-checks the header against this table and the built library).
 _SIGNATURES = {
@@ -104,6 +110,11 @@ _SIGNATURES = {
     "ssc_pack_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
     "ssc_pack_transitions": (c_int, [POINTER(TransitionLog), c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p,
                                      c_void_p]),
+    "ssc_critic_forward": (c_int, [POINTER(CriticDesc), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ssc_kde_evaluate": (c_int, [c_int32, c_int64, c_void_p, c_int64, c_void_p, POINTER(c_float), c_double, c_void_p,
+                                 c_void_p]),
+    "ssc_ucb_argmax": (c_int, [c_int64, c_void_p, c_void_p, c_float, c_float, c_double, c_double, c_void_p, c_void_p,
+                               c_void_p]),
     "ssc_mlp_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),
     "ssc_mlp_forward": (c_int, [POINTER(MlpDesc), c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "ssc_dyn_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),

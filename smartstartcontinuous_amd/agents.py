@@ -102,6 +102,18 @@ class DecayingOrnsteinUhlenbeckActionNoise:
         self.epsilon = max(self.epsilon * self.epsilon_decay_factor, self.min_epsilon)
 
 
+def init_critic_weights(obs_dim, h1, h2, nb_actions, generator=None):
+    """Critic_Editted (models_editted.py:78-100): glorot-uniform kernels, zero biases, W2 is
+    [h1 + nb_actions, h2] (the action joins after the first ReLU), last layer U(-3e-3, 3e-3)."""
+    g = generator
+
+    def glorot(i, o):
+        lim = float(np.sqrt(6.0 / (i + o)))
+        return (torch.rand((i, o), generator=g) * 2 - 1) * lim
+    return dict(W1=glorot(obs_dim, h1), b1=torch.zeros(h1), W2=glorot(h1 + nb_actions, h2), b2=torch.zeros(h2),
+                W3=(torch.rand((h2, 1), generator=g) * 2 - 1) * 3e-3, b3=torch.zeros(1))
+
+
 def init_actor_weights(obs_dim, h1, h2, nb_actions, generator=None):
     """tf.layers.dense defaults in Actor_Editted (models_editted.py:44-59): glorot-uniform kernels,
     zero biases; last layer U(-3e-3, 3e-3)."""
@@ -146,6 +158,7 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         obs_dim = env.observation_space.shape[-1]
         gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
         self.set_weights(init_actor_weights(obs_dim, actor_h1, actor_h2, nb_actions, gen))
+        self.set_critic_weights(init_critic_weights(obs_dim, critic_h1, critic_h2, nb_actions, gen))
         self.decaying_ou_action_noise = DecayingOrnsteinUhlenbeckActionNoise(
             ou_epsilon, ou_min_epsilon, ou_epsilon_decay_factor, mu=ou_mu * np.ones(nb_actions),
             sigma=float(ou_sigma) * np.ones(nb_actions), theta=ou_theta)   # :152-157
@@ -165,6 +178,29 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         d.last_layer_tanh = int(self.lastLayerTanh)
         d.precision = _ffi.SSC_PREC_F32 if self.precision == "f32" else _ffi.SSC_PREC_BF16_MFMA
         self._desc = d
+
+    def set_critic_weights(self, weights):
+        """weights: dict W1[obs,h1] b1 W2[h1+act,h2] b2 W3[h2,1] b3 (Critic_Editted, models_editted.py:78-100)."""
+        self.critic_weights = {k: torch.as_tensor(v, dtype=torch.float32).to(self.device).contiguous()
+                               for k, v in weights.items()}
+        w = self.critic_weights
+        c = _ffi.CriticDesc()
+        c.obs_dim, c.h1 = w["W1"].shape
+        c.h2 = w["W2"].shape[1]
+        c.act_dim = w["W2"].shape[0] - c.h1
+        c.W1, c.b1, c.W2, c.b2, c.W3, c.b3 = (w[k].data_ptr() for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
+        c.last_layer_tanh = int(self.lastLayerTanh)
+        self._critic_desc = c
+
+    def critic(self, obs, act):
+        """Critic_Editted forward: Q(obs [m, obs_dim], act [m, act_dim]) -> [m]."""
+        o = torch.as_tensor(obs, dtype=torch.float32, device=self.device).reshape(-1, self.obs_dim).contiguous()
+        a = torch.as_tensor(act, dtype=torch.float32, device=self.device).reshape(o.shape[0], -1).contiguous()
+        q = torch.empty(o.shape[0], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.ssc_critic_forward(ctypes.byref(self._critic_desc), o.shape[0], _ffi.ptr(o),
+                                                   _ffi.ptr(a), _ffi.ptr(q), _stream()))
+        return q
 
     def actor(self, obs):
         """Actor_Editted forward (models_editted.py:38-61) on a batch: obs [m, obs_dim] -> [m, act_dim]."""
@@ -198,7 +234,12 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
                            ou_dt=n.dt, ou_epsilon=float(max(n.epsilon, 0)))
 
     def get_state_value(self, state):
-        raise NotImplementedError("critic forward / Q-values belong to the DDPG training step (SURVEY.md 8f, next)")
+        """:197-204 -> DDPG_editted.get_q_value (ddpg_editted.py:274-279): Q(s, pi(s)) without noise.
+        Returns [n, 1] for a batch, a length-1 array for a single state (like ``sess.run(...)[0]``)."""
+        single = np.ndim(state) == 1 if not torch.is_tensor(state) else state.dim() == 1
+        o = torch.as_tensor(state, dtype=torch.float32, device=self.device).reshape(-1, self.obs_dim)
+        q = self.critic(o, self.actor(o)).reshape(-1, 1).double().cpu().numpy()
+        return q[0] if single else q
 
     def observe(self, state, action, reward, new_state, done):
         """:242-247 (store_transition, ddpg_editted.py:281-285); training is not on this path."""
@@ -278,6 +319,7 @@ class NND_MB_agent(NavigationRLAgent):
                                                  precision=precision)
         self.state_dim, self.act_dim = state_dim, act_dim
         self.desired_states = None
+        self.radii = None                   # NND_MB_agent.py:168
         self.param_dict = None
 
     @staticmethod

@@ -1,0 +1,208 @@
+// smartstart.hip -- SmartStart selection on the GPU (smartexplorationcontinuous.py:223-305):
+// batched critic value V(s) = Q(s, pi(s)), Gaussian kernel-density "visitation count" and the
+// UCB1 argmax over the candidate smart-start states.
+//
+// The KDE is the n_ss x |D| pairwise kernel the reference evaluates through
+// scipy.stats.gaussian_kde (2000 x 100 000 in the shipped runs): 2e8 exp() per episode start --
+// the latency spike the author timed (:354-360).  Here: one block per 8 query points, the data
+// set streamed from L2 (0.8 MB at |D| = 1e5, d = 2), fp32 exp on the transcendental pipe, f64
+// block reduction.
+#include "ssc_device.h"
+#include "ssc_host.h"
+
+namespace ssc {
+
+struct CriticW {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    int32_t obs_dim, act_dim, h1, h2, last_tanh;
+};
+
+// one row per lane; layer-1 activations (+ the action, models_editted.py:89) parked in LDS as [unit][lane]
+__global__ __launch_bounds__(64) void critic_kernel(CriticW w, int64_t m, const float *__restrict__ obs,
+                                                    const float *__restrict__ act, float *__restrict__ q) {
+    extern __shared__ float hs[];  // [(h1 + act_dim)][64]
+    const int lane = threadIdx.x;
+    const int64_t gi = (int64_t)blockIdx.x * 64 + lane;
+    const bool active = gi < m;
+    const int64_t i = active ? gi : m - 1;
+    float o[SSC_MAX_STATE];
+#pragma unroll
+    for (int c = 0; c < SSC_MAX_STATE; ++c) o[c] = (c < w.obs_dim) ? obs[i * w.obs_dim + c] : 0.0f;
+    for (int j = 0; j < w.h1; ++j) {
+        float acc = w.b1[j];
+#pragma unroll
+        for (int c = 0; c < SSC_MAX_STATE; ++c)
+            if (c < w.obs_dim) acc = fmaf(o[c], w.W1[c * w.h1 + j], acc);
+        hs[j * 64 + lane] = fmaxf(acc, 0.0f);  // models_editted.py:87
+    }
+    for (int a = 0; a < w.act_dim; ++a) hs[(w.h1 + a) * 64 + lane] = act[i * w.act_dim + a];  // :89
+    const int in2 = w.h1 + w.act_dim;
+    float out = w.b3[0];
+    for (int j = 0; j < w.h2; ++j) {
+        float acc = w.b2[j];
+        for (int k = 0; k < in2; ++k) acc = fmaf(hs[k * 64 + lane], w.W2[k * w.h2 + j], acc);
+        const float h2 = w.last_tanh ? tanhf(acc) : fmaxf(acc, 0.0f);  // :95-98
+        out = fmaf(h2, w.W3[j], out);                                    // :100 (no output tanh)
+    }
+    if (active) q[i] = out;
+}
+
+constexpr int kKdeQ = 8;  // query points per block
+
+struct KdeArgs {
+    int32_t d;
+    int64_t n, m;
+    float wh[SSC_MAX_STATE * SSC_MAX_STATE];
+    double norm;
+};
+
+__global__ __launch_bounds__(256) void kde_kernel(KdeArgs a, const float *__restrict__ data,
+                                                  const float *__restrict__ points, float *__restrict__ pdf) {
+    __shared__ double red[256 / 64][kKdeQ];
+    const int d = a.d;
+    // whitened query points: y_q = Wh * x_q  (then || Wh (x_q - x_j) || = || y_q - Wh x_j ||)
+    float yq[kKdeQ][SSC_MAX_STATE];
+#pragma unroll
+    for (int q = 0; q < kKdeQ; ++q) {
+        const int64_t qi = min((int64_t)blockIdx.x * kKdeQ + q, a.m - 1);
+#pragma unroll
+        for (int r = 0; r < SSC_MAX_STATE; ++r) {
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < SSC_MAX_STATE; ++c)
+                if (r < d && c < d) s = fmaf(a.wh[r * d + c], points[qi * d + c], s);
+            yq[q][r] = s;
+        }
+    }
+    float sum[kKdeQ];
+#pragma unroll
+    for (int q = 0; q < kKdeQ; ++q) sum[q] = 0.0f;
+    for (int64_t j = threadIdx.x; j < a.n; j += 256) {
+        float x[SSC_MAX_STATE], y[SSC_MAX_STATE];
+#pragma unroll
+        for (int c = 0; c < SSC_MAX_STATE; ++c) x[c] = (c < d) ? data[j * d + c] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < SSC_MAX_STATE; ++r) {
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < SSC_MAX_STATE; ++c)
+                if (r < d && c < d) s = fmaf(a.wh[r * d + c], x[c], s);
+            y[r] = s;
+        }
+#pragma unroll
+        for (int q = 0; q < kKdeQ; ++q) {
+            float e = 0.0f;
+#pragma unroll
+            for (int r = 0; r < SSC_MAX_STATE; ++r)
+                if (r < d) {
+                    const float t = yq[q][r] - y[r];
+                    e = fmaf(t, t, e);
+                }
+            sum[q] += __expf(-0.5f * e);
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < kKdeQ; ++q) {
+        double v = (double)sum[q];
+#pragma unroll
+        for (int msk = 32; msk >= 1; msk >>= 1) v += __shfl_xor(v, msk);
+        if (lane == 0) red[wave][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kKdeQ) {
+        const int64_t qi = (int64_t)blockIdx.x * kKdeQ + threadIdx.x;
+        if (qi < a.m) {
+            double v = 0.0;
+            for (int w = 0; w < 256 / 64; ++w) v += red[w][threadIdx.x];
+            pdf[qi] = (float)(v * a.norm);
+        }
+    }
+}
+
+// single block: ucb + argmax (m <= a few thousand candidates)
+__global__ __launch_bounds__(256) void ucb_kernel(int64_t m, const float *__restrict__ value,
+                                                  const float *__restrict__ pdf, float alpha, float beta,
+                                                  double buffer_len, double volume, float *__restrict__ ucb,
+                                                  int32_t *__restrict__ best) {
+    __shared__ float rs[4];
+    __shared__ int ri[4];
+    float bs = -INFINITY;
+    int bi = 0x7fffffff;
+    const double num = (double)beta * log(buffer_len);
+    for (int64_t i = threadIdx.x; i < m; i += 256) {
+        const double c_hat = buffer_len * (double)pdf[i] * volume;              // :276
+        const float u = alpha * value[i] + (float)sqrt(num / c_hat);            // :277-279
+        if (ucb != nullptr) ucb[i] = u;
+        if (u > bs || (u == bs && (int)i < bi)) { bs = u; bi = (int)i; }
+    }
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+        const float os = __shfl_xor(bs, msk);
+        const int oi = __shfl_xor(bi, msk);
+        if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = bs; ri[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (rs[w] > bs || (rs[w] == bs && ri[w] < bi)) { bs = rs[w]; bi = ri[w]; }
+        best[0] = (bi == 0x7fffffff) ? 0 : bi;   // :280 np.argmax
+    }
+}
+
+}  // namespace ssc
+
+using namespace ssc;
+
+extern "C" {
+
+int ssc_critic_forward(const ssc_critic_desc *c, int64_t m, const float *d_obs, const float *d_act, float *d_q,
+                       ssc_stream_t stream) {
+    SSC_REQUIRE(c != nullptr, "ssc_critic_forward: critic NULL");
+    SSC_REQUIRE(m >= 0, "ssc_critic_forward: m < 0");
+    SSC_REQUIRE(c->obs_dim >= 1 && c->obs_dim <= SSC_MAX_STATE && c->act_dim >= 1 && c->act_dim <= SSC_MAX_ACT,
+                "ssc_critic_forward: obs_dim %d / act_dim %d out of range", c->obs_dim, c->act_dim);
+    SSC_REQUIRE(c->h1 >= 1 && c->h2 >= 1 && c->h1 + c->act_dim <= 600, "ssc_critic_forward: bad hidden sizes");
+    if (m == 0) return SSC_OK;
+    SSC_REQUIRE(c->W1 && c->b1 && c->W2 && c->b2 && c->W3 && c->b3 && d_obs && d_act && d_q,
+                "ssc_critic_forward: NULL device pointer");
+    const CriticW w{c->W1, c->b1, c->W2, c->b2, c->W3, c->b3, c->obs_dim, c->act_dim, c->h1, c->h2, c->last_layer_tanh};
+    const size_t lds = (size_t)(c->h1 + c->act_dim) * 64 * sizeof(float);
+    if (lds > 64 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "hipFuncSetAttribute(critic_kernel)");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(critic_kernel, dim3(blocks_for(m, 64)), dim3(64), lds, as_stream(stream), w, m, d_obs, d_act,
+                       d_q);
+    return check_launch("ssc_critic_forward");
+}
+
+int ssc_kde_evaluate(int32_t d, int64_t n, const float *d_data, int64_t m, const float *d_points,
+                     const float *whitening, double norm, float *d_pdf, ssc_stream_t stream) {
+    SSC_REQUIRE(d >= 1 && d <= SSC_MAX_STATE, "ssc_kde_evaluate: d = %d out of range", d);
+    SSC_REQUIRE(n >= 1 && m >= 0, "ssc_kde_evaluate: need n >= 1, m >= 0");
+    SSC_REQUIRE(whitening != nullptr, "ssc_kde_evaluate: whitening NULL");
+    if (m == 0) return SSC_OK;
+    SSC_REQUIRE(d_data && d_points && d_pdf, "ssc_kde_evaluate: NULL device pointer");
+    KdeArgs a{};
+    a.d = d; a.n = n; a.m = m; a.norm = norm;
+    for (int i = 0; i < d * d; ++i) a.wh[i] = whitening[i];
+    hipLaunchKernelGGL(kde_kernel, dim3(blocks_for(m, kKdeQ)), dim3(256), 0, as_stream(stream), a, d_data, d_points,
+                       d_pdf);
+    return check_launch("ssc_kde_evaluate");
+}
+
+int ssc_ucb_argmax(int64_t m, const float *d_value, const float *d_pdf, float alpha, float beta, double buffer_len,
+                   double volume, float *d_ucb, int32_t *d_best, ssc_stream_t stream) {
+    SSC_REQUIRE(m >= 1, "ssc_ucb_argmax: m < 1");
+    SSC_REQUIRE(buffer_len >= 1.0 && volume > 0.0, "ssc_ucb_argmax: bad buffer_len / volume");
+    SSC_REQUIRE(d_value && d_pdf && d_best, "ssc_ucb_argmax: NULL device pointer");
+    hipLaunchKernelGGL(ucb_kernel, dim3(1), dim3(256), 0, as_stream(stream), m, d_value, d_pdf, alpha, beta, buffer_len,
+                       volume, d_ucb, d_best);
+    return check_launch("ssc_ucb_argmax");
+}
+
+}  // extern "C"

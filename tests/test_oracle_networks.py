@@ -125,3 +125,21 @@ def test_pendulum_restatement_properties(oracle_clib):
     assert np.allclose(ct, t0, atol=1e-13) and np.allclose(cd, d0, atol=1e-13) and np.allclose(cr, r0, atol=1e-12)
     obs = O.pend_obs(th, thd)
     assert obs.shape == (1000, 3) and np.allclose(obs[:, 0] ** 2 + obs[:, 1] ** 2, 1)
+
+
+def test_kde_restatement_matches_scipy():
+    """scipy.stats.gaussian_kde is what the reference calls (smartexplorationcontinuous.py:260,275)."""
+    import scipy.stats
+    rng = np.random.default_rng(0)
+    for n, d in [(50, 2), (3000, 2), (500, 3), (200, 1)]:
+        data = np.cumsum(rng.normal(size=(n, d)) * 0.02, axis=0)
+        pts = np.concatenate([data[rng.integers(0, n, 40)], rng.normal(size=(10, d))])
+        cov, wh, norm = O.kde_scott(data)
+        k = scipy.stats.gaussian_kde(data.T, bw_method='scott')
+        assert np.allclose(cov, k.covariance, rtol=1e-12)
+        ref = k(pts.T)
+        got = O.kde_evaluate(data, pts, wh, norm)
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-300)
+    ucb, best = O.smart_start_ucb(np.array([0.0, 1.0, 0.5]), np.array([1.0, 1.0, 1e-6]), 1000, 0.01)
+    assert best == 2 and np.isclose(ucb[0], np.sqrt(2 * np.log(1000) / (1000 * 0.01)))
+    assert np.isclose(O.hyperellipsoid_volume([2.0, 3.0]), np.pi * 6)
