@@ -31,6 +31,7 @@ struct ActorWeights {
 // ---------------------------------------------------------------------------------------
 template <int OBS, int H1, int H2>
 struct ActorF32 {
+    static constexpr int kLanesPerEnv = 1;
     // The weights (9.2 KB for 64-32) are staged ONCE per block into LDS and read back as broadcast
     // ds_read_b128: reading them through the kernel-argument pointers inside the step loop forces
     // hipcc to re-issue ~300 global loads per env-step (the log stores may alias them).
@@ -101,8 +102,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // row of a 32x32 MFMA accumulator element: (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
-template <int OBS, int UT, int JT>
+// ET = number of 32-env tiles per wave:
+//   ET = 2  one wave = 64 envs, one env per lane (lane l owns env l);
+//   ET = 1  one wave = 32 envs, each env DUPLICATED on lanes l and l+32: twice the waves for the same
+//           env count (2 waves per SIMD at 65 536 envs).  Measured SLOWER than ET = 2 (0.322 vs
+//           0.293 ms per 65 536 x 256 steps): the kernel is bound by the quarter-rate transcendental
+//           pipe (2 per tanh, 66 per 64 env-steps), whose work does not shrink, while the per-env
+//           dynamics and noise are computed twice.  Kept selectable; the dispatcher uses ET = 2.
+template <int OBS, int UT, int JT, int ET = 2>
 struct ActorMfma {
+    static constexpr int kLanesPerEnv = (ET == 1) ? 2 : 1;
     static constexpr int KS1 = (OBS + 1) / 2;  // 32x32x2 k-steps of layer 1
     float a1[UT][KS1];     // layer-1 A operand: W1[k = 2ks + half][unit = ut*32 + (lane&31)]
     f32x16 c1[UT];         // b1 broadcast in accumulator layout
@@ -165,25 +174,29 @@ struct ActorMfma {
     // obs: this lane's env observation.  Returns the actor output for this lane's env.
     // Wave-collective: every lane of the wave must call it.
     __device__ float forward(const float (&obs)[OBS]) const {
-        // layer-1 B operands for the two 32-env tiles: tile 0 needs [v0.lo | v1.lo], tile 1 [v0.hi | v1.hi]
-        // (v0/v1 = obs components 2ks / 2ks+1 of this lane's env) -- exactly one v_permlane32_swap
-        float bop[2][KS1];
+        const int half = (threadIdx.x & 63) >> 5;
+        // layer-1 B operand of tile et, k-step ks: obs component (2ks + half) of env (et*32 + lane&31).
+        float bop[ET][KS1];
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
             const float v0 = obs[2 * ks];
             const float v1 = (2 * ks + 1 < OBS) ? obs[2 * ks + 1] : 0.0f;
-            half_swap(v0, v1, bop[0][ks], bop[1][ks]);
+            if constexpr (ET == 2) {
+                // tile 0 needs [v0.lo | v1.lo], tile 1 [v0.hi | v1.hi]: exactly one v_permlane32_swap
+                half_swap(v0, v1, bop[0][ks], bop[1][ks]);
+            } else {
+                bop[0][ks] = half ? v1 : v0;  // both lane halves already hold the env's observation
+            }
         }
-        f32x16 acc2[JT][2];
+        f32x16 acc2[JT][ET];
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            acc2[jt][0] = c2[jt];
-            acc2[jt][1] = c2[jt];
-        }
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int et = 0; et < ET; ++et) acc2[jt][et] = c2[jt];
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
 #pragma unroll
-            for (int et = 0; et < 2; ++et) {
+            for (int et = 0; et < ET; ++et) {
                 f32x16 d = c1[ut];
 #pragma unroll
                 for (int ks = 0; ks < KS1; ++ks)
@@ -202,29 +215,32 @@ struct ActorMfma {
                 }
             }
         }
-        float part0 = 0.0f, part1 = 0.0f;
+        float part[ET];
+#pragma unroll
+        for (int et = 0; et < ET; ++et) part[et] = 0.0f;
         if (last_tanh) {  // one wave-uniform branch around the whole layer, not one per element
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float r0 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc2[jt][0][reg]) + 1.0f);
-                    const float r1 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc2[jt][1][reg]) + 1.0f);
-                    part0 = fmaf(r0, w3[jt][reg], part0);
-                    part1 = fmaf(r1, w3[jt][reg], part1);
-                }
+                for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+                    for (int et = 0; et < ET; ++et) {
+                        const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc2[jt][et][reg]) + 1.0f);
+                        part[et] = fmaf(r, w3[jt][reg], part[et]);
+                    }
         } else {
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    part0 = fmaf(fmaxf(acc2[jt][0][reg], 0.0f), w3[jt][reg], part0);
-                    part1 = fmaf(fmaxf(acc2[jt][1][reg], 0.0f), w3[jt][reg], part1);
-                }
+                for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+                    for (int et = 0; et < ET; ++et)
+                        part[et] = fmaf(fmaxf(acc2[jt][et][reg], 0.0f), w3[jt][reg], part[et]);
         }
-        // lanes 0-31 need full0 = part0.lo + part0.hi, lanes 32-63 full1 = part1.lo + part1.hi
+        // ET == 2: lanes 0-31 need part0.lo + part0.hi, lanes 32-63 part1.lo + part1.hi;
+        // ET == 1: every lane needs part.lo + part.hi.  One swap + one add either way.
         float s_lo, s_hi;
-        half_swap(part0, part1, s_lo, s_hi);
+        half_swap(part[0], part[ET - 1], s_lo, s_hi);
         return tanh_fast(s_lo + s_hi + b3);
     }
 };

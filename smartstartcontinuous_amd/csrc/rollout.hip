@@ -103,6 +103,7 @@ struct PhiloxPipe {
 template <int OBS>
 struct RandomPolicy {
     static constexpr bool kPipelined = true;
+    static constexpr int kLanesPerEnv = 1;
     u32x4 cache;
     float low, span;
     __device__ void init(const PolicyArgs &pa, const RolloutArgs &, int64_t) { low = pa.act_low; span = pa.act_span; }
@@ -123,6 +124,7 @@ struct RandomPolicy {
 template <class Net, int OBS>
 struct ActorPolicy {
     static constexpr bool kPipelined = false;
+    static constexpr int kLanesPerEnv = Net::kLanesPerEnv;
     Net net;
     u32x4 cache;
     float ou_x, mu, sig_sqrt_dt, theta_dt, eps;
@@ -178,7 +180,8 @@ struct Rollout {
     int32_t n_goal, n_eps;
     uint64_t env_id;
     uint32_t voff;  // byte offset of this env inside a log row (fp32 columns); row bases are wave-uniform
-    bool active;
+    bool active;    // this lane's env exists (ragged last wave) ...
+    bool owner;     // ... and this lane is the one that reports it (kLanesPerEnv == 2: lanes 0-31 only)
 
     __device__ __forceinline__ Rollout(const typename EnvT::Const &ec_, const RolloutArgs &ra_) : ec(ec_), ra(ra_) {}
 
@@ -197,7 +200,7 @@ struct Rollout {
         ep_ret += rew;
         sum_r += rew;
         n_goal += goal ? 1 : 0;
-        if (LOG) {
+        if (LOG && (PolT::kLanesPerEnv == 1 || owner)) {
             const int64_t row = (int64_t)k * ra.log.row_stride;  // wave-uniform
             const int64_t drow = (int64_t)k * ra.log.done_row_stride;
 #pragma unroll
@@ -214,7 +217,7 @@ struct Rollout {
         for (int c = 0; c < OBS; ++c) obs[c] = obs2[c];
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(done) != 0, 0)) {  // wave-uniform, rare
             if (done) {
-                if (ra.has_ring && active) {
+                if (ra.has_ring && active && owner) {
                     const uint32_t slot = atomicAdd(ra.ring.cursor, 1u);
                     if (slot < (uint32_t)ra.ring.capacity) {
                         ra.ring.env_id[slot] = (int64_t)env_id;
@@ -235,9 +238,14 @@ struct Rollout {
 
 template <class EnvT, class PolT, bool LOG>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec, PolicyArgs pa, RolloutArgs ra) {
-    const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    constexpr int LPE = PolT::kLanesPerEnv;
+    constexpr int kEnvsPerBlock = kBlock / LPE;
+    // LPE == 2: a wave covers 32 envs, env j of the wave lives on lanes j and j+32
+    const int in_block = (LPE == 1) ? (int)threadIdx.x : (int)((threadIdx.x >> 6) * 32 + (threadIdx.x & 31));
+    const int64_t gi = (int64_t)blockIdx.x * kEnvsPerBlock + in_block;
     Rollout<EnvT, PolT, LOG> r(ec, ra);
     r.active = gi < ra.n;
+    r.owner = (LPE == 1) || ((threadIdx.x & 63) < 32);
     const int64_t i = r.active ? gi : ra.n - 1;
     r.env_id = ra.env_id0 + (uint64_t)i;
     r.voff = (uint32_t)i * 4u;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec
             r.step(r.pol.act(r.obs, ra.seed, r.env_id, ra.step0 + (uint64_t)k, k == 0), k);
     }
 
-    if (r.active) {
+    if (r.active && r.owner) {
         ra.st.s0[i] = r.env.s0();
         ra.st.s1[i] = r.env.s1();
         ra.st.steps[i] = r.el;
@@ -295,8 +303,9 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec
     }
 
     if (ra.stats != nullptr) {
-        double v[4] = {r.active ? (double)r.sum_r : 0.0, r.active ? (double)r.n_goal : 0.0,
-                       r.active ? (double)ra.K : 0.0, r.active ? (double)r.n_eps : 0.0};
+        const bool cnt = r.active && r.owner;
+        double v[4] = {cnt ? (double)r.sum_r : 0.0, cnt ? (double)r.n_goal : 0.0, cnt ? (double)ra.K : 0.0,
+                       cnt ? (double)r.n_eps : 0.0};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -319,12 +328,11 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec
 template <class EnvT, class PolT>
 static int launch_rollout(const typename EnvT::Const &ec, const PolicyArgs &pa, const RolloutArgs &ra,
                           hipStream_t stream) {
+    const dim3 grid(blocks_for(ra.n, kBlock / PolT::kLanesPerEnv));
     if (ra.has_log)
-        hipLaunchKernelGGL((rollout_kernel<EnvT, PolT, true>), dim3(blocks_for(ra.n)), dim3(kBlock), 0, stream, ec,
-                           pa, ra);
+        hipLaunchKernelGGL((rollout_kernel<EnvT, PolT, true>), grid, dim3(kBlock), 0, stream, ec, pa, ra);
     else
-        hipLaunchKernelGGL((rollout_kernel<EnvT, PolT, false>), dim3(blocks_for(ra.n)), dim3(kBlock), 0, stream, ec,
-                           pa, ra);
+        hipLaunchKernelGGL((rollout_kernel<EnvT, PolT, false>), grid, dim3(kBlock), 0, stream, ec, pa, ra);
     return check_launch("ssc_rollout");
 }
 
@@ -349,9 +357,9 @@ static int dispatch_policy(const typename EnvT::Const &ec, const ssc_policy_desc
     }
     if (a.precision == SSC_PREC_BF16_MFMA) {
         if (a.h1 <= 64 && a.h2 <= 32)
-            return launch_rollout<EnvT, ActorPolicy<ActorMfma<OBS, 2, 1>, OBS>>(ec, pa, ra, stream);
+            return launch_rollout<EnvT, ActorPolicy<ActorMfma<OBS, 2, 1, 2>, OBS>>(ec, pa, ra, stream);
         if (a.h1 <= 128 && a.h2 <= 64)
-            return launch_rollout<EnvT, ActorPolicy<ActorMfma<OBS, 4, 2>, OBS>>(ec, pa, ra, stream);
+            return launch_rollout<EnvT, ActorPolicy<ActorMfma<OBS, 4, 2, 2>, OBS>>(ec, pa, ra, stream);
         return set_error(SSC_EUNSUPPORTED, "ssc_rollout: MFMA actor supports h1 <= 128, h2 <= 64 (got %d-%d)",
                          a.h1, a.h2);
     }
