@@ -294,6 +294,43 @@ int ssc_kde_evaluate(int32_t d, int64_t n, const float *d_data, int64_t m, const
 int ssc_ucb_argmax(int64_t m, const float *d_value, const float *d_pdf, float alpha, float beta, double buffer_len,
                    double volume, float *d_ucb, int32_t *d_best, ssc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * DDPG training step
+ * ------------------------------------------------------------------------------------- */
+
+/* DDPG_editted.train() + update_target_net() (DDPG_Baselines_editted/ddpg_editted.py:287-339) as
+ * driven by DDPG_Baselines_agent.train (smartstart/RLAgents/DDPG_Baselines_agent.py:264-273), in the
+ * configuration of every shipped run: no observation/return normalisation, no popart, no l2
+ * regularisation, no gradient clipping.  Each network's parameters are ONE flat fp32 device array
+ * in TensorFlow trainable_vars order [W1 | b1 | W2 | b2 | W3 | b3] (the order U.flatgrad and
+ * MpiAdam use); Adam moments have the same shape.  Critic W2 is [critic_h1 + act_dim][critic_h2]. */
+typedef struct ssc_ddpg_desc {
+    int32_t obs_dim, act_dim, actor_h1, actor_h2, critic_h1, critic_h2;
+    int32_t last_layer_tanh;
+    int32_t batch_size;                                   /* 64 */
+    float *actor, *critic, *target_actor, *target_critic; /* device, flat */
+    float *adam_m_actor, *adam_v_actor, *adam_m_critic, *adam_v_critic; /* device, flat, zero-initialised */
+    int32_t *adam_t;                                      /* device [2]: MpiAdam step counters (actor, critic) */
+    float gamma, tau, actor_lr, critic_lr;
+    float beta1, beta2, epsilon;                          /* MpiAdam: 0.9, 0.999, 1e-8 (ddpg_editted.py:176,198) */
+} ssc_ddpg_desc;
+
+/* Replay storage the batches are drawn from: row-major device arrays of `capacity` records
+ * (the (s, a, r, t, s2) tuple of replay_buffer.py:53). */
+typedef struct ssc_replay_view {
+    const float *s, *a, *r;
+    const uint8_t *t;
+    const float *s2;
+    int64_t capacity;
+} ssc_replay_view;
+
+/* n_iters sequential training iterations in ONE launch (one workgroup: the iterations are a serial
+ * chain through the parameters).  d_batch_idx [n_iters][batch_size] are record indices
+ * (ReplayBuffer.sample_batch, replay_buffer.py:79-91, draws them on the host).  d_losses
+ * [n_iters][2] = (critic_loss, actor_loss) per iteration, may be NULL. */
+int ssc_ddpg_train(const ssc_ddpg_desc *ddpg, const ssc_replay_view *replay, const int32_t *d_batch_idx,
+                   int32_t n_iters, float *d_losses, ssc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,21 @@ class CriticDesc(Structure):
                 ("W3", c_void_p), ("b3", c_void_p), ("last_layer_tanh", c_int32)]
 
 
+class DdpgDesc(Structure):
+    _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("actor_h1", c_int32), ("actor_h2", c_int32),
+                ("critic_h1", c_int32), ("critic_h2", c_int32), ("last_layer_tanh", c_int32), ("batch_size", c_int32),
+                ("actor", c_void_p), ("critic", c_void_p), ("target_actor", c_void_p), ("target_critic", c_void_p),
+                ("adam_m_actor", c_void_p), ("adam_v_actor", c_void_p), ("adam_m_critic", c_void_p),
+                ("adam_v_critic", c_void_p), ("adam_t", c_void_p),
+                ("gamma", c_float), ("tau", c_float), ("actor_lr", c_float), ("critic_lr", c_float),
+                ("beta1", c_float), ("beta2", c_float), ("epsilon", c_float)]
+
+
+class ReplayView(Structure):
+    _fields_ = [("s", c_void_p), ("a", c_void_p), ("r", c_void_p), ("t", c_void_p), ("s2", c_void_p),
+                ("capacity", c_int64)]
+
+
 # symbol -> (restype, argtypes); every function include/ssc.h declares must be listed here
 # (tests/test_abi.py cross-checks the header against this table and the built library).
 _SIGNATURES = {
@@ -115,6 +130,7 @@ _SIGNATURES = {
                                  c_void_p]),
     "ssc_ucb_argmax": (c_int, [c_int64, c_void_p, c_void_p, c_float, c_float, c_double, c_double, c_void_p, c_void_p,
                                c_void_p]),
+    "ssc_ddpg_train": (c_int, [POINTER(DdpgDesc), POINTER(ReplayView), c_void_p, c_int32, c_void_p, c_void_p]),
     "ssc_mlp_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),
     "ssc_mlp_forward": (c_int, [POINTER(MlpDesc), c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "ssc_dyn_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),

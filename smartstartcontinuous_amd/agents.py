@@ -3,9 +3,9 @@ smartstart/reinforcementLearningCore/agents_abstract_classes.py and GPU-backed c
 ``DDPG_Baselines_agent`` (action path) and ``NND_MB_agent`` (the SmartStart navigator).
 
 Constructor keyword names follow the reference classes so existing call sites keep working; the
-TensorFlow session argument ``sess`` is accepted and ignored.  Learning (DDPG / dynamics-model
-training) is NOT part of the accelerated path (SURVEY.md section 8f "next"): weights are plain torch
-tensors that a trainer may overwrite through ``set_weights``; ``train()`` raises.
+TensorFlow session argument ``sess`` is accepted and ignored.  The DDPG learner step runs on the GPU
+(``ssc_ddpg_train``); dynamics-model training is still "next": the
+navigator's weights are plain torch tensors that a trainer may overwrite through ``set_weights``.
 """
 from __future__ import annotations
 
@@ -126,6 +126,23 @@ def init_actor_weights(obs_dim, h1, h2, nb_actions, generator=None):
                 W3=(torch.rand((h2, nb_actions), generator=g) * 2 - 1) * 3e-3, b3=torch.zeros(nb_actions))
 
 
+PARAM_KEYS = ("W1", "b1", "W2", "b2", "W3", "b3")
+
+
+def flatten_params(weights, device):
+    """One flat fp32 tensor in TensorFlow trainable_vars order [W1|b1|W2|b2|W3|b3] plus a dict of VIEWS
+    into it, so that kernels reading the dict see what the learner kernel wrote into the flat array."""
+    parts = [torch.as_tensor(weights[k], dtype=torch.float32).reshape(-1) for k in PARAM_KEYS]
+    flat = torch.cat(parts).to(device).contiguous()
+    views, o = {}, 0
+    for k in PARAM_KEYS:
+        shape = tuple(torch.as_tensor(weights[k]).shape)
+        n = int(np.prod(shape))
+        views[k] = flat[o:o + n].view(shape)
+        o += n
+    return flat, views
+
+
 class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
     """Action path of smartstart/RLAgents/DDPG_Baselines_agent.py (:86-273): actor forward on the GPU
     (``ssc_actor_forward``), decaying OU noise, clip, double ``scale``; transitions go to the shared
@@ -136,7 +153,7 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
                  ou_mu=0.4, ou_sigma=0.2, ou_theta=.15, actor_lr=1e-4, actor_h1=64, actor_h2=64, critic_lr=1e-3,
                  critic_h1=64, critic_h2=64, gamma=0.99, tau=0.001, layer_norm=False, normalize_observations=False,
                  normalize_returns=False, critic_l2_reg=0, enable_popart=False, clip_norm=None, reward_scale=1.,
-                 lastLayerTanh=False, finalizeGraph=True, device="cuda", precision="f32", seed=None):
+                 lastLayerTanh=False, finalizeGraph=True, device="cuda", precision="f32", seed=None, training=True):
         args = dict(locals())
         self.param_dict = {k: (v if isinstance(v, (int, float, bool, str, type(None))) else "Not serializable")
                            for k, v in args.items() if k not in ("self", "__class__")}   # :135-137
@@ -151,9 +168,13 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         self.num_steps_before_train = num_steps_before_train
         self.remaining_steps_before_train = num_steps_before_train
         self.reward_scale = reward_scale
+        self.gamma, self.tau, self.actor_lr, self.critic_lr = gamma, tau, actor_lr, critic_lr
+        if critic_l2_reg or clip_norm is not None:
+            raise NotImplementedError("critic_l2_reg / clip_norm are not on the accelerated path (unused by every shipped run)")
         self.lastLayerTanh = bool(lastLayerTanh)
         self.precision = precision
         self.replay_buffer = replay_buffer if replay_buffer is not None else ReplayBuffer(self, buffer_size)
+        self.training_enabled = training
         nb_actions = env.action_space.shape[-1]
         obs_dim = env.observation_space.shape[-1]
         gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
@@ -167,8 +188,9 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
     # ---- weights ---------------------------------------------------------------------------
     def set_weights(self, weights):
         """weights: dict W1[obs,h1] b1 W2[h1,h2] b2 W3[h2,act] b3 (TensorFlow layout)."""
-        self.weights = {k: torch.as_tensor(v, dtype=torch.float32).to(self.device).contiguous()
-                        for k, v in weights.items()}
+        self.actor_flat, self.weights = flatten_params(weights, self.device)
+        self.target_actor_flat = self.actor_flat.clone()        # target_init_updates (ddpg_editted.py:331-336)
+        self._adam_actor = (torch.zeros_like(self.actor_flat), torch.zeros_like(self.actor_flat))
         w = self.weights
         self.obs_dim, self.h1 = w["W1"].shape
         self.h2, self.act_dim = w["W3"].shape
@@ -181,8 +203,10 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
 
     def set_critic_weights(self, weights):
         """weights: dict W1[obs,h1] b1 W2[h1+act,h2] b2 W3[h2,1] b3 (Critic_Editted, models_editted.py:78-100)."""
-        self.critic_weights = {k: torch.as_tensor(v, dtype=torch.float32).to(self.device).contiguous()
-                               for k, v in weights.items()}
+        self.critic_flat, self.critic_weights = flatten_params(weights, self.device)
+        self.target_critic_flat = self.critic_flat.clone()
+        self._adam_critic = (torch.zeros_like(self.critic_flat), torch.zeros_like(self.critic_flat))
+        self._adam_t = torch.zeros(2, dtype=torch.int32, device=self.device)
         w = self.critic_weights
         c = _ffi.CriticDesc()
         c.obs_dim, c.h1 = w["W1"].shape
@@ -242,9 +266,11 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         return q[0] if single else q
 
     def observe(self, state, action, reward, new_state, done):
-        """:242-247 (store_transition, ddpg_editted.py:281-285); training is not on this path."""
+        """:242-247 (store_transition, ddpg_editted.py:281-285)"""
         self.replay_buffer.add(self, state, action, reward * self.reward_scale, done, new_state)
         self.remaining_steps_before_train -= 1
+        if self.training_enabled and self.remaining_steps_before_train <= 0:
+            self.train()
 
     def start_new_episode(self, state):
         self.replay_buffer.start_new_episode(self)
@@ -256,12 +282,58 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         """:255-258"""
         self.decaying_ou_action_noise.reset()
         self.decaying_ou_action_noise.reduce_epsilon()
+        if self.training_enabled:
+            self.train()
 
     def get_param_dict(self):
         return self.param_dict
 
+    # ---- learner (SURVEY.md 8f rank 1) -------------------------------------------------------------
+    def ddpg_desc(self):
+        d = _ffi.DdpgDesc()
+        d.obs_dim, d.act_dim = self.obs_dim, self.act_dim
+        d.actor_h1, d.actor_h2 = self.h1, self.h2
+        d.critic_h1, d.critic_h2 = self._critic_desc.h1, self._critic_desc.h2
+        d.last_layer_tanh, d.batch_size = int(self.lastLayerTanh), self.batch_size
+        d.actor, d.critic = self.actor_flat.data_ptr(), self.critic_flat.data_ptr()
+        d.target_actor, d.target_critic = self.target_actor_flat.data_ptr(), self.target_critic_flat.data_ptr()
+        d.adam_m_actor, d.adam_v_actor = (t.data_ptr() for t in self._adam_actor)
+        d.adam_m_critic, d.adam_v_critic = (t.data_ptr() for t in self._adam_critic)
+        d.adam_t = self._adam_t.data_ptr()
+        d.gamma, d.tau, d.actor_lr, d.critic_lr = self.gamma, self.tau, self.actor_lr, self.critic_lr
+        d.beta1, d.beta2, d.epsilon = 0.9, 0.999, 1e-8          # ddpg_editted.py:176,198
+        return d
+
+    def train_on(self, s, a, r, t, s2, batch_idx, n_iters):
+        """``n_iters`` x (DDPG_editted.train + update_target_net) on device replay arrays; ``batch_idx``
+        int32 [n_iters, batch_size].  Returns the (critic_loss, actor_loss) tensor [n_iters, 2]."""
+        rv = _ffi.ReplayView(s.data_ptr(), a.data_ptr(), r.data_ptr(), t.data_ptr(), s2.data_ptr(), s.shape[0])
+        losses = torch.empty((n_iters, 2), dtype=torch.float32, device=self.device)
+        d = self.ddpg_desc()
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.ssc_ddpg_train(ctypes.byref(d), ctypes.byref(rv), _ffi.ptr(batch_idx), n_iters,
+                                               _ffi.ptr(losses), _stream()))
+        return losses
+
     def train(self):
-        raise NotImplementedError("DDPG training is outside the accelerated path (SURVEY.md section 8f)")
+        """DDPG_Baselines_agent.train (:264-273): ``num_train_iterations`` x (train + update_target_net),
+        each on a fresh uniform batch -- all iterations in one kernel launch."""
+        if len(self.replay_buffer) < self.batch_size:
+            return None
+        self.remaining_steps_before_train = self.num_steps_before_train
+        n = self.num_train_iterations
+        B = self.batch_size
+        cols = [[] for _ in range(5)]
+        for _ in range(n):                                       # sample_batch per iteration (:287-289)
+            for c, x in zip(cols, self.replay_buffer.sample_batch(B)):
+                c.append(x)
+        s, a, r, t, s2 = (np.concatenate(c) for c in cols)
+        dev = self.device
+        f = lambda x, dt: torch.as_tensor(np.ascontiguousarray(x), dtype=dt).to(dev)
+        idx = torch.arange(n * B, dtype=torch.int32, device=dev).view(n, B)
+        losses = self.train_on(f(s, torch.float32), f(a, torch.float32), f(r, torch.float32), f(t, torch.uint8),
+                               f(s2, torch.float32), idx, n)
+        return losses
 
 
 # ---------------------------------------------------------------------------- navigator --

@@ -51,8 +51,7 @@ def test_rltrain_with_ddpg_agent(ssc):
     torch.cuda.synchronize()
     o = chunk.obs.cpu().numpy().transpose(1, 2, 0).reshape(-1, 2)
     assert np.max(np.abs(chunk.act.cpu().numpy().reshape(-1) - np.clip(O.actor_forward(o, **w)[:, 0], -1, 1))) <= 1e-5
-    with pytest.raises(NotImplementedError):
-        agent.train()
+    assert int(agent._adam_t[0].item()) > 100      # observe()/end_episode() trained once the buffer held 64 records
 
 
 def test_navigator_get_action_matches_oracle_pipeline(ssc, golden_dir):
@@ -197,3 +196,78 @@ def test_rltrain_with_smartstart_agent(ssc, golden_dir):
     assert ref_ucb[best] >= ref_ucb.max() - 2e-3 * abs(ref_ucb.max())
     path = agent.get_smart_start_path()
     assert len(path) >= 2 and np.asarray(path).shape[1] == 2
+
+
+def test_ddpg_train_kernel_vs_oracle(ssc):
+    """ssc_ddpg_train (train + update_target_net, n iterations in one launch) against the fp64 restatement
+    of ddpg_editted.py:287-339 (itself cross-checked against torch autograd on the CPU)."""
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    rng = np.random.default_rng(11)
+    env = ssc.make("MountainCarContinuous-v0")
+    for llt in (True, False):
+        agent = DDPG_Baselines_agent(env, None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32, lastLayerTanh=llt,
+                                     actor_lr=1e-3, critic_lr=1e-3, gamma=0.99, tau=0.001, batch_size=64, seed=5,
+                                     training=False)
+        # non-trivial starting point: perturb every parameter (biases and the 3e-3 output layers included)
+        aw = {k: v.cpu().numpy() + (0.05 * rng.normal(size=tuple(v.shape))).astype(np.float32) for k, v in agent.weights.items()}
+        cw = {k: v.cpu().numpy() + (0.05 * rng.normal(size=tuple(v.shape))).astype(np.float32) for k, v in agent.critic_weights.items()}
+        agent.set_weights(aw)
+        agent.set_critic_weights(cw)
+        agent.target_actor_flat += 0.01
+        agent.target_critic_flat -= 0.01
+        cap, n_iters, B = 1000, 6, 64
+        s = rng.uniform(-1.2, 0.6, (cap, 2)).astype(np.float32)
+        a = rng.uniform(-1, 1, (cap, 1)).astype(np.float32)
+        r = (rng.normal(size=cap) * 0.5).astype(np.float32)
+        t = (rng.random(cap) < 0.1)
+        s2 = (s + rng.normal(size=(cap, 2)) * 0.01).astype(np.float32)
+        idx = np.stack([rng.permutation(cap)[:B] for _ in range(n_iters)]).astype(np.int32)
+        # oracle state (fp64 copies of what the device holds)
+        o_a = {k: v.astype(np.float64) for k, v in aw.items()}
+        o_c = {k: v.astype(np.float64) for k, v in cw.items()}
+        o_ta = O.unflatten_params(agent.target_actor_flat.cpu().numpy().astype(np.float64), o_a)
+        o_tc = O.unflatten_params(agent.target_critic_flat.cpu().numpy().astype(np.float64), o_c)
+        na, nc = agent.actor_flat.numel(), agent.critic_flat.numel()
+        adam = dict(m_actor=np.zeros(na), v_actor=np.zeros(na), t_actor=0, m_critic=np.zeros(nc), v_critic=np.zeros(nc), t_critic=0)
+        ref_losses = []
+        for it in range(n_iters):
+            bi = idx[it]
+            o_a, o_c, o_ta, o_tc, adam, cl, al = O.ddpg_train_step(
+                o_a, o_c, o_ta, o_tc, adam, (s[bi], a[bi], r[bi], t[bi], s2[bi]), gamma=0.99, tau=0.001,
+                actor_lr=1e-3, critic_lr=1e-3, last_layer_tanh=llt)
+            ref_losses.append((cl, al))
+        dev = lambda x, dt: torch.as_tensor(x, dtype=dt, device="cuda").contiguous()
+        losses = agent.train_on(dev(s, torch.float32), dev(a, torch.float32), dev(r, torch.float32), dev(t, torch.uint8),
+                                dev(s2, torch.float32), dev(idx, torch.int32), n_iters)
+        torch.cuda.synchronize()
+        assert agent._adam_t.cpu().tolist() == [n_iters, n_iters]
+        got_l = losses.cpu().numpy()
+        assert np.allclose(got_l, np.asarray(ref_losses), rtol=2e-4, atol=1e-6), (got_l, ref_losses)
+        tol = 5e-6     # 6 Adam steps of size ~1e-3 each; fp32 kernel vs fp64 oracle
+        assert np.max(np.abs(agent.actor_flat.cpu().numpy() - O.flatten_params(o_a))) <= tol
+        assert np.max(np.abs(agent.critic_flat.cpu().numpy() - O.flatten_params(o_c))) <= tol
+        assert np.max(np.abs(agent.target_actor_flat.cpu().numpy() - O.flatten_params(o_ta))) <= tol
+        assert np.max(np.abs(agent.target_critic_flat.cpu().numpy() - O.flatten_params(o_tc))) <= tol
+        assert np.allclose(agent._adam_actor[0].cpu().numpy(), adam["m_actor"], rtol=1e-3, atol=1e-7)
+        assert np.allclose(agent._adam_critic[1].cpu().numpy(), adam["v_critic"], rtol=2e-3, atol=1e-9)
+        # the weight VIEWS used by the forward kernels see the update
+        assert np.max(np.abs(agent.weights["W2"].cpu().numpy() - o_a["W2"])) <= tol
+
+
+def test_ddpg_training_reduces_critic_loss(ssc):
+    """Functional check: repeated train iterations on one fixed data set drive the TD error down."""
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    rng = np.random.default_rng(2)
+    env = ssc.make("MountainCarContinuous-v0")
+    agent = DDPG_Baselines_agent(env, None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32, lastLayerTanh=True,
+                                 actor_lr=1e-4, critic_lr=1e-3, seed=1, training=False)
+    cap = 256
+    s = rng.uniform(-1.2, 0.6, (cap, 2)).astype(np.float32)
+    a = rng.uniform(-1, 1, (cap, 1)).astype(np.float32)
+    r = (-0.1 * a[:, 0] ** 2 + s[:, 0]).astype(np.float32)
+    t = np.ones(cap, bool)                       # terminal everywhere: target_Q = r, a pure regression problem
+    dev = lambda x, dt: torch.as_tensor(x, dtype=dt, device="cuda").contiguous()
+    idx = torch.as_tensor(np.stack([rng.permutation(cap)[:64] for _ in range(600)]).astype(np.int32), device="cuda")
+    losses = agent.train_on(dev(s, torch.float32), dev(a, torch.float32), dev(r, torch.float32), dev(t, torch.uint8),
+                            dev(s, torch.float32), idx, 600).cpu().numpy()
+    assert losses[-50:, 0].mean() < 0.2 * losses[:20, 0].mean()

@@ -143,3 +143,48 @@ def test_kde_restatement_matches_scipy():
     ucb, best = O.smart_start_ucb(np.array([0.0, 1.0, 0.5]), np.array([1.0, 1.0, 1e-6]), 1000, 0.01)
     assert best == 2 and np.isclose(ucb[0], np.sqrt(2 * np.log(1000) / (1000 * 0.01)))
     assert np.isclose(O.hyperellipsoid_volume([2.0, 3.0]), np.pi * 6)
+
+
+def test_ddpg_train_step_matches_torch_autograd():
+    """The manual backprop of oracle.ddpg_train_step against torch autograd + torch.optim-free Adam."""
+    rng = np.random.default_rng(7)
+    for llt in (True, False):
+        aw = {k: v.astype(np.float64) for k, v in actor_weights(2, 64, 32, seed=1, w3_scale=0.3).items()}
+        cw = dict(W1=rng.normal(size=(2, 64)) * 0.3, b1=rng.normal(size=64) * 0.1, W2=rng.normal(size=(65, 32)) * 0.2,
+                  b2=rng.normal(size=32) * 0.1, W3=rng.normal(size=(32, 1)) * 0.2, b3=rng.normal(size=1) * 0.1)
+        taw = {k: v + 0.01 * rng.normal(size=v.shape) for k, v in aw.items()}
+        tcw = {k: v + 0.01 * rng.normal(size=v.shape) for k, v in cw.items()}
+        B = 64
+        batch = (rng.uniform(-1, 0.5, (B, 2)), rng.uniform(-1, 1, (B, 1)), rng.normal(size=B), rng.random(B) < 0.1,
+                 rng.uniform(-1, 0.5, (B, 2)))
+        na, nc = O.flatten_params(aw).size, O.flatten_params(cw).size
+        adam = dict(m_actor=np.zeros(na), v_actor=np.zeros(na), t_actor=0, m_critic=np.zeros(nc), v_critic=np.zeros(nc), t_critic=0)
+        a2, c2, ta2, tc2, adam2, closs, aloss = O.ddpg_train_step(aw, cw, taw, tcw, adam, batch, last_layer_tanh=llt)
+
+        T = lambda d: {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in d.items()}
+        pa, pc = T(aw), T(cw)
+        s, a, r, t, s2 = (torch.tensor(np.asarray(x, np.float64)) for x in batch)
+        act_fn = torch.tanh if llt else torch.relu
+
+        def actor(p, x):
+            return torch.tanh(act_fn(torch.relu(x @ p["W1"] + p["b1"]) @ p["W2"] + p["b2"]) @ p["W3"] + p["b3"])
+
+        def critic(p, x, u):
+            h = torch.cat([torch.relu(x @ p["W1"] + p["b1"]), u], dim=1)
+            return act_fn(h @ p["W2"] + p["b2"]) @ p["W3"] + p["b3"]
+        with torch.no_grad():
+            y = r[:, None] + (1 - t[:, None]) * 0.99 * critic(T(tcw), s2, actor(T(taw), s2))
+        closs_t = ((critic(pc, s, a) - y) ** 2).mean()
+        gc = torch.autograd.grad(closs_t, [pc[k] for k in O.ACTOR_KEYS])
+        aloss_t = -critic(pc, s, actor(pa, s)).mean()
+        ga = torch.autograd.grad(aloss_t, [pa[k] for k in O.ACTOR_KEYS])
+        assert abs(closs - closs_t.item()) < 1e-12 and abs(aloss - aloss_t.item()) < 1e-12
+
+        def adam1(p, g, lr):      # first Adam step: m = (1-b1) g, v = (1-b2) g^2
+            a_ = lr * np.sqrt(1 - 0.999) / (1 - 0.9)
+            return p - a_ * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-8)
+        for i, k in enumerate(O.ACTOR_KEYS):
+            assert np.allclose(c2[k], adam1(cw[k], gc[i].numpy(), 1e-3), rtol=1e-9, atol=1e-12), k
+            assert np.allclose(a2[k], adam1(aw[k], ga[i].numpy(), 1e-4), rtol=1e-9, atol=1e-12), k
+            assert np.allclose(ta2[k], 0.999 * taw[k] + 0.001 * a2[k]) and np.allclose(tc2[k], 0.999 * tcw[k] + 0.001 * c2[k])
+        assert adam2["t_actor"] == 1 and adam2["t_critic"] == 1
