@@ -4,8 +4,9 @@
 //
 // The iterations form a serial chain through the parameters (the reference runs one per env step),
 // so ONE workgroup executes `n_iters` of them per launch: 4 waves, lane = sample, every activation and
-// every back-propagated delta of the batch lives in LDS as [unit][65] (padded: column reads of the
-// weight-gradient pass are conflict-free), weights stream from L2 as wave-uniform loads.  fp32, plain
+// every back-propagated delta of the batch lives in LDS as [unit][68]; in the dense passes a lane owns a
+// unit (its weights arrive as one coalesced load per input row), a wave owns 16 samples whose
+// activations are broadcast float4 LDS reads.  fp32, plain
 // FMA chains in k order; the Adam moments, step counters and target networks are updated in place.
 #include "ssc_device.h"
 #include "ssc_host.h"
@@ -13,7 +14,8 @@
 namespace ssc {
 
 constexpr int kB = 64;       // batch size = lanes of a wave
-constexpr int kP = kB + 1;   // padded LDS row
+constexpr int kP = kB + 4;   // padded LDS row: 16-B aligned rows (float4 access over 4 samples); a stride of
+                             // 68 dwords keeps both ds_read_b128 column gathers and ds_write_b128 conflict-free
 constexpr int kTrainThreads = 256;
 
 struct NetDims {
@@ -30,27 +32,64 @@ struct NetDims {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 
-// Z[j][b] = act(bias[j] + sum_i W[i][j] X[i][b]);  wave w handles units j = w, w+4, ...
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int kSPW = kB / (kTrainThreads / 64);   // samples per wave = 16
+
+// Z[j][b] = act(bias[j] + sum_i W[i][j] X[i][b]).  Lane = output unit j (W[i][j] is one coalesced load
+// per input row i), wave w = samples [16w, 16w+16) (X rows are broadcast float4 reads).
 __device__ __forceinline__ void dense_fwd(const float *__restrict__ W, const float *__restrict__ bias, int in, int out,
                                           const float *X, float *Z, int act) {
-    const int wave = threadIdx.x >> 6, b = threadIdx.x & 63;
-    for (int j = wave; j < out; j += kTrainThreads / 64) {
-        float acc = bias[j];
-        for (int i = 0; i < in; ++i) acc = fmaf(W[i * out + j], X[i * kP + b], acc);
-        if (act == ACT_RELU) acc = fmaxf(acc, 0.0f);
-        else if (act == ACT_TANH) acc = tanhf(acc);
-        Z[j * kP + b] = acc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, b0 = wave * kSPW;
+    for (int j0 = 0; j0 < out; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < out;
+        const int jc = valid ? j : out - 1;
+        f4 acc[kSPW / 4];
+        const float bj = bias[jc];
+#pragma unroll
+        for (int q = 0; q < kSPW / 4; ++q) acc[q] = (f4)(bj);
+#pragma unroll 4
+        for (int i = 0; i < in; ++i) {
+            const float w = W[i * out + jc];
+#pragma unroll
+            for (int q = 0; q < kSPW / 4; ++q) acc[q] += w * *reinterpret_cast<const f4 *>(X + i * kP + b0 + 4 * q);
+        }
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < kSPW / 4; ++q) {
+                f4 v = acc[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (act == ACT_RELU) v[e] = fmaxf(v[e], 0.0f);
+                    else if (act == ACT_TANH) v[e] = tanhf(v[e]);
+                }
+                *reinterpret_cast<f4 *>(Z + j * kP + b0 + 4 * q) = v;
+            }
+        }
     }
 }
 
-// dX[i][b] = sum_j W[i][j] dZ[j][b]   for rows i in [i0, i1)
+// dX[i - i0][b] = sum_j W[i][j] dZ[j][b] for input rows i in [i0, i1).  Lane = input row.
 __device__ __forceinline__ void dense_bwd_in(const float *__restrict__ W, int out, int i0, int i1, const float *dZ,
                                              float *dX) {
-    const int wave = threadIdx.x >> 6, b = threadIdx.x & 63;
-    for (int i = i0 + wave; i < i1; i += kTrainThreads / 64) {
-        float acc = 0.0f;
-        for (int j = 0; j < out; ++j) acc = fmaf(W[i * out + j], dZ[j * kP + b], acc);
-        dX[(i - i0) * kP + b] = acc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, b0 = wave * kSPW;
+    for (int r0 = i0; r0 < i1; r0 += 64) {
+        const int i = r0 + lane;
+        const bool valid = i < i1;
+        const int ic = valid ? i : i1 - 1;
+        f4 acc[kSPW / 4];
+#pragma unroll
+        for (int q = 0; q < kSPW / 4; ++q) acc[q] = (f4)(0.0f);
+#pragma unroll 4
+        for (int j = 0; j < out; ++j) {
+            const float w = W[ic * out + j];
+#pragma unroll
+            for (int q = 0; q < kSPW / 4; ++q) acc[q] += w * *reinterpret_cast<const f4 *>(dZ + j * kP + b0 + 4 * q);
+        }
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < kSPW / 4; ++q) *reinterpret_cast<f4 *>(dX + (i - i0) * kP + b0 + 4 * q) = acc[q];
+        }
     }
 }
 
@@ -72,14 +111,16 @@ __device__ __forceinline__ void weight_grad_adam(const float *X, const float *dZ
                                                  float *m, float *v, int offW, int offb, const AdamCfg &c) {
     for (int idx = threadIdx.x; idx < in * out; idx += kTrainThreads) {
         const int i = idx / out, j = idx - i * out;
-        float g = 0.0f;
-        for (int b = 0; b < kB; ++b) g = fmaf(X[i * kP + b], dZ[j * kP + b], g);
-        adam_apply(theta, m, v, offW + idx, g, c);
+        f4 g4 = (f4)(0.0f);
+#pragma unroll 4
+        for (int q = 0; q < kB / 4; ++q)
+            g4 += *reinterpret_cast<const f4 *>(X + i * kP + 4 * q) * *reinterpret_cast<const f4 *>(dZ + j * kP + 4 * q);
+        adam_apply(theta, m, v, offW + idx, (g4[0] + g4[1]) + (g4[2] + g4[3]), c);
     }
     for (int j = threadIdx.x; j < out; j += kTrainThreads) {
-        float g = 0.0f;
-        for (int b = 0; b < kB; ++b) g += dZ[j * kP + b];
-        adam_apply(theta, m, v, offb + j, g, c);
+        f4 g4 = (f4)(0.0f);
+        for (int q = 0; q < kB / 4; ++q) g4 += *reinterpret_cast<const f4 *>(dZ + j * kP + 4 * q);
+        adam_apply(theta, m, v, offb + j, (g4[0] + g4[1]) + (g4[2] + g4[3]), c);
     }
 }
 
@@ -92,7 +133,7 @@ struct TrainArgs {
 };
 
 __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const ssc_ddpg_desc &d = g.d;
     const NetDims A{d.obs_dim, d.actor_h1, d.actor_h2, d.act_dim, 0};
     const NetDims C{d.obs_dim, d.critic_h1, d.critic_h2, 1, d.act_dim};
