@@ -2,9 +2,12 @@
 (smartstart/reinforcementLearningCore/rlTrain.py:13-133) for any ``gym.Env``-shaped env and any
 ``RLAgent``, plus ``rl_train_vec`` -- the same loop over N device envs in fused chunks.
 ``Episode`` / ``Summary`` keep the per-episode quantities of smartstart/utilities/datacontainers.py
-(:41-49, :61-80, :173-193); the JSON/GCS persistence of the reference is out of scope."""
+(:41-49, :61-80, :173-193) and read/write the reference's Summary JSON files (:257-374)."""
 from __future__ import annotations
 
+import json
+import os
+import sys
 import time
 
 import numpy as np
@@ -37,41 +40,112 @@ class Episode:
 
 
 class Summary:
-    """datacontainers.py:85-193: per-episode (steps, total_reward), best path, last ``last_x`` paths."""
+    """smartstart/utilities/datacontainers.py:130-374: per-episode (steps, total_reward), best path, the
+    last ``last_x`` paths, SmartStart episode indices and the agent's hyper-parameters -- with the
+    reference's attribute names, so that ``to_json`` / ``save`` / ``load`` read and write the same JSON
+    files as the reference (``data/**/*.json``); the GCS upload is out of scope."""
 
     def __init__(self, name=None, last_x=5):
         self.name = name
         self.episodes = []
-        self.best_path, self.best_reward = None, None
-        self.last_x, self.last_paths, self.last_rewards = last_x, [], []
+        self.best_path = None
+        self.best_reward = -sys.maxsize                      # :163
+        self.last_x = max(last_x, 1)
+        self.last_paths = [[None]] * last_x                  # :167 (oldest first)
+        self.last_rewards = [None] * last_x
         self.smart_start_episodes = []
-        self.agent = None
+        self.name_of_agent = ""
+        self.param_dict = {}
 
     def set_agent(self, agent):
-        self.agent = agent
+        """:173-176"""
+        self.name_of_agent = str(agent.__class__.__name__)
+        try:
+            pd = agent.get_param_dict()
+        except NotImplementedError:
+            pd = None
+        if pd is not None:
+            self.param_dict = {**pd, **self.param_dict}
+
+    def add_params_to_param_dict(self, **kwargs):
+        self.param_dict = {**kwargs, **self.param_dict}
 
     def start_smart_start_episode(self):
         self.smart_start_episodes.append(len(self.episodes))
 
     def append(self, episode):
+        """:180-203"""
         total = episode.total_reward()
         self.episodes.append((len(episode), total))
-        if self.best_reward is None or total > self.best_reward:
-            self.best_reward, self.best_path = total, episode.path()
-        self.last_paths.append(episode.path())
-        self.last_rewards.append(total)
-        if len(self.last_paths) > self.last_x:
-            self.last_paths.pop(0)
-            self.last_rewards.pop(0)
+        if total > self.best_reward:
+            self.best_path, self.best_reward = episode.path(), total
+        self.last_paths = self.last_paths[1:] + [episode.path()]
+        self.last_rewards = self.last_rewards[1:] + [total]
 
     def append_record(self, length, total_reward):
         """A finished episode reported by the fused rollout kernel's episode ring (no path)."""
         self.episodes.append((int(length), float(total_reward)))
-        if self.best_reward is None or total_reward > self.best_reward:
+        if total_reward > self.best_reward:
             self.best_reward = float(total_reward)
+
+    # ---- accessors (:205-255) ---------------------------------------------------------------------
+    def total_episode_reward(self):
+        return [reward for _, reward in self.episodes]
+
+    def total_reward(self):
+        return sum(self.total_episode_reward())
+
+    def average_reward(self):
+        return self.total_reward() / len(self)
+
+    def average_episode_reward(self):
+        return [reward / steps for steps, reward in self.episodes]
+
+    def steps_episode(self):
+        return [steps for steps, _ in self.episodes]
+
+    def get_best_path_and_reward(self):
+        return self.best_path, self.best_reward
+
+    def get_last_path(self, x):
+        return self.last_paths[-(x + 1)]
+
+    def get_last_reward(self, x):
+        return self.last_rewards[-(x + 1)]
 
     def __len__(self):
         return len(self.episodes)
+
+    # ---- persistence (:257-374) ---------------------------------------------------------------------
+    def to_json(self):
+        def plain(o):
+            return o.tolist() if isinstance(o, np.ndarray) else float(o) if isinstance(o, np.floating) else \
+                int(o) if isinstance(o, np.integer) else str(o)
+        return json.dumps(self.__dict__, default=plain)
+
+    @classmethod
+    def from_json(cls, data):
+        summary = cls()
+        summary.__dict__.update(json.loads(data))
+        return summary
+
+    def save(self, directory=".", post_fix=0, extra_name_append="", last_name_section=False):
+        """:288-326: <name><extra>_<post_fix>.json, post_fix auto-incremented past existing files."""
+        def make_name(pf):
+            name = self.name.split("_")[-1] if last_name_section else self.name
+            return os.path.join(directory, name + extra_name_append + "_" + str(pf) + ".json")
+        fp = make_name(post_fix)
+        while os.path.exists(fp):
+            post_fix += 1
+            fp = make_name(post_fix)
+        with open(fp, "x") as f:
+            f.write(self.to_json())
+        return fp
+
+    @classmethod
+    def load(cls, fp):
+        with open(fp, "r") as f:
+            return cls.from_json(f.read())
 
 
 def rlTrain(agent, env, render=False, render_episode=False, print_results=True, print_steps=True,

@@ -219,6 +219,20 @@ def replay_buffer_kats():
     print("replay kats ok")
 
 
+def summary_json_fixture():
+    """One of the reference's own Summary dumps (data/**/*.json, written by Summary.save,
+    smartstart/utilities/datacontainers.py:288-326), trimmed to its first 60 episode records so that the
+    fixture stays small.  Pins the on-disk schema for Summary.load / to_json."""
+    f = sorted(glob.glob(os.path.join(
+        REF, "data/smart_start_continuous_summaries/ddpg_baselines/hyper_parameter_search/*.json")))[0]
+    d = json.load(open(f))
+    d["episodes"] = d["episodes"][:60]
+    d["smart_start_episodes"] = [e for e in d["smart_start_episodes"] if e < 60]
+    with open(os.path.join(OUT, "reference_summary.json"), "w") as fh:
+        json.dump(d, fh)
+    print("summary fixture:", os.path.relpath(f, REF), sorted(d.keys()))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not found at %s" % REF)
@@ -226,3 +240,4 @@ if __name__ == "__main__":
     summaries()
     numerical_kats()
     replay_buffer_kats()
+    summary_json_fixture()

@@ -140,3 +140,34 @@ def test_oracle_and_product_helpers_agree():
     radii = N.radii_calc(means, stds, 1, 1, 1)
     assert np.array_equal(N.path_shortcutter(path, N.elliptical_euclidean_distance_function_generator(radii), 1),
                           O.path_shortcutter(path, O.distance_func(radii), 1))
+
+
+def test_summary_reads_and_writes_the_reference_json_schema(golden_dir, tmp_path):
+    """Summary.load on one of the reference's own dumps (tests/golden/reference_summary.json), and the
+    files we write have exactly the same keys (datacontainers.py:257-374)."""
+    import json
+    import sys
+    from smartstartcontinuous_amd.rl_train import Episode, Summary
+    ref = Summary.load(f"{golden_dir}/reference_summary.json")
+    raw = json.load(open(f"{golden_dir}/reference_summary.json"))
+    assert ref.name.startswith("SmartStartC_DDPG_Baselines_agent_MountainCarContinuous-v0")
+    assert len(ref) == 60 and ref.steps_episode()[0] == raw["episodes"][0][0]
+    assert ref.get_best_path_and_reward()[1] == raw["best_reward"] and len(ref.last_paths) == raw["last_x"] == 5
+    assert ref.param_dict["n_ss"] == 2000 and ref.name_of_agent == "SmartStartContinuous"
+    assert abs(ref.total_reward() - sum(r for _, r in raw["episodes"])) < 1e-9
+    # our own summaries: same schema, save() auto-increments the postfix like the reference
+    s = Summary("Agent_Env-v0")
+    assert json.loads(s.to_json())["best_reward"] == -sys.maxsize
+    for k in range(7):
+        ep = Episode()
+        for t in range(3 + k):
+            ep.append(np.array([t, 0.0]), np.array([0.5]), -1.0 + k, np.array([t + 1, 0.0]), t == 2 + k)
+        s.append(ep)
+    s.start_smart_start_episode()
+    f0 = s.save(str(tmp_path))
+    f1 = s.save(str(tmp_path))
+    assert f0.endswith("Agent_Env-v0_0.json") and f1.endswith("Agent_Env-v0_1.json")
+    back = Summary.load(f0)
+    assert set(json.load(open(f0)).keys()) == set(raw.keys())
+    assert [tuple(e) for e in back.episodes] == s.episodes and back.best_reward == s.best_reward == (3 + 6) * 5.0
+    assert len(back.last_paths) == 5 and len(back.best_path) == 3 + 6 + 1 and back.smart_start_episodes == [7]
