@@ -331,6 +331,31 @@ typedef struct ssc_replay_view {
 int ssc_ddpg_train(const ssc_ddpg_desc *ddpg, const ssc_replay_view *replay, const int32_t *d_batch_idx,
                    int32_t n_iters, float *d_losses, ssc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Dynamics-model training step
+ * ------------------------------------------------------------------------------------- */
+
+/* One iteration of Dyn_Model.train's inner loop (NN_Dynamics_Model/dynamics_model.py:98-101 /
+ * :111-113): mse = mean((z - net(x))^2) over the batch (:41), tf.train.AdamOptimizer(lr) step
+ * (:44-50) [third-party TF 1.5: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * theta -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + 1e-8)].  The batch is rows d_idx[0..B) of the
+ * (already normalised) device data sets d_X [n][in], d_Z [n][out] -- the old/new mixing of :60-96 is
+ * index arithmetic done by the caller.  Weights and Adam moments are updated in place. */
+typedef struct ssc_mlp_train_desc {
+    int32_t n_layers;
+    int32_t dims[SSC_MAX_LAYERS + 1];
+    float *W[SSC_MAX_LAYERS], *b[SSC_MAX_LAYERS];      /* device, updated in place */
+    float *mW[SSC_MAX_LAYERS], *vW[SSC_MAX_LAYERS];    /* device Adam moments, zero-initialised */
+    float *mb[SSC_MAX_LAYERS], *vb[SSC_MAX_LAYERS];
+    int32_t *adam_t;                                    /* device [1] step counter */
+    float lr, beta1, beta2, epsilon;
+} ssc_mlp_train_desc;
+
+size_t ssc_mlp_train_workspace_bytes(const ssc_mlp_train_desc *net, int32_t batch);
+/* d_loss [1] receives the batch MSE (before the update); may be NULL. */
+int ssc_mlp_train_step(const ssc_mlp_train_desc *net, const float *d_X, const float *d_Z, const int32_t *d_idx,
+                       int32_t batch, float *d_loss, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,14 @@ class CriticDesc(Structure):
                 ("W3", c_void_p), ("b3", c_void_p), ("last_layer_tanh", c_int32)]
 
 
+class MlpTrainDesc(Structure):
+    _fields_ = [("n_layers", c_int32), ("dims", c_int32 * (SSC_MAX_LAYERS + 1)),
+                ("W", c_void_p * SSC_MAX_LAYERS), ("b", c_void_p * SSC_MAX_LAYERS),
+                ("mW", c_void_p * SSC_MAX_LAYERS), ("vW", c_void_p * SSC_MAX_LAYERS),
+                ("mb", c_void_p * SSC_MAX_LAYERS), ("vb", c_void_p * SSC_MAX_LAYERS),
+                ("adam_t", c_void_p), ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("epsilon", c_float)]
+
+
 class DdpgDesc(Structure):
     _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("actor_h1", c_int32), ("actor_h2", c_int32),
                 ("critic_h1", c_int32), ("critic_h2", c_int32), ("last_layer_tanh", c_int32), ("batch_size", c_int32),
@@ -131,6 +139,9 @@ _SIGNATURES = {
     "ssc_ucb_argmax": (c_int, [c_int64, c_void_p, c_void_p, c_float, c_float, c_double, c_double, c_void_p, c_void_p,
                                c_void_p]),
     "ssc_ddpg_train": (c_int, [POINTER(DdpgDesc), POINTER(ReplayView), c_void_p, c_int32, c_void_p, c_void_p]),
+    "ssc_mlp_train_workspace_bytes": (c_size_t, [POINTER(MlpTrainDesc), c_int32]),
+    "ssc_mlp_train_step": (c_int, [POINTER(MlpTrainDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                   c_size_t, c_void_p]),
     "ssc_mlp_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),
     "ssc_mlp_forward": (c_int, [POINTER(MlpDesc), c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "ssc_dyn_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),

@@ -380,10 +380,18 @@ class NND_MB_agent(NavigationRLAgent):
         self.seed, self._t = int(seed), 0
         state_dim = env.observation_space.shape[0]
         act_dim = env.action_space.shape[0]
+        self._train_inputs = self._train_outputs = None
         if norm is None:
             if training_data is None:
                 raise ValueError("NND_MB_agent needs `training_data` (dataX, dataY, dataZ) or `norm` statistics")
             norm = self.normalisation_from_data(training_data["dataX"], training_data["dataY"], training_data["dataZ"])
+        if training_data is not None:
+            # z-scored (x, y) -> z training set (NND_MB_agent.py:302-319)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                nz = lambda v, m, s: np.nan_to_num((np.asarray(v, np.float64) - m) / s)
+                self._train_inputs = np.concatenate([nz(training_data["dataX"], norm["mean_x"], norm["std_x"]),
+                                                     nz(training_data["dataY"], norm["mean_y"], norm["std_y"])], axis=1)
+                self._train_outputs = nz(training_data["dataZ"], norm["mean_z"], norm["std_z"])
         if weights is None:
             gen = torch.Generator().manual_seed(self.seed)
             weights, biases = init_dynamics_weights(state_dim + act_dim, state_dim, num_fc_layers, depth_fc_layers, gen)
@@ -488,5 +496,15 @@ class NND_MB_agent(NavigationRLAgent):
     def get_param_dict(self):
         return self.param_dict
 
-    def train_dynamics_model(self):
-        raise NotImplementedError("dynamics-model training is outside the accelerated path (SURVEY.md 8f)")
+    def train_dynamics_model(self, dataX_new=None, dataZ_new=None, nEpoch=30, fraction_use_new=0.9, batchsize=512,
+                             lr=0.001):
+        """NND_MB_agent.train_dynamics_model (:437-480) without the noise injection / TF saver: trains the
+        model on the stored (normalised) initial data set mixed with the aggregated ``*_new`` rows through
+        ``Dyn_Model.train``'s batching (DynamicsModel.train -> ssc_mlp_train_step)."""
+        if self._train_inputs is None:
+            raise RuntimeError("NND_MB_agent was built without training_data")
+        in_dim, out_dim = self.dyn_model.in_dim, self.dyn_model.out_dim
+        xn = np.zeros((0, in_dim)) if dataX_new is None else np.asarray(dataX_new)
+        zn = np.zeros((0, out_dim)) if dataZ_new is None else np.asarray(dataZ_new)
+        return self.dyn_model.train(self._train_inputs, self._train_outputs, xn, zn, nEpoch, fraction_use_new,
+                                    batchsize=batchsize, lr=lr)

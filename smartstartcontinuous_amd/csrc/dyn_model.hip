@@ -140,6 +140,13 @@ static int max_width(const ssc_mlp_desc *mlp) {
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+void launch_mlp_layer_f32(bool relu, int64_t m, int K, int N, const float *X, const float *W, const float *b, float *Y,
+                          hipStream_t s) {
+    const unsigned grid = (unsigned)((m + kRows - 1) / kRows);
+    if (relu) hipLaunchKernelGGL(mlp_layer_f32_kernel<true>, dim3(grid), dim3(256), 0, s, m, K, N, X, W, b, Y);
+    else hipLaunchKernelGGL(mlp_layer_f32_kernel<false>, dim3(grid), dim3(256), 0, s, m, K, N, X, W, b, Y);
+}
+
 // fp32 path: y = net(x); act buffers a0/a1 of m*maxw floats each.
 int mlp_forward_f32(const ssc_mlp_desc *mlp, int64_t m, const float *x, float *y, float *a0, float *a1,
                     hipStream_t s) {

@@ -71,6 +71,68 @@ class DynamicsModel:
                 arr[i] = float(v[i])
         self.norm = nm
 
+    # ---- training (Dyn_Model.train, dynamics_model.py:52-171) ----------------------------------------
+    def _train_desc(self, lr):
+        if not hasattr(self, "_adam"):
+            z = lambda t: torch.zeros_like(t)
+            self._adam = dict(mW=[z(w) for w in self.W], vW=[z(w) for w in self.W], mb=[z(b) for b in self.b],
+                              vb=[z(b) for b in self.b], t=torch.zeros(1, dtype=torch.int32, device=self.device))
+        d = _ffi.MlpTrainDesc()
+        d.n_layers = len(self.W)
+        for l in range(len(self.W) + 1):
+            d.dims[l] = self.desc.dims[l]
+        for l in range(len(self.W)):
+            d.W[l], d.b[l] = self.W[l].data_ptr(), self.b[l].data_ptr()
+            d.mW[l], d.vW[l] = self._adam["mW"][l].data_ptr(), self._adam["vW"][l].data_ptr()
+            d.mb[l], d.vb[l] = self._adam["mb"][l].data_ptr(), self._adam["vb"][l].data_ptr()
+        d.adam_t = self._adam["t"].data_ptr()
+        d.lr, d.beta1, d.beta2, d.epsilon = float(lr), 0.9, 0.999, 1e-8   # tf.train.AdamOptimizer defaults
+        return d
+
+    def train_step(self, X, Z, idx, lr=0.001, loss=None):
+        """One Adam step on rows ``idx`` of the device data sets X [n, in], Z [n, out] (fp32, already
+        normalised).  ``loss`` (a 1-element fp32 tensor) receives the batch MSE if given."""
+        d = self._train_desc(lr)
+        B = idx.numel()
+        with torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.ssc_mlp_train_workspace_bytes(ctypes.byref(d), B))
+            _ffi.check(self.lib.ssc_mlp_train_step(ctypes.byref(d), _ffi.ptr(X), _ffi.ptr(Z), _ffi.ptr(idx), B,
+                                                   _ffi.ptr(loss), _ffi.ptr(ws), ws.numel(), _stream()))
+
+    def train(self, dataX, dataZ, dataX_new, dataZ_new, nEpoch, fraction_use_new, batchsize=512, lr=0.001,
+              rng=None):
+        """``Dyn_Model.train`` (dynamics_model.py:52-171): every batch mixes ``batchsize*fraction_use_new``
+        rows of the new (aggregated) data with a walk through the shuffled old data.  The data sets are
+        uploaded once; only index vectors travel per iteration.  Returns the mean training loss of the
+        last epoch, like the reference's first return value."""
+        rng = rng if rng is not None else np.random
+        f = lambda a, cols: torch.as_tensor(np.asarray(a, np.float32).reshape(-1, cols), device=self.device)
+        n_old, n_new = len(dataX), len(dataX_new)
+        X = torch.cat([f(dataX, self.in_dim), f(dataX_new, self.in_dim)])
+        Z = torch.cat([f(dataZ, self.out_dim), f(dataZ_new, self.out_dim)])
+        b_new = n_new if n_new < batchsize * fraction_use_new else int(batchsize * fraction_use_new)   # :60-67
+        b_old = int(batchsize - b_new)
+        perm_new = np.arange(n_new)
+        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        last = 0.0
+        for _ in range(nEpoch):
+            losses = []
+            old = rng.choice(np.arange(n_old), size=(n_old,), replace=False)                          # :78
+            if b_old > 0:
+                batches = []
+                for batch in range(int(np.floor(n_old / b_old))):                                     # :82
+                    new_idx = rng.randint(0, n_new, (b_new,)) if n_new > 0 else np.zeros(0, np.int64)   # :88
+                    batches.append(np.concatenate([old[batch * b_old:(batch + 1) * b_old], n_old + perm_new[new_idx]]))
+            else:
+                batches = [n_old + perm_new[b * b_new:(b + 1) * b_new] for b in range(int(np.floor(n_new / b_new)))]
+                perm_new = perm_new[rng.permutation(n_new)]                                           # :120-122
+            for bi in batches:
+                idx = torch.as_tensor(bi.astype(np.int32), device=self.device)
+                self.train_step(X, Z, idx, lr=lr, loss=loss)
+                losses.append(loss.clone())
+            last = float(torch.stack(losses).mean().item()) if losses else 0.0
+        return last
+
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)

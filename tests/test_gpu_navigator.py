@@ -244,3 +244,54 @@ def test_forward_sim_mfma(nav, dims, H):
     # fp32 and MFMA paths agree on the same inputs
     Sf = model.do_forward_sim(s0, A, precision="f32").cpu().numpy()
     assert np.max(np.abs(Sf - S)) <= 3e-2 * np.maximum(1.0, np.abs(Sf).max())
+
+
+@pytest.mark.parametrize("dims,B", [((3, 32, 2), 512), ((4, 500, 500, 3), 512), ((3, 40, 24, 16, 2), 77)])
+def test_mlp_train_step_kernel_vs_oracle(nav, dims, B):
+    """ssc_mlp_train_step (forward, MSE, backprop, tf-style Adam) for several steps against the fp64 oracle."""
+    rng = np.random.default_rng(sum(dims))
+    Ws, bs = make_mlp(rng, dims)
+    d, a = dims[-1], dims[0] - dims[-1]
+    model = nav.DynamicsModel(Ws, bs, make_norm(rng, d, max(a, 1)), state_dim=d, act_dim=max(a, 1))
+    n = 2000
+    X = rng.normal(size=(n, dims[0])).astype(np.float32)
+    Z = (rng.normal(size=(n, dims[-1])) * 0.5).astype(np.float32)
+    Xd, Zd = torch.as_tensor(X, device="cuda"), torch.as_tensor(Z, device="cuda")
+    oW, ob = [w.astype(np.float64) for w in Ws], [b.astype(np.float64) for b in bs]
+    adam = dict(mW=[np.zeros_like(w) for w in oW], vW=[np.zeros_like(w) for w in oW],
+                mb=[np.zeros_like(b) for b in ob], vb=[np.zeros_like(b) for b in ob], t=0)
+    loss = torch.zeros(1, device="cuda")
+    for step in range(4):
+        idx = rng.permutation(n)[:B].astype(np.int32)
+        oW, ob, adam, ref_loss = O.mlp_train_step(oW, ob, adam, X[idx], Z[idx], lr=1e-3)
+        model.train_step(Xd, Zd, torch.as_tensor(idx, device="cuda"), lr=1e-3, loss=loss)
+        assert abs(loss.item() - ref_loss) <= 2e-4 * max(1.0, ref_loss), (step, loss.item(), ref_loss)
+    for l in range(len(oW)):
+        # 4 Adam steps of ~1e-3: parameters agree to a small fraction of one step
+        assert np.max(np.abs(model.W[l].cpu().numpy() - oW[l])) <= 2e-5, l
+        assert np.max(np.abs(model.b[l].cpu().numpy() - ob[l])) <= 2e-5, l
+    assert int(model._adam["t"].item()) == 4
+
+
+def test_dynamics_model_training_learns_mountaincar(nav, golden_dir):
+    """Semantic check: a 1x32 model trained on the reference's dataX/Y/Z reaches a low one-step
+    error on the reference's held-out validation rollouts (states_val / controls_val)."""
+    import smartstartcontinuous_amd as ssc
+    from smartstartcontinuous_amd.agents import NND_MB_agent
+    g = np.load(f"{golden_dir}/mc_reference_rollouts.npz")
+    env = ssc.make("MountainCarContinuous-v0")
+    agent = NND_MB_agent(env, None, horizon=4, num_control_samples=100, num_fc_layers=1, depth_fc_layers=32,
+                         training_data=dict(dataX=g["dataX"], dataY=g["dataY"], dataZ=g["dataZ"]), precision="f32", seed=3)
+    S, A = g["states_val"], g["controls_val"]
+    s0 = S[:, :-1].reshape(-1, 2).astype(np.float32)
+    act = A[:, :-1].reshape(-1, 1, 1).astype(np.float32)
+    true_next = S[:, 1:].reshape(-1, 2)
+
+    def one_step_err():
+        pred = agent.dyn_model.do_forward_sim(torch.as_tensor(s0, device="cuda"), torch.as_tensor(act, device="cuda"))
+        return np.abs(pred[1].cpu().numpy() - true_next).mean(axis=0) / np.abs(true_next - s0).mean(axis=0)
+    before = one_step_err()
+    np.random.seed(0)
+    last_loss = agent.train_dynamics_model(nEpoch=12, fraction_use_new=0.0, batchsize=512, lr=0.001)
+    after = one_step_err()
+    assert last_loss < 0.05 and (after < 0.35).all() and (after < 0.3 * before).all(), (before, after, last_loss)

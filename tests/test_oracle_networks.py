@@ -188,3 +188,40 @@ def test_ddpg_train_step_matches_torch_autograd():
             assert np.allclose(a2[k], adam1(aw[k], ga[i].numpy(), 1e-4), rtol=1e-9, atol=1e-12), k
             assert np.allclose(ta2[k], 0.999 * taw[k] + 0.001 * a2[k]) and np.allclose(tc2[k], 0.999 * tcw[k] + 0.001 * c2[k])
         assert adam2["t_actor"] == 1 and adam2["t_critic"] == 1
+
+
+def test_mlp_train_step_matches_torch_autograd_and_adam():
+    """oracle.mlp_train_step (manual backprop + tf-style Adam) against torch autograd + torch.optim.Adam
+    (same update rule as tf.train.AdamOptimizer up to where epsilon enters -- compared after ONE step where
+    both reduce to -lr * sign-like update, and gradients compared exactly)."""
+    rng = np.random.default_rng(3)
+    dims = (3, 32, 16, 2)
+    Ws = [rng.normal(size=(dims[i], dims[i + 1])) * 0.3 for i in range(3)]
+    bs = [rng.normal(size=dims[i + 1]) * 0.1 for i in range(3)]
+    x, z = rng.normal(size=(50, 3)), rng.normal(size=(50, 2))
+    zero = lambda: dict(mW=[np.zeros_like(w) for w in Ws], vW=[np.zeros_like(w) for w in Ws],
+                        mb=[np.zeros_like(b) for b in bs], vb=[np.zeros_like(b) for b in bs], t=0)
+    nW, nb, adam, loss = O.mlp_train_step(Ws, bs, zero(), x, z, lr=1e-3)
+    tW = [torch.tensor(w, requires_grad=True) for w in Ws]
+    tb = [torch.tensor(b, requires_grad=True) for b in bs]
+    h = torch.tensor(x)
+    for l in range(3):
+        h = h @ tW[l] + tb[l]
+        if l < 2:
+            h = torch.relu(h)
+    tl = ((torch.tensor(z) - h) ** 2).mean()
+    tl.backward()
+    assert abs(loss - tl.item()) < 1e-12
+    for l in range(3):
+        assert np.allclose(adam["mW"][l], 0.1 * tW[l].grad.numpy(), atol=1e-14)       # m = (1-b1) g
+        assert np.allclose(adam["vb"][l], 0.001 * tb[l].grad.numpy() ** 2, atol=1e-16)
+        g = tW[l].grad.numpy()
+        lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+        assert np.allclose(nW[l], Ws[l] - lr_t * 0.1 * g / (np.sqrt(0.001 * g * g) + 1e-8), atol=1e-14)
+    # batch composition: every old row is visited once per epoch, new rows are drawn with replacement
+    batches = list(O.dyn_train_batches(1000, 300, 512, 0.9, 2, np.random.RandomState(0)))
+    assert len(batches) == 2 * (1000 // (512 - 300)) and all(len(o) == 212 and len(n) == 300 for o, n in batches)
+    per_epoch = np.concatenate([o for o, _ in batches[:4]])
+    assert len(set(per_epoch.tolist())) == len(per_epoch)
+    only_new = list(O.dyn_train_batches(10, 2000, 512, 1.0, 1, np.random.RandomState(0)))
+    assert len(only_new) == 2000 // 512 and all(len(o) == 0 and len(n) == 512 for o, n in only_new)
