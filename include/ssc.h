@@ -254,6 +254,16 @@ size_t ssc_mpc_score_workspace_bytes(int32_t n_problems, int32_t n_samples, int3
 int ssc_mpc_score(const ssc_mpc_problems *prob, const float *d_S, float *d_scores, int32_t *d_best_idx,
                   float *d_best_score, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream);
 
+/* NND_MB_agent.observe (NND_MB_agent.py:360-373) + close_enough_to_goal (:425-432) for P navigators at
+ * once: given the state each env reached, advance its waypoint index when the waypoint was reached /
+ * overtaken (move_to_next, :491-496) or given up on (d_actions_done > give_up_after), and flag envs that
+ * are within theta of their final waypoint (or timed out on it after final_steps actions).
+ * d_cur_idx [P] and d_actions_done [P] are updated in place; d_at_goal [P] (u8) may be NULL.
+ * d_new_state is [P][state_dim].  (get_action's `actions_done += 1`, :340, is the caller's.) */
+int ssc_mpc_observe(const ssc_mpc_problems *prob, const float *d_new_state, int32_t *d_cur_idx,
+                    int32_t *d_actions_done, int32_t give_up_after, int32_t final_steps, uint8_t *d_at_goal,
+                    ssc_stream_t stream);
+
 /* get_action_with_predicted_states (NND_MB_agent.py:339-358): action[p] = A[best][0] +
  * noise_amount * N(0,1) (no clip, :353-356); also copies the predicted path
  * S[:, best] -> d_best_path [P][H+1][state_dim] (may be NULL). */

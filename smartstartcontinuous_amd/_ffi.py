@@ -152,6 +152,7 @@ _SIGNATURES = {
     "ssc_mpc_score_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "ssc_mpc_score": (c_int, [POINTER(MpcProblems), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                               c_void_p]),
+    "ssc_mpc_observe": (c_int, [POINTER(MpcProblems), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "ssc_mpc_select_action": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                       c_float, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
 }

@@ -262,6 +262,37 @@ __global__ __launch_bounds__(64) void mpc_select_kernel(int P, int N, int H, int
                 best_path[((int64_t)p * (H + 1) + tt) * d + k] = S[((int64_t)tt * P * N + row) * d + k];
 }
 
+// NND_MB_agent.observe (:360-373) and close_enough_to_goal (:425-432), one thread per navigator
+__global__ __launch_bounds__(64) void mpc_observe_kernel(MpcArgs a, const float *__restrict__ ns, int32_t *cur_idx,
+                                                         int32_t *actions_done, int give_up, int final_steps,
+                                                         uint8_t *at_goal) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= a.P) return;
+    const int off = a.wp_off[p], W = a.wp_off[p + 1] - off, d = a.d;
+    float inv_r[SSC_MAX_STATE], x[SSC_MAX_STATE];
+#pragma unroll
+    for (int k = 0; k < SSC_MAX_STATE; ++k) {
+        inv_r[k] = (k < d) ? 1.0f / a.radii[p * d + k] : 0.0f;
+        x[k] = (k < d) ? ns[p * d + k] : 0.0f;
+    }
+    int idx = cur_idx[p];
+    int done_act = actions_done[p];
+    const float *wp = a.wp + (int64_t)off * d;
+    const float dc = ell_dist(x, wp + idx * d, inv_r, d);                        // :364
+    const float dn = ell_dist(x, wp + min(idx + 1, W - 1) * d, inv_r, d);        // :365
+    const bool move = (dc <= a.theta || dn <= dc) && idx != W - 1;               // :491-496
+    if (move || (done_act > give_up && idx != W - 1)) {                          // :368-373
+        idx += 1;
+        done_act = 0;
+    }
+    cur_idx[p] = idx;
+    actions_done[p] = done_act;
+    if (at_goal != nullptr) {
+        const bool near = ell_dist(x, wp + (W - 1) * d, inv_r, d) <= a.theta;   // :426
+        at_goal[p] = (near || (idx == W - 1 && final_steps <= done_act)) ? 1 : 0; // :429-431
+    }
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace ssc
@@ -331,6 +362,24 @@ int ssc_mpc_score(const ssc_mpc_problems *pr, const float *d_S, float *d_scores,
     hipLaunchKernelGGL(mpc_pass_c_kernel, dim3((a.P + 63) / 64), dim3(64), 0, s, a.P, a.nblk, bbs, bbi, d_best_idx,
                        d_best_score);
     return check_launch("ssc_mpc_score");
+}
+
+int ssc_mpc_observe(const ssc_mpc_problems *pr, const float *d_new_state, int32_t *d_cur_idx,
+                    int32_t *d_actions_done, int32_t give_up_after, int32_t final_steps, uint8_t *d_at_goal,
+                    ssc_stream_t stream) {
+    SSC_REQUIRE(pr != nullptr, "ssc_mpc_observe: problems NULL");
+    SSC_REQUIRE(pr->n_problems >= 0, "ssc_mpc_observe: negative size");
+    SSC_REQUIRE(pr->state_dim >= 1 && pr->state_dim <= SSC_MAX_STATE, "ssc_mpc_observe: state_dim out of range");
+    if (pr->n_problems == 0) return SSC_OK;
+    SSC_REQUIRE(pr->wp && pr->wp_off && pr->radii && d_new_state && d_cur_idx && d_actions_done,
+                "ssc_mpc_observe: NULL device pointer");
+    MpcArgs a{};
+    a.P = pr->n_problems; a.d = pr->state_dim;
+    a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx;
+    a.theta = pr->theta;
+    hipLaunchKernelGGL(mpc_observe_kernel, dim3((a.P + 63) / 64), dim3(64), 0, as_stream(stream), a, d_new_state,
+                       d_cur_idx, d_actions_done, give_up_after, final_steps, d_at_goal);
+    return check_launch("ssc_mpc_observe");
 }
 
 int ssc_mpc_select_action(int32_t P, int32_t N, int32_t H, int32_t d, int32_t act, const float *d_A,

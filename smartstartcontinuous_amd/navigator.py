@@ -253,3 +253,52 @@ def mpc_select_action(A, S, best_idx, P, noise_amount, seed, problem_id0=0, t=0,
                                                     float(noise_amount), int(seed), int(problem_id0), int(t),
                                                     _ffi.ptr(action), _ffi.ptr(path), _stream()))
     return action, path
+
+
+class NavigatorBatch:
+    """P navigators (one per env) sharing one dynamics model: the vectorised counterpart of
+    ``NND_MB_agent.get_action`` / ``observe`` (NND_MB_agent.py:339-373, 498-520) -- per step ONE sample /
+    forward-sim / score / select pipeline over all P x N candidate sequences, and one waypoint-advance
+    kernel.  Plans (waypoints, distances_left, radii) come from ``NND_MB_agent.start_new_episode_plan`` or
+    any code that fills :class:`MpcProblemSet`."""
+
+    def __init__(self, dyn_model, problems, num_control_samples=5000, horizon=4, action_low=(-1.0,),
+                 action_high=(1.0,), noise_amount=0.005, steps_before_giving_up_on_waypoint=5, final_steps=10,
+                 seed=1234, problem_id0=0):
+        self.model, self.problems = dyn_model, problems
+        self.P, self.N, self.H = problems.P, int(num_control_samples), int(horizon)
+        self.low, self.high = np.asarray(action_low, np.float32), np.asarray(action_high, np.float32)
+        self.noise_amount, self.give_up, self.final_steps = noise_amount, steps_before_giving_up_on_waypoint, final_steps
+        self.seed, self.problem_id0 = int(seed), int(problem_id0)
+        dev = problems.wp.device
+        self.actions_done = torch.zeros(self.P, dtype=torch.int32, device=dev)
+        self.at_goal = torch.zeros(self.P, dtype=torch.uint8, device=dev)
+        self.start_idx = problems.cur_idx.clone()
+        self._S = torch.empty((self.H + 1, self.P * self.N, problems.d), dtype=torch.float32, device=dev)
+
+    def get_action(self, states, t):
+        """states [P, d] (device) -> (action [P, act], best_idx [P]) for global step ``t``."""
+        self.actions_done += 1                                                            # :340
+        A = mpc_sample_actions(self.P, self.N, self.H, self.low, self.high, self.seed, self.problem_id0, t,
+                               device=states.device)
+        s0 = states.float().repeat_interleave(self.N, dim=0)                              # np.tile, :215-217
+        S = self.model.do_forward_sim(s0, A, out=self._S)
+        _, best, _ = mpc_score(self.problems, S)
+        action, _ = mpc_select_action(A, S, best, self.P, self.noise_amount, self.seed, self.problem_id0, t,
+                                      want_path=False)
+        return action, best
+
+    def observe(self, new_states):
+        """Waypoint bookkeeping after env.step (NND_MB_agent.observe :360-373; goal test :425-432)."""
+        st = self.problems.as_struct(self.N, self.H)
+        ns = new_states.float().contiguous()
+        with torch.cuda.device(ns.device):
+            _ffi.check(_ffi.lib().ssc_mpc_observe(ctypes.byref(st), _ffi.ptr(ns), _ffi.ptr(self.problems.cur_idx),
+                                                  _ffi.ptr(self.actions_done), self.give_up, self.final_steps,
+                                                  _ffi.ptr(self.at_goal), _stream()))
+
+    def restart(self, mask):
+        """Envs that were reset start their plan over (start_new_episode_plan :383-384)."""
+        m = mask.bool()
+        self.problems.cur_idx[m] = self.start_idx[m]
+        self.actions_done[m] = 0

@@ -71,6 +71,16 @@ class ActorPolicy:
     ou_epsilon: float = 1.0
 
 
+@dataclass
+class MpcPolicy:
+    """The SmartStart navigator as a rollout policy (NND_MB_agent.get_action, NND_MB_agent.py:339-358):
+    ``navigators`` is a :class:`smartstartcontinuous_amd.navigator.NavigatorBatch` with one problem per env.
+    Unlike RANDOM / ACTOR this policy is a chain of kernels per step (sample, forward-sim, score, select,
+    env step, waypoint advance), not one fused launch: the forward simulation dominates by orders of
+    magnitude."""
+    navigators: object
+
+
 class TransitionChunk:
     """Transition log of one rollout chunk -- the (s, a, r, t, s2) records of
     ReplayBuffer.add (smartstart/RLAgents/replay_buffer.py:49-74) as SoA columns.
@@ -284,6 +294,8 @@ class VecEnv:
         finished episodes) is accumulated on the device."""
         if self._needs_reset:
             self.reset()
+        if isinstance(policy, MpcPolicy):
+            return self._rollout_mpc(K, policy.navigators, out, log)
         if policy_desc is None:
             policy_desc = self.policy_desc(policy)
         pd, keep = policy_desc
@@ -305,6 +317,37 @@ class VecEnv:
                 _ffi.ptr(self.stats), self._seed, self.env_id0, self.t, _stream()))
         self.t += K
         del keep
+        return chunk
+
+
+    def _rollout_mpc(self, K, nav, out, log):
+        """K steps with the MPC navigator choosing every action (one problem per env); same transition log
+        and statistics as the fused kernels, auto-reset on done."""
+        if nav.P != self.n:
+            raise ValueError("MpcPolicy needs one navigation problem per env")
+        chunk = None
+        if log:
+            chunk = out if out is not None else TransitionChunk(self.obs_dim, K, self.n, self.device)
+            chunk.step0, chunk.env_id0 = self.t, self.env_id0
+        for k in range(K):
+            obs = self.observe().contiguous()                       # [N, obs_dim] (a copy: _obs is reused)
+            action, _ = nav.get_action(obs, self.t)
+            obs2, rew, done, _ = self.step(action)
+            if chunk is not None:
+                chunk.obs[:, k, :] = obs.t()
+                chunk.act[k] = action[:, 0]
+                chunk.rew[k] = rew
+                chunk.done[k] = done.to(torch.uint8)
+                chunk.obs2[:, k, :] = obs2.t()
+            nav.observe(obs2)
+            self.ep_ret += rew
+            self.stats += torch.stack([rew.double().sum(), torch.zeros((), dtype=torch.float64, device=self.device),
+                                       torch.tensor(float(self.n), dtype=torch.float64, device=self.device),
+                                       done.double().sum()])
+            if bool(done.any()):
+                self.ep_ret[done] = 0.0
+                self.reset(mask=done)
+                nav.restart(done)
         return chunk
 
 
