@@ -158,19 +158,33 @@ def bench_config4(args, torch):
     from oracle import ssc_oracle as O
     from smartstartcontinuous_amd import navigator as nav
     from smartstartcontinuous_amd.agents import init_dynamics_weights
+    from smartstartcontinuous_amd import RandomPolicy, VecEnv
+    from smartstartcontinuous_amd import numerical as num
     P, N, H, d, a = 16, 4096, 4, 3, 1
     M = P * N
+    # data set exactly as the reference builds it (NND_MB_agent.py:75-76,230-242): 25 random-policy
+    # rollouts of 333 steps -- produced by the Pendulum rollout kernel; z-score statistics :302-315
+    denv = VecEnv("Pendulum-v0", 25, seed=1234)
+    dchunk = denv.rollout(333, RandomPolicy())
+    X = dchunk.obs.permute(2, 1, 0).reshape(-1, d).double().cpu().numpy()
+    Y = dchunk.act.t().reshape(-1, a).double().cpu().numpy()
+    Z = dchunk.obs2.permute(2, 1, 0).reshape(-1, d).double().cpu().numpy() - X
+    norm = dict(mean_x=X.mean(0), std_x=X.std(0), mean_y=Y.mean(0), std_y=Y.std(0), mean_z=Z.mean(0), std_z=Z.std(0))
     Ws, bs = init_dynamics_weights(d + a, d, 2, 500, torch.Generator().manual_seed(1234))
-    norm = dict(mean_x=np.zeros(d), std_x=np.ones(d), mean_y=np.zeros(a), std_y=np.full(a, 1.2), mean_z=np.zeros(d),
-                std_z=np.full(d, 0.05))
     model = nav.DynamicsModel(Ws, bs, norm, d, a, precision="bf16_mfma")
-    rng = np.random.default_rng(0)
-    wps = [np.cumsum(rng.normal(scale=0.05, size=(200, d)), axis=0) for _ in range(P)]
-    radii = [np.full(d, 0.06)] * P
-    lefts = [np.arange(200, 0, -1, dtype=np.float64) - 1 for _ in range(P)]
-    ps = nav.MpcProblemSet(wps, lefts, radii, [0] * P)
+    # waypoints = a recorded 200-state path (env 0 of the data set), radii / distances_left as in
+    # start_new_episode_plan (NND_MB_agent.py:375-423, no shortcutting)
+    path = dchunk.obs[:, :200, 0].t().double().cpu().numpy()
+    stds, means = num.path_deltas_stds_and_means_per_dim(path)
+    rad = num.radii_calc(means, stds, 1, 1, 1)
+    dist = num.elliptical_euclidean_distance_function_generator(rad)
+    wps = [path] * P
+    radii = [rad] * P
+    lefts = [num.distances_left(path, dist)] * P
+    ps = nav.MpcProblemSet(wps, lefts, radii, [0] * P, theta=1.0, gamma=0.75, horizontal_penalty_factor=0.5)
     s0 = torch.as_tensor(np.repeat(np.stack([w[0] for w in wps]), N, axis=0), dtype=torch.float32, device="cuda")
     S = torch.empty((H + 1, M, d), device="cuda")
+    rng = np.random.default_rng(0)
 
     def step(t):
         A = nav.mpc_sample_actions(P, N, H, [-2.0], [2.0], 1234, 0, t)
@@ -196,10 +210,12 @@ def bench_config4(args, torch):
     kms = sum(x.elapsed_time(y) for x, y in evs) / args.steps
     flop_row = 2.0 * ((d + a) * 500 + 500 * 500 + 500 * d)         # 507 000, SURVEY 8d
     res = {"metric": "row-steps/sec, NND_MB dynamics MLP 2x500 forward sim + MPC scoring, 65 536 rows", "value": M * H * args.steps / el,
-           "unit": "row-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+           "unit": "row-steps/s", "env_steps_per_s": P * args.steps / el,
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (hidden/output GEMMs, fp32 accumulate), f32 layer 1",
            "data": "synthetic", "config": {"workload": "BASELINE configs[3]: Pendulum dims (in 4, out 3), num_fc_layers 2, depth 500, "
-                                          "%d MPC problems x %d samples = %d rows, horizon %d; sample + forward sim + score + select" % (P, N, M, H)},
+                                          "%d MPC problems x %d samples = %d rows, horizon %d; z-score stats from 25x333 Pendulum random rollouts, "
+                                          "200-state recorded path as waypoints; sample + forward sim + score + select" % (P, N, M, H)},
            "roofline": {"bound": "mfma", "achieved": flop_row * M * H / (kms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": flop_row * M * H / (kms * 1e-3) / 1e12 / 2500.0, "traffic": None, "kernel_ms": kms,
                         "kernel": "ssc::dyn_mfma_sim_kernel<16,2> (+ 5 us weight pack)", "algorithmic_flop_per_launch": flop_row * M * H}}
