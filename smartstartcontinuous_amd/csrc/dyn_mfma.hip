@@ -37,13 +37,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kDynRows = 256;     // rows per block
-#ifndef SSC_DYN_ET
-#define SSC_DYN_ET 1               // 32-row tiles per wave: 2 -> 4 waves/block (1 per SIMD), 1 -> 8 waves/block (2 per SIMD)
+constexpr int kDynRows = 256;     // rows per block: 8 waves x one 32-row tile
+constexpr int kDynThreads = 512;  // waves w and w+4 share a SIMD (2 waves per SIMD, 256 VGPRs each)
+constexpr int kNW = kDynThreads / 64;
+constexpr int kMaxIn = 12;        // network inputs (state + action)
+constexpr int kMaxKS1 = 3;        // layer-1 bf16 k-steps of 16 slots: 2 bias slots + 3 per input
+// Timing-only ablations for tools/exp_dyn_variants.py (results are WRONG when set; never in libssc.so):
+// 1 no per-tile barrier, 2 no W2 tile prefetch, 4 no layer-1 MFMAs, 8 no output-layer MFMAs
+#ifndef SSC_DYN_ABLATE
+#define SSC_DYN_ABLATE 0
 #endif
-constexpr int ET = SSC_DYN_ET;
-constexpr int kDynThreads = 64 * (kDynRows / (32 * ET));
-constexpr int kMaxKS1 = 6;        // layer-1 k-steps of 2: inputs <= 12
 
 // LDS-DMA: one wave-instruction copies 64 x 16 B = 1 KiB global -> LDS with no VGPR staging
 // (global_load_lds_dwordx4).  The LDS destination is wave-uniform base + lane*16; the global source
@@ -63,13 +66,18 @@ __device__ __forceinline__ int frag_unit(int ut, int s, int half, int j) {
     return ut * 32 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
 }
 
+// Layer 1 on the bf16 MFMA at fp32-level accuracy: x = xh + xl, w = wh + wl (bf16 head + bf16 residual),
+// x*w ~= xh*wh + xl*wh + xh*wl (dropped xl*wl <= 2^-16 |x w|; products of bf16 pairs are exact in the
+// fp32 accumulator).  K slots of the layer-1 contraction (16 per k-step):
+//   slot 0: 1 * bf16(b1)   slot 1: 1 * residual(b1)   slot 2+3i+{0,1,2}: {xh_i*wh_i, xl_i*wh_i, xh_i*wl_i}
+__host__ __device__ __forceinline__ int l1_ksteps(int in) { return (2 + 3 * in + 15) / 16; }
+
 // Packed weight image in the workspace (all offsets in bytes, 256-aligned)
 struct DynPack {
     size_t a2;   // bf16 [UT jt][UT ut][2 s][64 lane][8]   W2^T fragments (NFC == 2)
-    size_t a3;   // bf16 [UT ut][2 s][64 lane][8]          Wout^T fragments, rows >= out are 0
-    size_t w1;   // f32  [KS1][UT][64 lane]                 W1[2ks+half][ut*32 + lane&31]
-    size_t b1;   // f32  [UT][2 half][16]                   b1 in accumulator layout
-    size_t b2;   // f32  [UT][2][16]
+    size_t a3;   // bf16 [UT ut][2 s][2 half][8 o][8]       Wout^T fragments, only the 8 possible output rows
+    size_t a1;   // bf16 [KS1][UT ut][64 lane][8]           layer-1 fragments (bias + split W1, see above)
+    size_t b2;   // f32  [UT][2 half][16]                   b2 in accumulator layout
     size_t b3;   // f32  [2][16]
     size_t nm;   // f32  [6][8]  mean_x std_x mean_y std_y mean_z std_z
     size_t total;
@@ -81,9 +89,8 @@ static DynPack make_pack(int UT, int nfc) {
     DynPack p;
     size_t o = 0;
     p.a2 = o; o += al256(nfc == 2 ? (size_t)UT * UT * 2 * 64 * 8 * 2 : 0);
-    p.a3 = o; o += al256((size_t)UT * 2 * 64 * 8 * 2);
-    p.w1 = o; o += al256((size_t)kMaxKS1 * UT * 64 * 4);
-    p.b1 = o; o += al256((size_t)UT * 32 * 4);
+    p.a3 = o; o += al256((size_t)UT * 2 * 2 * 8 * 8 * 2);
+    p.a1 = o; o += al256((size_t)kMaxKS1 * UT * 64 * 8 * 2);
     p.b2 = o; o += al256((size_t)UT * 32 * 4);
     p.b3 = o; o += al256(32 * 4);
     p.nm = o; o += al256(48 * 4);
@@ -95,6 +102,9 @@ struct DynNet {
     const float *W1, *b1, *W2, *b2, *W3, *b3;  // W3/b3 = output layer; W2/b2 unused when nfc == 1
     int in, depth, out, nfc;
 };
+
+__device__ __forceinline__ __bf16 bf16_head(float v) { return (__bf16)v; }
+__device__ __forceinline__ __bf16 bf16_resid(float v) { return (__bf16)(v - (float)(__bf16)v); }
 
 __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack pk, ssc_norm nm,
                                                        unsigned char *__restrict__ ws) {
@@ -108,8 +118,8 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
         reinterpret_cast<float *>(ws + pk.nm)[gid] = v;
     }
     const int64_t n_a2 = (n.nfc == 2) ? (int64_t)UT * UT * 2 * 64 * 8 : 0;
-    const int64_t n_a3 = (int64_t)UT * 2 * 64 * 8;
-    const int64_t n_w1 = (int64_t)kMaxKS1 * UT * 64;
+    const int64_t n_a3 = (int64_t)UT * 2 * 2 * 8 * 8;
+    const int64_t n_a1 = (int64_t)kMaxKS1 * UT * 64 * 8;
     const int64_t n_b = (int64_t)UT * 32;
     int64_t e = gid;
     if (e < n_a2) {
@@ -122,28 +132,33 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
     }
     e -= n_a2;
     if (e < n_a3) {
-        const int j = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 1, ut = (int)(e >> 10);
-        const int u = frag_unit(ut, s, lane >> 5, j), o = lane & 31;
+        const int j = e & 7, o = (e >> 3) & 7, half = (e >> 6) & 1, s = (e >> 7) & 1, ut = (int)(e >> 8);
+        const int u = frag_unit(ut, s, half, j);
         const float v = (u < n.depth && o < n.out) ? n.W3[(int64_t)u * n.out + o] : 0.0f;
         reinterpret_cast<__bf16 *>(ws + pk.a3)[e] = (__bf16)v;
         return;
     }
     e -= n_a3;
-    if (e < n_w1) {
-        const int lane = e & 63, ut = (int)((e >> 6) % UT), ks = (int)((e >> 6) / UT);
-        const int k = 2 * ks + (lane >> 5), unit = ut * 32 + (lane & 31);
-        reinterpret_cast<float *>(ws + pk.w1)[e] = (k < n.in && unit < n.depth) ? n.W1[(int64_t)k * n.depth + unit] : 0.0f;
+    if (e < n_a1) {
+        const int j = e & 7, lane = (e >> 3) & 63, ut = (int)((e >> 9) % UT), ks = (int)((e >> 9) / UT);
+        const int q = 16 * ks + 8 * (lane >> 5) + j, unit = ut * 32 + (lane & 31);
+        __bf16 v = (__bf16)0.0f;
+        if (unit < n.depth) {
+            if (q == 0) v = bf16_head(n.b1[unit]);
+            else if (q == 1) v = bf16_resid(n.b1[unit]);
+            else {
+                const int i = (q - 2) / 3, c = (q - 2) % 3;
+                if (i < n.in) {
+                    const float w = n.W1[(int64_t)i * n.depth + unit];
+                    v = (c == 2) ? bf16_resid(w) : bf16_head(w);
+                }
+            }
+        }
+        reinterpret_cast<__bf16 *>(ws + pk.a1)[e] = v;
         return;
     }
-    e -= n_w1;
-    if (e < n_b) {  // b1: [ut][half][reg]
-        const int reg = e & 15, half = (e >> 4) & 1, ut = (int)(e >> 5);
-        const int u = ut * 32 + acc_row32(reg, half);
-        reinterpret_cast<float *>(ws + pk.b1)[e] = (u < n.depth) ? n.b1[u] : 0.0f;
-        return;
-    }
-    e -= n_b;
-    if (e < n_b) {
+    e -= n_a1;
+    if (e < n_b) {  // b2: [ut][half][reg]
         const int reg = e & 15, half = (e >> 4) & 1, ut = (int)(e >> 5);
         const int u = ut * 32 + acc_row32(reg, half);
         reinterpret_cast<float *>(ws + pk.b2)[e] = (n.nfc == 2 && u < n.depth) ? n.b2[u] : 0.0f;
@@ -166,8 +181,8 @@ struct DynSimArgs {
     int64_t s0_rows;
     const float *A;         // sim: [m][H][a]; fwd: x [m][in]
     float *S;               // sim: [H+1][m][d]; fwd: y [m][out]
-    const unsigned char *a2, *a3;       // packed weight image (workspace)
-    const float *w1, *b1, *b2, *b3, *nm;
+    const unsigned char *a1, *a2, *a3;  // packed weight image (workspace)
+    const float *b2, *b3, *nm;
 };
 
 __device__ __forceinline__ float nan_to_num_div(float x, float mean, float stdv) {
@@ -198,139 +213,183 @@ __device__ __forceinline__ void relu_to_frags(const f32x16 &acc, bf16x8 &f0, bf1
     f1 = __builtin_bit_cast(bf16x8, p1);
 }
 
-// LDS carve (bytes): [a2 buffers 2 x UT*2048 (NFC==2)] [a3 UT*2048] [w1 6*UT*256] [b1 UT*128] [b2 UT*128] [b3 128] [nm 192]
+// bf16 head / residual of x as 16-bit patterns (round to nearest even, like the weights)
+__device__ __forceinline__ void split_bf16(float x, uint32_t &hi, uint32_t &lo) {
+    x = fminf(fmaxf(x, -3.3895314e38f), 3.3895314e38f);  // +-FLT_MAX of nan_to_num would round to bf16 inf
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+
+// LDS carve (bytes): [a2: NBUF x UT*2048] [a1: ks1*UT*1024] [a3: UT*512] [zero 16] [b2 UT*128] [b3 128] [nm 192]
+// W2 (NFC == 2): resident when it fits (UT <= 4: all UT tiles), otherwise streamed through a ring of 3.
 template <int UT, int NFC>
-__global__ __launch_bounds__(kDynThreads, ET == 2 ? 1 : 2) void dyn_mfma_sim_kernel(DynSimArgs g) {
+__host__ __device__ constexpr int dyn_a2_bufs() { return NFC == 2 ? (UT <= 4 ? UT : 3) : 0; }
+
+template <int UT, int NFC>
+__global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int A2_TILE = UT * 2048;  // one output tile of W2^T fragments
+    constexpr int A2_TILE = UT * 2048;  // one 32-unit output tile of W2^T fragments
+    constexpr int NBUF = dyn_a2_bufs<UT, NFC>();
+    constexpr bool STREAM = (NFC == 2) && (UT > 4);
+    constexpr int A2_CHUNKS = A2_TILE / 1024;           // LDS-DMA pieces per tile
+    constexpr int PPW = (A2_CHUNKS + kNW - 1) / kNW;    // pieces per wave per tile
     unsigned char *l_a2 = lds;
-    unsigned char *l_a3 = l_a2 + (NFC == 2 ? 2 * A2_TILE : 0);
-    float *l_w1 = reinterpret_cast<float *>(l_a3 + UT * 2048);
-    float *l_b1 = l_w1 + kMaxKS1 * UT * 64;
-    float *l_b2 = l_b1 + UT * 32;
+    unsigned char *l_a1 = l_a2 + NBUF * A2_TILE;
+    unsigned char *l_a3 = l_a1 + g.ks1 * UT * 1024;
+    unsigned char *l_zero = l_a3 + UT * 512;
+    float *l_b2 = reinterpret_cast<float *>(l_zero + 16);
     float *l_b3 = l_b2 + UT * 32;
     float *l_nm = l_b3 + 32;  // [6][8]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, half = lane >> 5;
+    // Waves 0-3 (group 0) and 4-7 (group 1) pair up on the SIMDs.  Group 1 takes the per-tile barrier in
+    // the MIDDLE of its tile, group 0 at the end: the two waves of a SIMD are then half a tile out of
+    // phase, and the tile-boundary work of one (ReLU, output MFMAs, bias/fragment refill) runs under the
+    // other's MFMA stream instead of both idling the matrix pipe together.
+    const int group = wave >> 2;
 
-    // ---- stage the resident weights: a3, w1, biases, normalisation ----------------------------
+    // ---- stage the resident weights ------------------------------------------------------------
     {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(g.a3);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(l_a3);
-        for (int e = tid; e < UT * 2048 / 16; e += kDynThreads) dst[e] = src[e];
-        for (int e = tid; e < kMaxKS1 * UT * 64; e += kDynThreads) l_w1[e] = g.w1[e];
-        for (int e = tid; e < UT * 32; e += kDynThreads) { l_b1[e] = g.b1[e]; l_b2[e] = g.b2[e]; }
+        const f32x4 *s3 = reinterpret_cast<const f32x4 *>(g.a3);
+        f32x4 *d3 = reinterpret_cast<f32x4 *>(l_a3);
+        for (int e = tid; e < UT * 512 / 16; e += kDynThreads) d3[e] = s3[e];
+        const f32x4 *s1 = reinterpret_cast<const f32x4 *>(g.a1);
+        f32x4 *d1 = reinterpret_cast<f32x4 *>(l_a1);
+        for (int e = tid; e < g.ks1 * UT * 1024 / 16; e += kDynThreads) d1[e] = s1[e];
+        for (int e = tid; e < UT * 32; e += kDynThreads) l_b2[e] = g.b2[e];
         if (tid < 32) l_b3[tid] = g.b3[tid];
         if (tid < 48) l_nm[tid] = g.nm[tid];
+        if (tid < 4) reinterpret_cast<float *>(l_zero)[tid] = 0.0f;
     }
-    // W2^T tile 0 -> buffer 0 (LDS-DMA, 1 KiB per wave-instruction)
-    constexpr int NW = kDynThreads / 64;
-    constexpr int A2_CHUNKS = A2_TILE / 1024;
     const unsigned char *a2_src = g.a2;
-    if (NFC == 2) {
+    const int n_tiles = UT * g.H;  // W2 tiles this block walks through (STREAM)
+    if (NFC == 2) {  // first W2^T tiles by LDS-DMA: everything when resident, tiles 0 and 1 of the ring otherwise
+        constexpr int PRE = STREAM ? 2 : NBUF;
 #pragma unroll
-        for (int c = wave; c < A2_CHUNKS; c += NW) glds_1k(a2_src + c * 1024 + lane * 16, l_a2 + c * 1024);
+        for (int c = wave; c < PRE * A2_CHUNKS; c += kNW) glds_1k(a2_src + c * 1024 + lane * 16, l_a2 + c * 1024);
     }
     __syncthreads();
 
-    // ---- this lane's rows (one per tile) -------------------------------------------------------
-    int64_t row[ET], rowc[ET];
-    bool valid[ET];
-    float st[ET][SSC_MAX_STATE];
+    // output-layer A fragments: output row o = lane & 31 < 8 reads its 16 B, the others a zero line
+    const unsigned char *a3_lane = (r < 8) ? l_a3 + (half * 8 + r) * 16 : l_zero;
+    const int a3_step = (r < 8) ? 256 : 0;
+
+    // ---- this lane's row ---------------------------------------------------------------------
+    const int64_t row = (int64_t)blockIdx.x * kDynRows + wave * 32 + r;
+    const bool valid = row < g.m;
+    const int64_t rowc = valid ? row : g.m - 1;
+    float st[SSC_MAX_STATE];
+    if (!g.fwd_mode) {
 #pragma unroll
-    for (int et = 0; et < ET; ++et) {
-        row[et] = (int64_t)blockIdx.x * kDynRows + wave * (32 * ET) + et * 32 + r;
-        valid[et] = row[et] < g.m;
-        rowc[et] = valid[et] ? row[et] : g.m - 1;
-        if (!g.fwd_mode) {
-#pragma unroll
-            for (int k = 0; k < SSC_MAX_STATE; ++k)
-                st[et][k] = (k < g.d) ? g.s0[(g.s0_rows == 1 ? 0 : rowc[et]) * g.d + k] : 0.0f;
-        }
+        for (int k = 0; k < SSC_MAX_STATE; ++k) st[k] = (k < g.d) ? g.s0[(g.s0_rows == 1 ? 0 : rowc) * g.d + k] : 0.0f;
     }
 
+    int bsel = 0;  // ring buffer of the current W2 tile (STREAM)
     for (int t = 0; t < g.H; ++t) {
         // ---- inputs: record S[t]; x = normalised (state, action) ------------------------------
-        float xs[ET][2 * kMaxKS1];
+        float xs[kMaxIn];
+        if (g.fwd_mode) {
 #pragma unroll
-        for (int et = 0; et < ET; ++et) {
-            if (g.fwd_mode) {
+            for (int k = 0; k < kMaxIn; ++k) xs[k] = (k < g.in) ? g.A[rowc * g.in + k] : 0.0f;
+        } else {
+            if (valid && half == 0) {
 #pragma unroll
-                for (int k = 0; k < 2 * kMaxKS1; ++k) xs[et][k] = (k < g.in) ? g.A[rowc[et] * g.in + k] : 0.0f;
-            } else {
-                if (valid[et] && half == 0) {
+                for (int k = 0; k < SSC_MAX_STATE; ++k)
+                    if (k < g.d) g.S[((int64_t)t * g.m + row) * g.d + k] = st[k];  // dynamics_model.py:225
+            }
 #pragma unroll
-                    for (int k = 0; k < SSC_MAX_STATE; ++k)
-                        if (k < g.d) g.S[((int64_t)t * g.m + row[et]) * g.d + k] = st[et][k];  // dynamics_model.py:225
+            for (int k = 0; k < kMaxIn; ++k) {
+                float v = 0.0f;
+                if (k < g.d) {
+                    v = nan_to_num_div(st[k < SSC_MAX_STATE ? k : 0], l_nm[0 * 8 + (k & 7)], l_nm[1 * 8 + (k & 7)]);
+                } else if (k < g.in) {
+                    const int ai = (k - g.d) & 3;
+                    v = nan_to_num_div(g.A[(rowc * g.H + t) * g.a + ai], l_nm[2 * 8 + ai], l_nm[3 * 8 + ai]);
                 }
-#pragma unroll
-                for (int k = 0; k < 2 * kMaxKS1; ++k) {
-                    float v = 0.0f;
-                    if (k < g.d) {
-                        v = nan_to_num_div(st[et][k < SSC_MAX_STATE ? k : 0], l_nm[0 * 8 + (k & 7)], l_nm[1 * 8 + (k & 7)]);
-                    } else if (k < g.in) {
-                        const int ai = (k - g.d) & 3;
-                        v = nan_to_num_div(g.A[(rowc[et] * g.H + t) * g.a + ai], l_nm[2 * 8 + ai], l_nm[3 * 8 + ai]);
-                    }
-                    xs[et][k] = v;
-                }
+                xs[k] = v;
             }
         }
-        // ---- layer 1 on fp32 MFMA: D[unit][row] = W1^T x + b1 -> ReLU -> bf16 B fragments --------
-        bf16x8 h1f[ET][UT][2];
+        // ---- layer-1 B fragments: this lane's 8 k slots per k-step (slot layout above) -------------
+        bf16x8 xf[kMaxKS1];
+        {
+            uint32_t xh[kMaxIn], xl[kMaxIn];
 #pragma unroll
-        for (int ut = 0; ut < UT; ++ut) {
-            const f32x16 c1 = lds_tile16(l_b1 + (ut * 2 + half) * 16);
-            f32x16 acc[ET];
+            for (int k = 0; k < kMaxIn; ++k) split_bf16(xs[k], xh[k], xl[k]);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int et = 0; et < ET; ++et) acc[et] = c1;
+            for (int ks = 0; ks < kMaxKS1; ++ks) {
+                u32x4 w;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    uint32_t dw[2];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        uint32_t v16[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int q = 16 * ks + 8 * hf + 2 * jj + e;
+                            const int i = (q - 2) / 3, c = (q - 2) % 3;
+                            v16[e] = (q < 2) ? 0x3F80u : (i < kMaxIn ? (c == 1 ? xl[i] : xh[i]) : 0u);
+                        }
+                        dw[hf] = v16[0] | (v16[1] << 16);
+                    }
+                    w[jj] = half ? dw[1] : dw[0];
+                }
+                xf[ks] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        // ---- layer 1: D[unit][row] = W1^T x + b1 -> ReLU -> bf16 B fragments of the next layer ------
+        bf16x8 h1f[UT][2];
+        auto layer1_tile = [&](int ut) {
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < kMaxKS1; ++ks)
-                if (ks < g.ks1) {  // block-uniform
-                    const float w = l_w1[(ks * UT + ut) * 64 + lane];
-#pragma unroll
-                    for (int et = 0; et < ET; ++et) {
-                        const float bop = half ? xs[et][2 * ks + 1] : xs[et][2 * ks];
-                        acc[et] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bop, acc[et], 0, 0, 0);
-                    }
+                if (ks < g.ks1 && !(SSC_DYN_ABLATE & 4)) {  // block-uniform
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a1 + ((ks * UT + ut) * 64 + lane) * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[ks], acc, 0, 0, 0);
                 }
+            return acc;
+        };
+        {
+            f32x16 accn = layer1_tile(0);
 #pragma unroll
-            for (int et = 0; et < ET; ++et) {
-                relu_to_frags(acc[et], h1f[et][ut][0], h1f[et][ut][1]);
+            for (int ut = 0; ut < UT; ++ut) {
+                const f32x16 acc = accn;
+                if (ut + 1 < UT) accn = layer1_tile(ut + 1);  // its MFMA runs under this tile's ReLU/convert
+                relu_to_frags(acc, h1f[ut][0], h1f[ut][1]);
                 // Pin the conversion HERE.  The fragments are first used inside the jt loop, so the
                 // optimiser otherwise sinks ReLU+convert down to that loop's preheader and keeps all
-                // 2*UT fp32 accumulator tiles (32 VGPRs each) alive until then -> hundreds of spills.
-                asm volatile("" : "+v"(h1f[et][ut][0]), "+v"(h1f[et][ut][1]));
+                // UT fp32 accumulator tiles (16 VGPRs each) alive until then -> hundreds of spills.
+                asm volatile("" : "+v"(h1f[ut][0]), "+v"(h1f[ut][1]));
+                __builtin_amdgcn_sched_barrier(0);  // and one unit tile at a time in the machine scheduler
             }
-            __builtin_amdgcn_sched_barrier(0);  // and one unit tile at a time in the machine scheduler
         }
         // ---- hidden layer 2 (+ output layer fused per tile) -------------------------------------
-        f32x16 acc3[ET];
-#pragma unroll
-        for (int et = 0; et < ET; ++et) acc3[et] = lds_tile16(l_b3 + half * 16);
+        f32x16 acc3 = lds_tile16(l_b3 + half * 16);
         if (NFC == 2) {
 #pragma unroll 1
             for (int jt = 0; jt < UT; ++jt) {
-                const unsigned char *buf = l_a2 + (UT > 1 ? (jt & 1) * A2_TILE : 0);
-                // prefetch the next W2^T tile (next jt, or tile 0 of the next step) straight into the other
-                // LDS buffer: its last readers (tile jt-1) all passed the previous barrier
-                const bool more = (UT > 1) && (jt + 1 < UT || t + 1 < g.H);
-                const int jn = (jt + 1 < UT) ? jt + 1 : 0;
-                if (more) {
-                    unsigned char *nb = l_a2 + ((jt + 1) & 1) * A2_TILE;
-#pragma unroll
-                    for (int c = wave; c < A2_CHUNKS; c += NW)
-                        glds_1k(a2_src + (size_t)jn * A2_TILE + c * 1024 + lane * 16, nb + c * 1024);
+                const int tl = t * UT + jt;  // linear tile counter == barrier counter (STREAM)
+                const unsigned char *buf = l_a2 + (STREAM ? bsel : jt) * A2_TILE;
+                // STREAM: the ring holds tiles tl (being read), tl+1 (landed) and the one in flight.  Barrier
+                // number tl (end of tile tl for group 0, middle of tile tl for group 1) retires every read of
+                // tile tl-1 and publishes tile tl+1; after it this wave issues its pieces of tile tl+2 into
+                // the slot of tile tl-1, spread over the following k-steps so their issue cost hides under MFMAs.
+                int dma_jn = -1, dma_slot = 0;
+                if (STREAM && group == 0 && tl >= 1 && tl + 1 < n_tiles && !(SSC_DYN_ABLATE & 2)) {
+                    dma_jn = (jt + 1) & (UT - 1);                  // group 0 passed barrier tl-1 just before this tile
+                    dma_slot = bsel == 2 ? 0 : bsel + 1;
                 }
                 const f32x16 c2 = lds_tile16(l_b2 + (jt * 2 + half) * 16);
-                f32x16 acc2[ET];
-#pragma unroll
-                for (int et = 0; et < ET; ++et) acc2[et] = c2;
-                // software-pipelined fragment reads, two k-steps ahead; the fences pin the order so
-                // that the prefetch depth (and with it the register footprint) stays what is written
+                f32x16 acc2 = c2;
                 constexpr int NK = UT * 2;
                 constexpr int RING = (NK >= 4) ? 4 : 2;   // fragment reads in flight per wave
+                constexpr int MID = NK / 2 - 1;
+                constexpr int DSTRIDE = (NK / 2 - 2) / PPW > 0 ? (NK / 2 - 2) / PPW : 1;
                 bf16x8 ring[RING];
 #pragma unroll
                 for (int q = 0; q < RING; ++q) ring[q] = *reinterpret_cast<const bf16x8 *>(buf + (q * 64 + lane) * 16);
@@ -339,63 +398,78 @@ __global__ __launch_bounds__(kDynThreads, ET == 2 ? 1 : 2) void dyn_mfma_sim_ker
                     const bf16x8 a = ring[i % RING];
                     if (i + RING < NK)
                         ring[i % RING] = *reinterpret_cast<const bf16x8 *>(buf + ((i + RING) * 64 + lane) * 16);
-#pragma unroll
-                    for (int et = 0; et < ET; ++et)
-                        acc2[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[et][i >> 1][i & 1], acc2[et], 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[i >> 1][i & 1], acc2, 0, 0, 0);
+                    if (STREAM) {
+                        // piece p of this wave goes out after k-step 1 + p*DSTRIDE of the half tile that follows
+                        // the wave's barrier
+                        const int ih = (i > MID) ? i - MID - 1 : i;
+                        if (ih >= 1 && (ih - 1) % DSTRIDE == 0 && (ih - 1) / DSTRIDE < PPW) {
+                            const int p = (ih - 1) / DSTRIDE;
+                            if (dma_jn >= 0 && (group == (i > MID ? 1 : 0))) {
+                                const int c = wave + p * kNW;
+                                glds_1k(a2_src + (size_t)dma_jn * A2_TILE + c * 1024 + lane * 16,
+                                        l_a2 + dma_slot * A2_TILE + c * 1024);
+                            }
+                        }
+                        if (i == MID && group == 1) {
+                            if (!(SSC_DYN_ABLATE & 1)) __syncthreads();  // barrier tl of group 1
+                            if (tl + 2 < n_tiles && !(SSC_DYN_ABLATE & 2)) {
+                                dma_jn = (jt + 2) & (UT - 1);
+                                dma_slot = bsel == 0 ? 2 : bsel - 1;      // (bsel + 2) % 3
+                            }
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const bf16x8 a30 = *reinterpret_cast<const bf16x8 *>(l_a3 + ((jt * 2 + 0) * 64 + lane) * 16);
-                const bf16x8 a31 = *reinterpret_cast<const bf16x8 *>(l_a3 + ((jt * 2 + 1) * 64 + lane) * 16);
-#pragma unroll
-                for (int et = 0; et < ET; ++et) {
-                    bf16x8 f0, f1;
-                    relu_to_frags(acc2[et], f0, f1);
-                    acc3[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, f0, acc3[et], 0, 0, 0);
-                    acc3[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, f1, acc3[et], 0, 0, 0);
+                const bf16x8 a30 = *reinterpret_cast<const bf16x8 *>(a3_lane + (jt * 2 + 0) * a3_step);
+                const bf16x8 a31 = *reinterpret_cast<const bf16x8 *>(a3_lane + (jt * 2 + 1) * a3_step);
+                bf16x8 f0, f1;
+                relu_to_frags(acc2, f0, f1);
+                if (SSC_DYN_ABLATE & 8) {
+                    acc3[0] += (float)f0[0] + (float)f1[0];
+                } else {
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, f0, acc3, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, f1, acc3, 0, 0, 0);
                 }
-                if (UT > 1) __syncthreads();  // drains the LDS-DMA (vmcnt) and publishes the next tile
+                if (STREAM) {
+                    if (group == 0 && !(SSC_DYN_ABLATE & 1)) __syncthreads();  // barrier tl of group 0
+                    bsel = bsel == 2 ? 0 : bsel + 1;
+                }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < UT * 2; ++i) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a3 + (i * 64 + lane) * 16);
-#pragma unroll
-                for (int et = 0; et < ET; ++et)
-                    acc3[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[et][i >> 1][i & 1], acc3[et], 0, 0, 0);
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(a3_lane + i * a3_step);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[i >> 1][i & 1], acc3, 0, 0, 0);
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- z[o]: rows 0..3 sit in regs 0..3 of half 0, rows 4..7 in regs 0..3 of half 1 ------------
+        float z[SSC_MAX_STATE];
 #pragma unroll
-        for (int et = 0; et < ET; ++et) {
-            float z[SSC_MAX_STATE];
+        for (int o = 0; o < 4; ++o) {
+            const float mine = acc3[o], other = __shfl_xor(acc3[o], 32);
+            z[o] = half ? other : mine;
+            z[4 + o] = half ? mine : other;
+        }
+        if (g.fwd_mode) {
+            if (valid && half == 0) {
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const float mine = acc3[et][o], other = __shfl_xor(acc3[et][o], 32);
-                z[o] = half ? other : mine;
-                z[4 + o] = half ? mine : other;
+                for (int o = 0; o < SSC_MAX_STATE; ++o)
+                    if (o < g.out) g.S[row * g.out + o] = z[o];
             }
-            if (g.fwd_mode) {
-                if (valid[et] && half == 0) {
+        } else {
 #pragma unroll
-                    for (int o = 0; o < SSC_MAX_STATE; ++o)
-                        if (o < g.out) g.S[row[et] * g.out + o] = z[o];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < SSC_MAX_STATE; ++k)
-                    if (k < g.d) st[et][k] = st[et][k] + (z[k] * l_nm[5 * 8 + k] + l_nm[4 * 8 + k]);  // :234-237
-            }
+            for (int k = 0; k < SSC_MAX_STATE; ++k)
+                if (k < g.d) st[k] = st[k] + (z[k] * l_nm[5 * 8 + k] + l_nm[4 * 8 + k]);  // :234-237
         }
     }
     if (!g.fwd_mode) {
+        if (valid && half == 0) {
 #pragma unroll
-        for (int et = 0; et < ET; ++et)
-            if (valid[et] && half == 0) {
-#pragma unroll
-                for (int k = 0; k < SSC_MAX_STATE; ++k)
-                    if (k < g.d) g.S[((int64_t)g.H * g.m + row[et]) * g.d + k] = st[et][k];  // :240
-            }
+            for (int k = 0; k < SSC_MAX_STATE; ++k)
+                if (k < g.d) g.S[((int64_t)g.H * g.m + row) * g.d + k] = st[k];  // :240
+        }
     }
 }
 
@@ -407,7 +481,7 @@ bool dyn_mfma_supported(const ssc_mlp_desc *mlp, int state_dim, int act_dim) {
     if (nfc != 1 && nfc != 2) return false;
     const int depth = mlp->dims[1];
     if (depth > 512 || (nfc == 2 && mlp->dims[2] != depth)) return false;
-    if (mlp->dims[0] > 2 * kMaxKS1 || mlp->dims[mlp->n_layers] > SSC_MAX_STATE) return false;
+    if (mlp->dims[0] > kMaxIn || mlp->dims[mlp->n_layers] > SSC_MAX_STATE) return false;
     return true;
 }
 
@@ -419,8 +493,8 @@ size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp) {
 
 template <int UT, int NFC>
 static int launch_sim(const DynSimArgs &g, hipStream_t s) {
-    const size_t lds = (size_t)(NFC == 2 ? 2 * UT * 2048 : 0) + (size_t)UT * 2048 + (size_t)kMaxKS1 * UT * 256 +
-                       (size_t)UT * 128 * 2 + 128 + 192;
+    const size_t lds = (size_t)dyn_a2_bufs<UT, NFC>() * UT * 2048 + (size_t)g.ks1 * UT * 1024 + (size_t)UT * 512 + 16 +
+                       (size_t)UT * 128 + 128 + 192;
     auto kern = dyn_mfma_sim_kernel<UT, NFC>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -444,14 +518,13 @@ static int run_mfma(const ssc_mlp_desc *mlp, const ssc_norm *norm, DynSimArgs &g
     n.W2 = (nfc == 2) ? mlp->W[1] : nullptr; n.b2 = (nfc == 2) ? mlp->b[1] : nullptr;
     n.W3 = mlp->W[nfc]; n.b3 = mlp->b[nfc];
     unsigned char *ws = static_cast<unsigned char *>(wsv);
-    const int64_t n_pack = (nfc == 2 ? (int64_t)UT * UT * 1024 : 0) + (int64_t)UT * 1024 + (int64_t)kMaxKS1 * UT * 64 +
-                           2 * (int64_t)UT * 32 + 32;
+    const int64_t n_pack = (nfc == 2 ? (int64_t)UT * UT * 1024 : 0) + (int64_t)UT * 256 + (int64_t)kMaxKS1 * UT * 512 +
+                           (int64_t)UT * 32 + 32;
     ssc_norm nm{};
     if (norm) nm = *norm;
     hipLaunchKernelGGL(dyn_pack_kernel, dim3(blocks_for(n_pack)), dim3(256), 0, s, n, UT, pk, nm, ws);
-    g.in = n.in; g.out = n.out; g.ks1 = (n.in + 1) / 2;
-    g.a2 = ws + pk.a2; g.a3 = ws + pk.a3;
-    g.w1 = reinterpret_cast<const float *>(ws + pk.w1); g.b1 = reinterpret_cast<const float *>(ws + pk.b1);
+    g.in = n.in; g.out = n.out; g.ks1 = l1_ksteps(n.in);
+    g.a1 = ws + pk.a1; g.a2 = ws + pk.a2; g.a3 = ws + pk.a3;
     g.b2 = reinterpret_cast<const float *>(ws + pk.b2); g.b3 = reinterpret_cast<const float *>(ws + pk.b3);
     g.nm = reinterpret_cast<const float *>(ws + pk.nm);
 #define SSC_DYN_CASE(U, F) if (UT == U && nfc == F) return launch_sim<U, F>(g, s)
