@@ -27,6 +27,7 @@
 //     layout) and streamed L2 -> registers -> LDS one 32-unit output tile (UT*2 KB) at a time,
 //     double buffered, one barrier per tile.
 #include <float.h>
+#include <type_traits>
 
 #include "ssc_device.h"
 #include "ssc_host.h"
@@ -42,21 +43,23 @@ constexpr int kDynThreads = 512;  // waves w and w+4 share a SIMD (2 waves per S
 constexpr int kNW = kDynThreads / 64;
 constexpr int kMaxIn = 12;        // network inputs (state + action)
 constexpr int kMaxKS1 = 3;        // layer-1 bf16 k-steps of 16 slots: 2 bias slots + 3 per input
-// Timing-only ablations for tools/exp_dyn_variants.py (results are WRONG when set; never in libssc.so):
-// 1 no per-tile barrier, 2 no W2 tile prefetch, 4 no layer-1 MFMAs, 8 no output-layer MFMAs
+// Diagnostic builds for tools/exp_dyn_clock.py (results are WRONG when set; never in libssc.so):
+// 16 clock stamps: every block overwrites S[4*block .. +3] with {d_memtime, d_memrealtime} of its step loop
 #ifndef SSC_DYN_ABLATE
 #define SSC_DYN_ABLATE 0
 #endif
 
 // LDS-DMA: one wave-instruction copies 64 x 16 B = 1 KiB global -> LDS with no VGPR staging
-// (global_load_lds_dwordx4).  The LDS destination is wave-uniform base + lane*16; the global source
-// is per lane.  Completion is tracked by vmcnt (the __syncthreads() that follows drains it).
-__device__ __forceinline__ void glds_1k(const unsigned char *gsrc_lane, unsigned char *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds(
-        reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(gsrc_lane)),
+// (buffer_load_dwordx4 ... lds).  LDS destination = wave-uniform base + lane*16; source = buffer base +
+// wave-uniform soffset + lane*16.  Completion is tracked by vmcnt.  The MUBUF form on purpose: hipcc models
+// the FLAT-encoded global_load_lds as "may touch LDS and memory" and from then on turns every counted
+// s_waitcnt lgkmcnt(N) into lgkmcnt(0), which serialises the fragment ring behind the LDS latency.
+__device__ __forceinline__ void lds_dma_1k(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int soffset, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rsrc,
         reinterpret_cast<__attribute__((address_space(3))) void *>(
             static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_wave_base))),
-        16, 0, 0);
+        16, lane_off, soffset, 0, 0);
 }
 
 __device__ __forceinline__ int acc_row32(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
@@ -265,13 +268,15 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         if (tid < 48) l_nm[tid] = g.nm[tid];
         if (tid < 4) reinterpret_cast<float *>(l_zero)[tid] = 0.0f;
     }
-    const unsigned char *a2_src = g.a2;
-    const int n_tiles = UT * g.H;  // W2 tiles this block walks through (STREAM)
+    // raw buffer over the W2^T fragment image (reads past the end return 0)
+    const __amdgpu_buffer_rsrc_t a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(g.a2), 0, NFC == 2 ? UT * A2_TILE : 0, 0x00020000);
     if (NFC == 2) {  // first W2^T tiles by LDS-DMA: everything when resident, tiles 0 and 1 of the ring otherwise
         constexpr int PRE = STREAM ? 2 : NBUF;
 #pragma unroll
-        for (int c = wave; c < PRE * A2_CHUNKS; c += kNW) glds_1k(a2_src + c * 1024 + lane * 16, l_a2 + c * 1024);
+        for (int c = wave; c < PRE * A2_CHUNKS; c += kNW) lds_dma_1k(a2_rsrc, lane * 16, c * 1024, l_a2 + c * 1024);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA pieces above
     __syncthreads();
 
     // output-layer A fragments: output row o = lane & 31 < 8 reads its 16 B, the others a zero line
@@ -289,6 +294,8 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     }
 
     int bsel = 0;  // ring buffer of the current W2 tile (STREAM)
+    const uint64_t stamp_c0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memtime() : 0;
+    const uint64_t stamp_r0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
     for (int t = 0; t < g.H; ++t) {
         // ---- inputs: record S[t]; x = normalised (state, action) ------------------------------
         float xs[kMaxIn];
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < kMaxKS1; ++ks)
-                if (ks < g.ks1 && !(SSC_DYN_ABLATE & 4)) {  // block-uniform
+                if (ks < g.ks1) {  // block-uniform
                     const bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a1 + ((ks * UT + ut) * 64 + lane) * 16);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[ks], acc, 0, 0, 0);
                 }
@@ -371,21 +378,27 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         // ---- hidden layer 2 (+ output layer fused per tile) -------------------------------------
         f32x16 acc3 = lds_tile16(l_b3 + half * 16);
         if (NFC == 2) {
-#pragma unroll 1
-            for (int jt = 0; jt < UT; ++jt) {
-                const int tl = t * UT + jt;  // linear tile counter == barrier counter (STREAM)
+            // One 32-unit output tile jt of hidden layer 2: 2*UT k-steps over the W2^T fragments in `buf`,
+            // then ReLU and the two output-layer MFMAs.  The body is ONE basic block (no branch between the
+            // k-steps), so hipcc's s_waitcnt insertion keeps counted lgkmcnt waits and the 4-deep fragment
+            // ring really is 4 deep; a branch inside (e.g. a conditional LDS-DMA) degrades every following
+            // wait to lgkmcnt(0) and exposes the LDS latency at each k-step.
+            // STREAM: the ring of 3 LDS slots holds tiles tl (being read), tl+1 (landed) and the one in
+            // flight.  Barrier number tl (end of tile tl for group 0, middle of tile tl for group 1) retires
+            // every read of tile tl-1 and publishes tile tl+1; after its barrier a wave issues its PPW pieces
+            // of tile tl+2 into the slot of tile tl-1, spread over the following k-steps so that their issue
+            // cost hides under MFMAs.  The issue is unconditional: past the last tile it re-loads a tile
+            // nobody reads, and group 0 in tile 0 re-loads the (identical) bytes of tile 1.
+            auto tile_body = [&](auto group_tag, int jt) {
+                constexpr int GROUP = decltype(group_tag)::value;
                 const unsigned char *buf = l_a2 + (STREAM ? bsel : jt) * A2_TILE;
-                // STREAM: the ring holds tiles tl (being read), tl+1 (landed) and the one in flight.  Barrier
-                // number tl (end of tile tl for group 0, middle of tile tl for group 1) retires every read of
-                // tile tl-1 and publishes tile tl+1; after it this wave issues its pieces of tile tl+2 into
-                // the slot of tile tl-1, spread over the following k-steps so their issue cost hides under MFMAs.
-                int dma_jn = -1, dma_slot = 0;
-                if (STREAM && group == 0 && tl >= 1 && tl + 1 < n_tiles && !(SSC_DYN_ABLATE & 2)) {
-                    dma_jn = (jt + 1) & (UT - 1);                  // group 0 passed barrier tl-1 just before this tile
-                    dma_slot = bsel == 2 ? 0 : bsel + 1;
-                }
-                const f32x16 c2 = lds_tile16(l_b2 + (jt * 2 + half) * 16);
-                f32x16 acc2 = c2;
+                // group 0 passed barrier tl-1 just before this tile -> tile tl+1; group 1 passes barrier tl
+                // in the middle of this tile -> tile tl+2
+                const int dma_jn = (jt + 1 + GROUP) & (UT - 1);
+                const int dma_slot = (bsel + 1 + GROUP) % 3;
+                const int dma_src = dma_jn * A2_TILE + wave * 1024;
+                unsigned char *dma_dst = l_a2 + dma_slot * A2_TILE + wave * 1024;
+                f32x16 acc2 = lds_tile16(l_b2 + (jt * 2 + half) * 16);
                 constexpr int NK = UT * 2;
                 constexpr int RING = (NK >= 4) ? 4 : 2;   // fragment reads in flight per wave
                 constexpr int MID = NK / 2 - 1;
@@ -400,23 +413,15 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                         ring[i % RING] = *reinterpret_cast<const bf16x8 *>(buf + ((i + RING) * 64 + lane) * 16);
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[i >> 1][i & 1], acc2, 0, 0, 0);
                     if (STREAM) {
-                        // piece p of this wave goes out after k-step 1 + p*DSTRIDE of the half tile that follows
-                        // the wave's barrier
-                        const int ih = (i > MID) ? i - MID - 1 : i;
+                        // piece p goes out after k-step 1 + p*DSTRIDE of the half tile that follows the barrier
+                        const int ih = GROUP ? i - MID - 1 : i;
                         if (ih >= 1 && (ih - 1) % DSTRIDE == 0 && (ih - 1) / DSTRIDE < PPW) {
                             const int p = (ih - 1) / DSTRIDE;
-                            if (dma_jn >= 0 && (group == (i > MID ? 1 : 0))) {
-                                const int c = wave + p * kNW;
-                                glds_1k(a2_src + (size_t)dma_jn * A2_TILE + c * 1024 + lane * 16,
-                                        l_a2 + dma_slot * A2_TILE + c * 1024);
-                            }
+                            lds_dma_1k(a2_rsrc, lane * 16, dma_src + p * kNW * 1024, dma_dst + p * kNW * 1024);
                         }
-                        if (i == MID && group == 1) {
-                            if (!(SSC_DYN_ABLATE & 1)) __syncthreads();  // barrier tl of group 1
-                            if (tl + 2 < n_tiles && !(SSC_DYN_ABLATE & 2)) {
-                                dma_jn = (jt + 2) & (UT - 1);
-                                dma_slot = bsel == 0 ? 2 : bsel - 1;      // (bsel + 2) % 3
-                            }
+                        if (GROUP == 1 && i == MID) {  // barrier tl of group 1
+                            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tl+1 landed
+                            __syncthreads();
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -425,16 +430,22 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 const bf16x8 a31 = *reinterpret_cast<const bf16x8 *>(a3_lane + (jt * 2 + 1) * a3_step);
                 bf16x8 f0, f1;
                 relu_to_frags(acc2, f0, f1);
-                if (SSC_DYN_ABLATE & 8) {
-                    acc3[0] += (float)f0[0] + (float)f1[0];
-                } else {
-                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, f0, acc3, 0, 0, 0);
-                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, f1, acc3, 0, 0, 0);
-                }
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, f0, acc3, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, f1, acc3, 0, 0, 0);
                 if (STREAM) {
-                    if (group == 0 && !(SSC_DYN_ABLATE & 1)) __syncthreads();  // barrier tl of group 0
+                    if (GROUP == 0) {  // barrier tl of group 0
+                        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tl+1 landed
+                        __syncthreads();
+                    }
                     bsel = bsel == 2 ? 0 : bsel + 1;
                 }
+            };
+            if (!STREAM || group == 0) {
+#pragma unroll 1
+                for (int jt = 0; jt < UT; ++jt) tile_body(std::integral_constant<int, 0>{}, jt);
+            } else {
+#pragma unroll 1
+                for (int jt = 0; jt < UT; ++jt) tile_body(std::integral_constant<int, 1>{}, jt);
             }
         } else {
 #pragma unroll
@@ -469,6 +480,15 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
 #pragma unroll
             for (int k = 0; k < SSC_MAX_STATE; ++k)
                 if (k < g.d) g.S[((int64_t)g.H * g.m + row) * g.d + k] = st[k];  // :240
+        }
+    }
+    // group 1 issued LDS-DMA after its last barrier: it must land before this workgroup's LDS is released
+    if (STREAM) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (SSC_DYN_ABLATE & 16) {
+        const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c0, dr = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        if (tid == 0) {
+            uint32_t *o = reinterpret_cast<uint32_t *>(g.S) + 4 * blockIdx.x;
+            o[0] = (uint32_t)dc; o[1] = (uint32_t)(dc >> 32); o[2] = (uint32_t)dr; o[3] = (uint32_t)(dr >> 32);
         }
     }
 }

@@ -1,0 +1,27 @@
+"""In-kernel clock of dyn_mfma_sim_kernel (diagnostic build -DSSC_DYN_ABLATE=16, tools/_build/libssc_clk.so):
+after ~2 s of back-to-back launches, Delta s_memtime / Delta s_memrealtime x 100 MHz per block."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import smartstartcontinuous_amd._ffi as F
+F.LIB_PATH = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "tools/_build/libssc_clk.so")
+import torch, numpy as np, time
+from exp_nav import make
+dims, M, H = (4, 500, 500, 3), 65536, 20
+model, d, a = make(dims)
+A = torch.rand((M, H, a), device="cuda") * 2 - 1
+s0 = torch.randn((M, d), device="cuda") * 0.3
+S = torch.empty((H + 1, M, d), device="cuda")
+t0 = time.time()
+while time.time() - t0 < 2.0:
+    for _ in range(50):
+        model.do_forward_sim(s0, A, precision="bf16_mfma", out=S)
+    torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); model.do_forward_sim(s0, A, precision="bf16_mfma", out=S); e1.record(); torch.cuda.synchronize()
+st = S.view(torch.int32).flatten()[: 4 * (M // 256)].cpu().numpy().astype(np.uint32).reshape(-1, 4).astype(np.uint64)
+dc = st[:, 0] | (st[:, 1] << np.uint64(32)); dr = st[:, 2] | (st[:, 3] << np.uint64(32))
+clk = dc / dr * 100.0
+mf = 560 * 2 * 32 * H   # MFMA pipe cycles per SIMD for the step loop (2 waves x 560 MFMAs x 32 cyc per step)
+print("launch %.4f ms; blocks %d; step-loop cycles median %.0f (%.0f per step); realtime median %.1f us; clock median %.0f MHz (min %.0f max %.0f); MFMA floor %.0f cyc -> pipe busy %.1f %%"
+      % (e0.elapsed_time(e1), len(dc), np.median(dc), np.median(dc) / H, np.median(dr) / 100.0, np.median(clk), clk.min(), clk.max(), mf, 100.0 * mf / np.median(dc)))
