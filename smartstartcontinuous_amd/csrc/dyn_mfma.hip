@@ -44,6 +44,7 @@ constexpr int kNW = kDynThreads / 64;
 constexpr int kMaxIn = 12;        // network inputs (state + action)
 constexpr int kMaxKS1 = 3;        // layer-1 bf16 k-steps of 16 slots: 2 bias slots + 3 per input
 // Diagnostic builds for tools/exp_dyn_clock.py (results are WRONG when set; never in libssc.so):
+// 32 hidden k-steps on the 16x16x32 MFMA shape (clock experiment, wrong results);
 // 16 clock stamps: every block overwrites S[4*block .. +3] with {d_memtime, d_memrealtime} of its step loop
 #ifndef SSC_DYN_ABLATE
 #define SSC_DYN_ABLATE 0
@@ -104,6 +105,7 @@ static DynPack make_pack(int UT, int nfc) {
 struct DynNet {
     const float *W1, *b1, *W2, *b2, *W3, *b3;  // W3/b3 = output layer; W2/b2 unused when nfc == 1
     int in, depth, out, nfc;
+    bool biask;  // b2 in the spare k slots depth, depth+1 of the hidden contraction (needs depth + 2 <= 32*UT)
 };
 
 __device__ __forceinline__ __bf16 bf16_head(float v) { return (__bf16)v; }
@@ -129,8 +131,13 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
         const int j = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 1;
         const int ut = (int)((e >> 10) % UT), jt = (int)((e >> 10) / UT);
         const int u = frag_unit(ut, s, lane >> 5, j), col = jt * 32 + (lane & 31);
-        const float v = (u < n.depth && col < n.depth) ? n.W2[(int64_t)u * n.depth + col] : 0.0f;
-        reinterpret_cast<__bf16 *>(ws + pk.a2)[e] = (__bf16)v;
+        __bf16 v = (__bf16)0.0f;
+        if (col < n.depth) {
+            if (u < n.depth) v = (__bf16)n.W2[(int64_t)u * n.depth + col];
+            else if (n.biask && u == n.depth) v = bf16_head(n.b2[col]);
+            else if (n.biask && u == n.depth + 1) v = bf16_resid(n.b2[col]);
+        }
+        reinterpret_cast<__bf16 *>(ws + pk.a2)[e] = v;
         return;
     }
     e -= n_a2;
@@ -156,6 +163,8 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
                     v = (c == 2) ? bf16_resid(w) : bf16_head(w);
                 }
             }
+        } else if (n.biask && unit < n.depth + 2 && q == 0) {
+            v = (__bf16)1.0f;  // hidden units depth, depth+1 == ReLU(1 * 1) == 1: the carriers of b2
         }
         reinterpret_cast<__bf16 *>(ws + pk.a1)[e] = v;
         return;
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
     if (e < n_b) {  // b2: [ut][half][reg]
         const int reg = e & 15, half = (e >> 4) & 1, ut = (int)(e >> 5);
         const int u = ut * 32 + acc_row32(reg, half);
-        reinterpret_cast<float *>(ws + pk.b2)[e] = (n.nfc == 2 && u < n.depth) ? n.b2[u] : 0.0f;
+        reinterpret_cast<float *>(ws + pk.b2)[e] = (n.nfc == 2 && !n.biask && u < n.depth) ? n.b2[u] : 0.0f;
         return;
     }
     e -= n_b;
@@ -230,7 +239,9 @@ __device__ __forceinline__ void split_bf16(float x, uint32_t &hi, uint32_t &lo) 
 template <int UT, int NFC>
 __host__ __device__ constexpr int dyn_a2_bufs() { return NFC == 2 ? (UT <= 4 ? UT : 3) : 0; }
 
-template <int UT, int NFC>
+// BIASK: b2 rides in two spare k slots of the hidden contraction (hidden units depth, depth+1 are the constant
+// 1; their W2^T rows hold bf16 head and residual of b2) instead of being the accumulator's C-in.
+template <int UT, int NFC, bool BIASK>
 __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int A2_TILE = UT * 2048;  // one 32-unit output tile of W2^T fragments
@@ -293,7 +304,14 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         for (int k = 0; k < SSC_MAX_STATE; ++k) st[k] = (k < g.d) ? g.s0[(g.s0_rows == 1 ? 0 : rowc) * g.d + k] : 0.0f;
     }
 
-    int bsel = 0;  // ring buffer of the current W2 tile (STREAM)
+    int bsel = 0;  // LDS slot of the current W2 tile (STREAM)
+    constexpr int NK = UT * 2;                // k-steps per hidden tile
+    constexpr int RING = (NK >= 4) ? 4 : 2;   // W2^T fragment reads in flight per wave
+    bf16x8 ring[RING];
+    if (NFC == 2) {
+#pragma unroll
+        for (int q = 0; q < RING; ++q) ring[q] = *reinterpret_cast<const bf16x8 *>(l_a2 + (q * 64 + lane) * 16);
+    }
     const uint64_t stamp_c0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memtime() : 0;
     const uint64_t stamp_r0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
     for (int t = 0; t < g.H; ++t) {
@@ -378,48 +396,64 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         // ---- hidden layer 2 (+ output layer fused per tile) -------------------------------------
         f32x16 acc3 = lds_tile16(l_b3 + half * 16);
         if (NFC == 2) {
-            // One 32-unit output tile jt of hidden layer 2: 2*UT k-steps over the W2^T fragments in `buf`,
-            // then ReLU and the two output-layer MFMAs.  The body is ONE basic block (no branch between the
-            // k-steps), so hipcc's s_waitcnt insertion keeps counted lgkmcnt waits and the 4-deep fragment
-            // ring really is 4 deep; a branch inside (e.g. a conditional LDS-DMA) degrades every following
-            // wait to lgkmcnt(0) and exposes the LDS latency at each k-step.
-            // STREAM: the ring of 3 LDS slots holds tiles tl (being read), tl+1 (landed) and the one in
-            // flight.  Barrier number tl (end of tile tl for group 0, middle of tile tl for group 1) retires
-            // every read of tile tl-1 and publishes tile tl+1; after its barrier a wave issues its PPW pieces
-            // of tile tl+2 into the slot of tile tl-1, spread over the following k-steps so that their issue
-            // cost hides under MFMAs.  The issue is unconditional: past the last tile it re-loads a tile
-            // nobody reads, and group 0 in tile 0 re-loads the (identical) bytes of tile 1.
+            // One 32-unit output tile jt of hidden layer 2: NK k-steps over the W2^T fragments of the current
+            // LDS slot, then ReLU and the two output-layer MFMAs.
+            //  * The body is ONE basic block (no branch between the k-steps), so hipcc's s_waitcnt insertion
+            //    keeps counted lgkmcnt waits and the fragment ring really stays RING deep.
+            //  * The fragment ring runs on ACROSS tiles: the last RING k-steps of a tile already fetch the
+            //    first fragments of the next one (and of the next step's first tile), so a tile starts with
+            //    its operands in registers; with BIASK the accumulator starts from the inline constant 0.
+            //  * STREAM: 3 LDS slots hold tiles tl (being read), tl+1 (landed) and the one in flight.
+            //    Barrier number tl -- taken in tile tl after k-step X0 by group 0 and X1 = X0 - NK/2 by group
+            //    1, which keeps the two waves of a SIMD half a tile out of phase -- retires every read of tile
+            //    tl-1 and publishes tile tl+1; after it a wave issues its PPW pieces of tile tl+2 into the
+            //    slot of tile tl-1, a few k-steps apart so that their issue cost hides under MFMAs.  The
+            //    issue is unconditional: past the last tile it re-loads a tile nobody reads, and group 0 in
+            //    tile 0 re-loads the (identical) bytes of tile 1.
             auto tile_body = [&](auto group_tag, int jt) {
                 constexpr int GROUP = decltype(group_tag)::value;
-                const unsigned char *buf = l_a2 + (STREAM ? bsel : jt) * A2_TILE;
-                // group 0 passed barrier tl-1 just before this tile -> tile tl+1; group 1 passes barrier tl
-                // in the middle of this tile -> tile tl+2
+                constexpr int X0 = NK - RING - 1, X1 = X0 - NK / 2;   // barrier k-step of group 0 / group 1
+                static_assert(!STREAM || (UT == 16 && X1 + 2 + 4 * (PPW - 1) < NK), "LDS-DMA issue slots");
+                const int nsel = STREAM ? (bsel == 2 ? 0 : bsel + 1) : ((jt + 1) & (UT - 1));
+                const unsigned char *buf = l_a2 + (STREAM ? bsel : jt) * A2_TILE + lane * 16;
+                const unsigned char *nbuf = l_a2 + nsel * A2_TILE + lane * 16;
+                // group 0 is past barrier tl-1 -> its pieces of tile tl+1; group 1 passes barrier tl at X1 ->
+                // pieces of tile tl+2
                 const int dma_jn = (jt + 1 + GROUP) & (UT - 1);
                 const int dma_slot = (bsel + 1 + GROUP) % 3;
                 const int dma_src = dma_jn * A2_TILE + wave * 1024;
                 unsigned char *dma_dst = l_a2 + dma_slot * A2_TILE + wave * 1024;
-                f32x16 acc2 = lds_tile16(l_b2 + (jt * 2 + half) * 16);
-                constexpr int NK = UT * 2;
-                constexpr int RING = (NK >= 4) ? 4 : 2;   // fragment reads in flight per wave
-                constexpr int MID = NK / 2 - 1;
-                constexpr int DSTRIDE = (NK / 2 - 2) / PPW > 0 ? (NK / 2 - 2) / PPW : 1;
-                bf16x8 ring[RING];
-#pragma unroll
-                for (int q = 0; q < RING; ++q) ring[q] = *reinterpret_cast<const bf16x8 *>(buf + (q * 64 + lane) * 16);
+                f32x16 acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (!BIASK) acc2 = lds_tile16(l_b2 + (jt * 2 + half) * 16);
 #pragma unroll
                 for (int i = 0; i < NK; ++i) {
                     const bf16x8 a = ring[i % RING];
-                    if (i + RING < NK)
-                        ring[i % RING] = *reinterpret_cast<const bf16x8 *>(buf + ((i + RING) * 64 + lane) * 16);
+                    ring[i % RING] = (i + RING < NK) ? *reinterpret_cast<const bf16x8 *>(buf + (i + RING) * 1024)
+                                                     : *reinterpret_cast<const bf16x8 *>(nbuf + (i + RING - NK) * 1024);
+#if SSC_DYN_ABLATE & 32   // timing only: the same k-step as two v_mfma_f32_16x16x32_bf16 (operand layout NOT adapted)
+                    {
+                        f32x4 q0 = {acc2[0], acc2[1], acc2[2], acc2[3]}, q1 = {acc2[4], acc2[5], acc2[6], acc2[7]};
+                        f32x4 q2 = {acc2[8], acc2[9], acc2[10], acc2[11]}, q3 = {acc2[12], acc2[13], acc2[14], acc2[15]};
+                        if (i & 1) {
+                            q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, h1f[i >> 1][1], q2, 0, 0, 0);
+                            q3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, h1f[(i >> 1) ^ 1][1], q3, 0, 0, 0);
+                        } else {
+                            q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, h1f[i >> 1][0], q0, 0, 0, 0);
+                            q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, h1f[(i >> 1) ^ 1][0], q1, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { acc2[e] = q0[e]; acc2[4 + e] = q1[e]; acc2[8 + e] = q2[e]; acc2[12 + e] = q3[e]; }
+                    }
+#else
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[i >> 1][i & 1], acc2, 0, 0, 0);
+#endif
                     if (STREAM) {
-                        // piece p goes out after k-step 1 + p*DSTRIDE of the half tile that follows the barrier
-                        const int ih = GROUP ? i - MID - 1 : i;
-                        if (ih >= 1 && (ih - 1) % DSTRIDE == 0 && (ih - 1) / DSTRIDE < PPW) {
-                            const int p = (ih - 1) / DSTRIDE;
+                        const int i0 = GROUP ? X1 + 2 : 1;  // first issue slot after this group's barrier
+                        if (i >= i0 && (i - i0) % 4 == 0 && (i - i0) / 4 < PPW) {
+                            const int p = (i - i0) / 4;
                             lds_dma_1k(a2_rsrc, lane * 16, dma_src + p * kNW * 1024, dma_dst + p * kNW * 1024);
                         }
-                        if (GROUP == 1 && i == MID) {  // barrier tl of group 1
+                        if (i == (GROUP ? X1 : X0)) {  // barrier tl
                             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tl+1 landed
                             __syncthreads();
                         }
@@ -432,13 +466,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 relu_to_frags(acc2, f0, f1);
                 acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, f0, acc3, 0, 0, 0);
                 acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, f1, acc3, 0, 0, 0);
-                if (STREAM) {
-                    if (GROUP == 0) {  // barrier tl of group 0
-                        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tl+1 landed
-                        __syncthreads();
-                    }
-                    bsel = bsel == 2 ? 0 : bsel + 1;
-                }
+                if (STREAM) bsel = nsel;
             };
             if (!STREAM || group == 0) {
 #pragma unroll 1
@@ -511,11 +539,11 @@ size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp) {
     return make_pack(tiles_for(mlp->dims[1]), nfc).total;
 }
 
-template <int UT, int NFC>
+template <int UT, int NFC, bool BIASK>
 static int launch_sim(const DynSimArgs &g, hipStream_t s) {
     const size_t lds = (size_t)dyn_a2_bufs<UT, NFC>() * UT * 2048 + (size_t)g.ks1 * UT * 1024 + (size_t)UT * 512 + 16 +
                        (size_t)UT * 128 + 128 + 192;
-    auto kern = dyn_mfma_sim_kernel<UT, NFC>;
+    auto kern = dyn_mfma_sim_kernel<UT, NFC, BIASK>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -534,6 +562,7 @@ static int run_mfma(const ssc_mlp_desc *mlp, const ssc_norm *norm, DynSimArgs &g
     const DynPack pk = make_pack(UT, nfc);
     DynNet n;
     n.in = mlp->dims[0]; n.depth = depth; n.out = mlp->dims[mlp->n_layers]; n.nfc = nfc;
+    n.biask = (nfc == 2) && (depth + 2 <= 32 * UT);
     n.W1 = mlp->W[0]; n.b1 = mlp->b[0];
     n.W2 = (nfc == 2) ? mlp->W[1] : nullptr; n.b2 = (nfc == 2) ? mlp->b[1] : nullptr;
     n.W3 = mlp->W[nfc]; n.b3 = mlp->b[nfc];
@@ -547,9 +576,10 @@ static int run_mfma(const ssc_mlp_desc *mlp, const ssc_norm *norm, DynSimArgs &g
     g.a1 = ws + pk.a1; g.a2 = ws + pk.a2; g.a3 = ws + pk.a3;
     g.b2 = reinterpret_cast<const float *>(ws + pk.b2); g.b3 = reinterpret_cast<const float *>(ws + pk.b3);
     g.nm = reinterpret_cast<const float *>(ws + pk.nm);
-#define SSC_DYN_CASE(U, F) if (UT == U && nfc == F) return launch_sim<U, F>(g, s)
-    SSC_DYN_CASE(1, 1); SSC_DYN_CASE(4, 1); SSC_DYN_CASE(16, 1);
-    SSC_DYN_CASE(1, 2); SSC_DYN_CASE(4, 2); SSC_DYN_CASE(16, 2);
+#define SSC_DYN_CASE(U, F, B) if (UT == U && nfc == F && n.biask == B) return launch_sim<U, F, B>(g, s)
+    SSC_DYN_CASE(1, 1, false); SSC_DYN_CASE(4, 1, false); SSC_DYN_CASE(16, 1, false);
+    SSC_DYN_CASE(1, 2, false); SSC_DYN_CASE(4, 2, false); SSC_DYN_CASE(16, 2, false);
+    SSC_DYN_CASE(1, 2, true); SSC_DYN_CASE(4, 2, true); SSC_DYN_CASE(16, 2, true);
 #undef SSC_DYN_CASE
     return set_error(SSC_EUNSUPPORTED, "dyn_mfma: no kernel for UT=%d nfc=%d", UT, nfc);
 }
