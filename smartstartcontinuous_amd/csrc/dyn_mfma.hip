@@ -8,24 +8,24 @@
 // NOTHING but the [H+1][m][d] trajectory (the result) and the per-step actions touch HBM.
 //
 // Mapping to CDNA4:
-//   * one wave owns two 32-row tiles (64 rows); a block = 4 waves = 256 rows = one CU's worth at
-//     one wave per SIMD (the 512-entry register file holds the first hidden layer of both tiles as
-//     bf16 fragments); the waves of a block share the weight fragments through LDS and every
-//     fragment read from LDS feeds two MFMAs.
-//   * every layer is computed TRANSPOSED: D[unit][row] = W^T[unit][k] * H[k][row], i.e. the
-//     weights are the MFMA A operand and the activations the B operand.  The 32x32 accumulator
-//     tile of a layer (unit on the register index, row on the lane) is therefore already in the
-//     B-operand layout of the next layer: ReLU + v_cvt_pk_bf16_f32 in registers and it is fed
-//     straight back -- no LDS round trip for activations, no lane movement
+//   * a block = 512 threads = 8 waves x 32 rows; waves w and w+4 share a SIMD (2 waves per SIMD, 256
+//     VGPRs each).  A wave holds the first hidden layer of its 32 rows as bf16 MFMA fragments in
+//     registers (128 VGPRs at depth 512); the waves of a block share the weight fragments through LDS.
+//   * every layer is computed TRANSPOSED: D[unit][row] = W^T[unit][k] * H[k][row], i.e. the weights
+//     are the MFMA A operand and the activations the B operand.  All contractions run on
+//     v_mfma_f32_16x16x32_bf16 (on this chip the 16x16x32 shape holds a ~6.5 % higher clock than
+//     32x32x16 at equal cycles: tools/exp_dyn_clock.py).  Two 16x16 accumulator tiles of a layer (units
+//     32p..32p+15 and 32p+16..32p+31 of 16 rows) are -- after ReLU + v_cvt_pk_bf16_f32 in registers --
+//     exactly ONE B fragment (32 k x 16 rows) of the next layer under a fixed permutation of k that is
+//     folded into the packed weights: activations never touch LDS and no lane moves
 //     (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand").
-//   * layer 1 (K = state+action <= 12) runs on the exact-fp32 MFMA v_mfma_f32_32x32x2_f32 with the
-//     bias as C-in; hidden and output layers on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
-//   * layer-2 output tiles are consumed immediately by the output layer (2 more MFMAs per tile),
-//     so the second hidden activation is never materialised: live registers = first hidden layer
-//     as bf16 B fragments (UT*8 VGPRs) + two accumulator tiles.
-//   * W2 is pre-packed once per call into fragment order (bf16, k order matched to the accumulator
-//     layout) and streamed L2 -> registers -> LDS one 32-unit output tile (UT*2 KB) at a time,
-//     double buffered, one barrier per tile.
+//   * layer 1 (K = state+action <= 12) also runs on the bf16 MFMA at fp32-level accuracy by splitting
+//     x and W1 into bf16 head + bf16 residual (3 products per input, bias in two more k slots).
+//   * layer-2 output tiles (32 units) are consumed immediately by the output layer (one more MFMA per
+//     16 rows), so the second hidden activation is never materialised.
+//   * W2 is packed once per call into fragment order (bf16) and streamed L2 -> LDS by LDS-DMA one
+//     32-unit output tile (32 KiB at depth 512) at a time through a ring of 3 slots, one barrier per
+//     tile, the two waves of a SIMD half a tile out of phase (details at tile_body below).
 #include <float.h>
 #include <type_traits>
 
@@ -34,17 +34,17 @@
 
 namespace ssc {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t vu32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kDynRows = 256;     // rows per block: 8 waves x one 32-row tile
-constexpr int kDynThreads = 512;  // waves w and w+4 share a SIMD (2 waves per SIMD, 256 VGPRs each)
+constexpr int kDynRows = 256;     // rows per block: 8 waves x two 16-row MFMA column tiles
+constexpr int kDynThreads = 512;
 constexpr int kNW = kDynThreads / 64;
 constexpr int kMaxIn = 12;        // network inputs (state + action)
-constexpr int kMaxKS1 = 3;        // layer-1 bf16 k-steps of 16 slots: 2 bias slots + 3 per input
+constexpr int kMaxKS1 = 2;        // layer-1 k-steps of 32 slots: 2 bias slots + 3 per input
 // Diagnostic builds for tools/exp_dyn_clock.py (results are WRONG when set; never in libssc.so):
-// 32 hidden k-steps on the 16x16x32 MFMA shape (clock experiment, wrong results);
 // 16 clock stamps: every block overwrites S[4*block .. +3] with {d_memtime, d_memrealtime} of its step loop
 #ifndef SSC_DYN_ABLATE
 #define SSC_DYN_ABLATE 0
@@ -63,27 +63,25 @@ __device__ __forceinline__ void lds_dma_1k(__amdgpu_buffer_rsrc_t rsrc, int lane
         16, lane_off, soffset, 0, 0);
 }
 
-__device__ __forceinline__ int acc_row32(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
-// hidden unit carried by k slot (8*half + j) of bf16 k-step (ut, s) when the B operand is a converted
-// 32x32 accumulator tile: registers 8s..8s+7 of unit tile ut
-__device__ __forceinline__ int frag_unit(int ut, int s, int half, int j) {
-    return ut * 32 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
-}
+// v_mfma_f32_16x16x32_bf16: lane l holds A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], j < 8, and
+// D[row 4(l>>4)+r][col l&15], r < 4.  Two D tiles (units 32p + 4g + r and 32p + 16 + 4g + r, g = l>>4) packed
+// to bf16 are the 8 k values of lane group g in k-step p of the next layer: k slot (8g + j) carries unit
+__host__ __device__ __forceinline__ int frag_unit(int p, int g, int j) { return 32 * p + 16 * (j >> 2) + 4 * g + (j & 3); }
 
 // Layer 1 on the bf16 MFMA at fp32-level accuracy: x = xh + xl, w = wh + wl (bf16 head + bf16 residual),
 // x*w ~= xh*wh + xl*wh + xh*wl (dropped xl*wl <= 2^-16 |x w|; products of bf16 pairs are exact in the
-// fp32 accumulator).  K slots of the layer-1 contraction (16 per k-step):
+// fp32 accumulator).  K slots of the layer-1 contraction (32 per k-step):
 //   slot 0: 1 * bf16(b1)   slot 1: 1 * residual(b1)   slot 2+3i+{0,1,2}: {xh_i*wh_i, xl_i*wh_i, xh_i*wl_i}
-__host__ __device__ __forceinline__ int l1_ksteps(int in) { return (2 + 3 * in + 15) / 16; }
+__host__ __device__ __forceinline__ int l1_ksteps(int in) { return (2 + 3 * in + 31) / 32; }
 
-// Packed weight image in the workspace (all offsets in bytes, 256-aligned)
+// Packed weight image in the workspace (all offsets in bytes, 256-aligned); UT = 32-unit tiles of a hidden layer
 struct DynPack {
-    size_t a2;   // bf16 [UT jt][UT ut][2 s][64 lane][8]   W2^T fragments (NFC == 2)
-    size_t a3;   // bf16 [UT ut][2 s][2 half][8 o][8]       Wout^T fragments, only the 8 possible output rows
-    size_t a1;   // bf16 [KS1][UT ut][64 lane][8]           layer-1 fragments (bias + split W1, see above)
-    size_t b2;   // f32  [UT][2 half][16]                   b2 in accumulator layout
-    size_t b3;   // f32  [2][16]
-    size_t nm;   // f32  [6][8]  mean_x std_x mean_y std_y mean_z std_z
+    size_t a2;   // bf16 [UT jt][2*UT f = 2p+mh][64 lane][8]  W2^T fragments: units 32jt+16mh+(lane&15), k-step p (NFC == 2)
+    size_t a3;   // bf16 [UT p][4 g][8 o][8]                  Wout^T fragments, only the 8 possible output rows
+    size_t a1;   // bf16 [KS1][2*UT mt][64 lane][8]           layer-1 fragments (bias + split W1, see above)
+    size_t b2;   // f32  [UT jt][2 mh][4 g][4 r]              b2 in accumulator layout (when not in the k slots)
+    size_t b3;   // f32  [4 g][4 r]
+    size_t nm;   // f32  [6][8]  mean_x 1/std_x mean_y 1/std_y mean_z std_z
     size_t total;
 };
 
@@ -93,10 +91,10 @@ static DynPack make_pack(int UT, int nfc) {
     DynPack p;
     size_t o = 0;
     p.a2 = o; o += al256(nfc == 2 ? (size_t)UT * UT * 2 * 64 * 8 * 2 : 0);
-    p.a3 = o; o += al256((size_t)UT * 2 * 2 * 8 * 8 * 2);
-    p.a1 = o; o += al256((size_t)kMaxKS1 * UT * 64 * 8 * 2);
+    p.a3 = o; o += al256((size_t)UT * 4 * 8 * 8 * 2);
+    p.a1 = o; o += al256((size_t)kMaxKS1 * 2 * UT * 64 * 8 * 2);
     p.b2 = o; o += al256((size_t)UT * 32 * 4);
-    p.b3 = o; o += al256(32 * 4);
+    p.b3 = o; o += al256(16 * 4);
     p.nm = o; o += al256(48 * 4);
     p.total = o;
     return p;
@@ -117,20 +115,21 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
     if (gid < 48) {
         const int q = (int)gid >> 3, k = (int)gid & 7;
         float v = 0.0f;
-        if (q == 0) v = nm.mean_x[k]; else if (q == 1) v = nm.std_x[k];
-        else if (q == 2) v = nm.mean_y[k & 3]; else if (q == 3) v = nm.std_y[k & 3];
+        // 1/std (std == 0 -> inf) so that the z-score is one multiply in the kernel (zscore())
+        if (q == 0) v = nm.mean_x[k]; else if (q == 1) v = 1.0f / nm.std_x[k];
+        else if (q == 2) v = nm.mean_y[k & 3]; else if (q == 3) v = 1.0f / nm.std_y[k & 3];
         else if (q == 4) v = nm.mean_z[k]; else v = nm.std_z[k];
         reinterpret_cast<float *>(ws + pk.nm)[gid] = v;
     }
     const int64_t n_a2 = (n.nfc == 2) ? (int64_t)UT * UT * 2 * 64 * 8 : 0;
-    const int64_t n_a3 = (int64_t)UT * 2 * 2 * 8 * 8;
-    const int64_t n_a1 = (int64_t)kMaxKS1 * UT * 64 * 8;
+    const int64_t n_a3 = (int64_t)UT * 4 * 8 * 8;
+    const int64_t n_a1 = (int64_t)kMaxKS1 * 2 * UT * 64 * 8;
     const int64_t n_b = (int64_t)UT * 32;
     int64_t e = gid;
     if (e < n_a2) {
-        const int j = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 1;
-        const int ut = (int)((e >> 10) % UT), jt = (int)((e >> 10) / UT);
-        const int u = frag_unit(ut, s, lane >> 5, j), col = jt * 32 + (lane & 31);
+        const int j = e & 7, lane = (e >> 3) & 63;
+        const int f = (int)((e >> 9) % (2 * UT)), jt = (int)((e >> 9) / (2 * UT));
+        const int u = frag_unit(f >> 1, lane >> 4, j), col = jt * 32 + 16 * (f & 1) + (lane & 15);
         __bf16 v = (__bf16)0.0f;
         if (col < n.depth) {
             if (u < n.depth) v = (__bf16)n.W2[(int64_t)u * n.depth + col];
@@ -142,16 +141,16 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
     }
     e -= n_a2;
     if (e < n_a3) {
-        const int j = e & 7, o = (e >> 3) & 7, half = (e >> 6) & 1, s = (e >> 7) & 1, ut = (int)(e >> 8);
-        const int u = frag_unit(ut, s, half, j);
+        const int j = e & 7, o = (e >> 3) & 7, g = (e >> 6) & 3, p = (int)(e >> 8);
+        const int u = frag_unit(p, g, j);
         const float v = (u < n.depth && o < n.out) ? n.W3[(int64_t)u * n.out + o] : 0.0f;
         reinterpret_cast<__bf16 *>(ws + pk.a3)[e] = (__bf16)v;
         return;
     }
     e -= n_a3;
     if (e < n_a1) {
-        const int j = e & 7, lane = (e >> 3) & 63, ut = (int)((e >> 9) % UT), ks = (int)((e >> 9) / UT);
-        const int q = 16 * ks + 8 * (lane >> 5) + j, unit = ut * 32 + (lane & 31);
+        const int j = e & 7, lane = (e >> 3) & 63, mt = (int)((e >> 9) % (2 * UT)), ks = (int)((e >> 9) / (2 * UT));
+        const int q = 32 * ks + 8 * (lane >> 4) + j, unit = mt * 16 + (lane & 15);
         __bf16 v = (__bf16)0.0f;
         if (unit < n.depth) {
             if (q == 0) v = bf16_head(n.b1[unit]);
@@ -170,24 +169,22 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
         return;
     }
     e -= n_a1;
-    if (e < n_b) {  // b2: [ut][half][reg]
-        const int reg = e & 15, half = (e >> 4) & 1, ut = (int)(e >> 5);
-        const int u = ut * 32 + acc_row32(reg, half);
+    if (e < n_b) {  // b2: [jt][mh][g][r]
+        const int r = e & 3, g = (e >> 2) & 3, mh = (e >> 4) & 1, jt = (int)(e >> 5);
+        const int u = jt * 32 + 16 * mh + 4 * g + r;
         reinterpret_cast<float *>(ws + pk.b2)[e] = (n.nfc == 2 && !n.biask && u < n.depth) ? n.b2[u] : 0.0f;
         return;
     }
     e -= n_b;
-    if (e < 32) {
-        const int reg = e & 15, half = (e >> 4) & 1;
-        const int o = acc_row32(reg, half);
-        reinterpret_cast<float *>(ws + pk.b3)[e] = (o < n.out) ? n.b3[o] : 0.0f;
+    if (e < 16) {  // b3: [g][r], output row o = 4g + r
+        reinterpret_cast<float *>(ws + pk.b3)[e] = ((int)e < n.out) ? n.b3[e] : 0.0f;
     }
 }
 
 struct DynSimArgs {
     int64_t m;
     int32_t H, d, a;        // horizon, state dim, action dim (forward mode: H = 1)
-    int32_t in, out, ks1;   // network input / output width, layer-1 k-steps
+    int32_t in, out;        // network input / output width
     int32_t fwd_mode;       // 1: plain y = net(x) (ssc_mlp_forward); 0: forward simulation
     const float *s0;
     int64_t s0_rows;
@@ -197,32 +194,21 @@ struct DynSimArgs {
     const float *b2, *b3, *nm;
 };
 
-__device__ __forceinline__ float nan_to_num_div(float x, float mean, float stdv) {
-    const float v = (x - mean) / stdv;  // dynamics_model.py:228-229
-    if (isnan(v)) return 0.0f;
-    if (isinf(v)) return v > 0.0f ? FLT_MAX : -FLT_MAX;
-    return v;
+// np.nan_to_num((x - mean) / std) (dynamics_model.py:228-229) with inv = 1/std: 0/0 = 0 * inf = NaN -> 0;
+// x/0 = +-inf is clamped to the largest bf16 by split_bf16 (nan_to_num's +-max, as far as bf16 reaches).
+__device__ __forceinline__ float zscore(float x, float mean, float inv) {
+    const float v = (x - mean) * inv;
+    return (v != v) ? 0.0f : v;
 }
 
-__device__ __forceinline__ f32x16 lds_tile16(const float *p) {  // 16 consecutive floats -> accumulator init
-    const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
-    const f32x4 c = *reinterpret_cast<const f32x4 *>(p + 8), d = *reinterpret_cast<const f32x4 *>(p + 12);
-    f32x16 r;
-    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-    r[8] = c[0]; r[9] = c[1]; r[10] = c[2]; r[11] = c[3]; r[12] = d[0]; r[13] = d[1]; r[14] = d[2]; r[15] = d[3];
-    return r;
-}
-
-__device__ __forceinline__ void relu_to_frags(const f32x16 &acc, bf16x8 &f0, bf16x8 &f1) {
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 p0, p1;  // feedforward_network.py:19 (ReLU) fused with the bf16 convert: 2 values per 2 VALU ops
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        p0[j] = relu_pack_bf16(acc[2 * j], acc[2 * j + 1]);
-        p1[j] = relu_pack_bf16(acc[8 + 2 * j], acc[8 + 2 * j + 1]);
-    }
-    f0 = __builtin_bit_cast(bf16x8, p0);
-    f1 = __builtin_bit_cast(bf16x8, p1);
+// ReLU (feedforward_network.py:19) fused with the bf16 convert: two accumulator tiles -> one B fragment
+__device__ __forceinline__ bf16x8 relu_to_frag(const f32x4 &lo, const f32x4 &hi) {
+    i32x4 p;
+    p[0] = relu_pack_bf16(lo[0], lo[1]);
+    p[1] = relu_pack_bf16(lo[2], lo[3]);
+    p[2] = relu_pack_bf16(hi[0], hi[1]);
+    p[3] = relu_pack_bf16(hi[2], hi[3]);
+    return __builtin_bit_cast(bf16x8, p);
 }
 
 // bf16 head / residual of x as 16-bit patterns (round to nearest even, like the weights)
@@ -234,36 +220,45 @@ __device__ __forceinline__ void split_bf16(float x, uint32_t &hi, uint32_t &lo) 
     lo = __builtin_bit_cast(unsigned short, l);
 }
 
-// LDS carve (bytes): [a2: NBUF x UT*2048] [a1: ks1*UT*1024] [a3: UT*512] [zero 16] [b2 UT*128] [b3 128] [nm 192]
+__device__ __forceinline__ f32x4 mfma16(const bf16x8 &a, const bf16x8 &b, const f32x4 &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// LDS carve (bytes): [a2: NBUF x UT*2048] [a1: KS1*UT*2048] [a3: UT*512] [zero 16] [b2 UT*128] [b3 64] [nm 192]
 // W2 (NFC == 2): resident when it fits (UT <= 4: all UT tiles), otherwise streamed through a ring of 3.
 template <int UT, int NFC>
 __host__ __device__ constexpr int dyn_a2_bufs() { return NFC == 2 ? (UT <= 4 ? UT : 3) : 0; }
 
 // BIASK: b2 rides in two spare k slots of the hidden contraction (hidden units depth, depth+1 are the constant
 // 1; their W2^T rows hold bf16 head and residual of b2) instead of being the accumulator's C-in.
-template <int UT, int NFC, bool BIASK>
+// KIN: compile-time bound on the network inputs AND outputs (4 covers MountainCar 3->2 and Pendulum 4->3; 10 is
+// what one layer-1 k-step holds): the per-step input/normalisation/state code is unrolled KIN times with
+// block-uniform guards, and layer 1 runs KS1(KIN) k-steps (unused slots carry zero weights).
+template <int UT, int NFC, bool BIASK, int KIN>
 __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs g) {
+    constexpr int DS = KIN < SSC_MAX_STATE ? KIN : SSC_MAX_STATE;  // state / output registers per row
+    constexpr int KS1 = (2 + 3 * KIN + 31) / 32;                   // layer-1 k-steps compiled in
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int A2_TILE = UT * 2048;  // one 32-unit output tile of W2^T fragments
+    constexpr int MT = 2 * UT;          // 16-unit tiles of a hidden layer
+    constexpr int A2_TILE = UT * 2048;  // W2^T fragments of one 32-unit output tile: NF fragments of 1 KiB
     constexpr int NBUF = dyn_a2_bufs<UT, NFC>();
     constexpr bool STREAM = (NFC == 2) && (UT > 4);
     constexpr int A2_CHUNKS = A2_TILE / 1024;           // LDS-DMA pieces per tile
     constexpr int PPW = (A2_CHUNKS + kNW - 1) / kNW;    // pieces per wave per tile
     unsigned char *l_a2 = lds;
     unsigned char *l_a1 = l_a2 + NBUF * A2_TILE;
-    unsigned char *l_a3 = l_a1 + g.ks1 * UT * 1024;
+    unsigned char *l_a3 = l_a1 + KS1 * MT * 1024;
     unsigned char *l_zero = l_a3 + UT * 512;
     float *l_b2 = reinterpret_cast<float *>(l_zero + 16);
     float *l_b3 = l_b2 + UT * 32;
-    float *l_nm = l_b3 + 32;  // [6][8]
+    float *l_nm = l_b3 + 16;  // [6][8]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, half = lane >> 5;
-    // Waves 0-3 (group 0) and 4-7 (group 1) pair up on the SIMDs.  Group 1 takes the per-tile barrier in
-    // the MIDDLE of its tile, group 0 at the end: the two waves of a SIMD are then half a tile out of
-    // phase, and the tile-boundary work of one (ReLU, output MFMAs, bias/fragment refill) runs under the
-    // other's MFMA stream instead of both idling the matrix pipe together.
+    const int c = lane & 15, kg = lane >> 4;  // MFMA column (row of the batch tile) and k group of this lane
+    // Waves 0-3 (group 0) and 4-7 (group 1) pair up on the SIMDs; the groups take the per-tile barrier half a
+    // tile apart (tile_body), so the two waves of a SIMD stay out of phase and the tile-boundary work of one
+    // (ReLU, output MFMAs) runs under the other's MFMA stream instead of both idling the matrix pipe together.
     const int group = wave >> 2;
 
     // ---- stage the resident weights ------------------------------------------------------------
@@ -273,9 +268,9 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         for (int e = tid; e < UT * 512 / 16; e += kDynThreads) d3[e] = s3[e];
         const f32x4 *s1 = reinterpret_cast<const f32x4 *>(g.a1);
         f32x4 *d1 = reinterpret_cast<f32x4 *>(l_a1);
-        for (int e = tid; e < g.ks1 * UT * 1024 / 16; e += kDynThreads) d1[e] = s1[e];
+        for (int e = tid; e < KS1 * MT * 1024 / 16; e += kDynThreads) d1[e] = s1[e];
         for (int e = tid; e < UT * 32; e += kDynThreads) l_b2[e] = g.b2[e];
-        if (tid < 32) l_b3[tid] = g.b3[tid];
+        if (tid < 16) l_b3[tid] = g.b3[tid];
         if (tid < 48) l_nm[tid] = g.nm[tid];
         if (tid < 4) reinterpret_cast<float *>(l_zero)[tid] = 0.0f;
     }
@@ -285,28 +280,34 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     if (NFC == 2) {  // first W2^T tiles by LDS-DMA: everything when resident, tiles 0 and 1 of the ring otherwise
         constexpr int PRE = STREAM ? 2 : NBUF;
 #pragma unroll
-        for (int c = wave; c < PRE * A2_CHUNKS; c += kNW) lds_dma_1k(a2_rsrc, lane * 16, c * 1024, l_a2 + c * 1024);
+        for (int ch = wave; ch < PRE * A2_CHUNKS; ch += kNW) lds_dma_1k(a2_rsrc, lane * 16, ch * 1024, l_a2 + ch * 1024);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA pieces above
     __syncthreads();
 
-    // output-layer A fragments: output row o = lane & 31 < 8 reads its 16 B, the others a zero line
-    const unsigned char *a3_lane = (r < 8) ? l_a3 + (half * 8 + r) * 16 : l_zero;
-    const int a3_step = (r < 8) ? 256 : 0;
+    // output-layer A fragments: output row o = lane & 15 < 8 reads its 16 B, the others a zero line
+    const unsigned char *a3_lane = (c < 8) ? l_a3 + (kg * 8 + c) * 16 : l_zero;
+    const int a3_step = (c < 8) ? 512 : 0;
 
-    // ---- this lane's row ---------------------------------------------------------------------
-    const int64_t row = (int64_t)blockIdx.x * kDynRows + wave * 32 + r;
-    const bool valid = row < g.m;
-    const int64_t rowc = valid ? row : g.m - 1;
-    float st[SSC_MAX_STATE];
-    if (!g.fwd_mode) {
+    // ---- this lane's rows: one per 16-row column tile; the 4 k-group lanes of a row carry it redundantly ----
+    int64_t row[2], rowc[2];
+    bool valid[2];
+    float st[2][DS];
 #pragma unroll
-        for (int k = 0; k < SSC_MAX_STATE; ++k) st[k] = (k < g.d) ? g.s0[(g.s0_rows == 1 ? 0 : rowc) * g.d + k] : 0.0f;
+    for (int nt = 0; nt < 2; ++nt) {
+        row[nt] = (int64_t)blockIdx.x * kDynRows + wave * 32 + nt * 16 + c;
+        valid[nt] = row[nt] < g.m;
+        rowc[nt] = valid[nt] ? row[nt] : g.m - 1;
+        if (!g.fwd_mode) {
+#pragma unroll
+            for (int k = 0; k < DS; ++k)
+                st[nt][k] = (k < g.d) ? g.s0[(g.s0_rows == 1 ? 0 : rowc[nt]) * g.d + k] : 0.0f;
+        }
     }
 
     int bsel = 0;  // LDS slot of the current W2 tile (STREAM)
-    constexpr int NK = UT * 2;                // k-steps per hidden tile
-    constexpr int RING = (NK >= 4) ? 4 : 2;   // W2^T fragment reads in flight per wave
+    constexpr int NF = 2 * UT;                // W2^T fragments (ring entries) per hidden tile: k-step p = f>>1, half f&1
+    constexpr int RING = (NF >= 4) ? 4 : 2;   // fragment reads in flight per wave
     bf16x8 ring[RING];
     if (NFC == 2) {
 #pragma unroll
@@ -315,105 +316,114 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     const uint64_t stamp_c0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memtime() : 0;
     const uint64_t stamp_r0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
     for (int t = 0; t < g.H; ++t) {
-        // ---- inputs: record S[t]; x = normalised (state, action) ------------------------------
-        float xs[kMaxIn];
-        if (g.fwd_mode) {
+        // ---- inputs: record S[t]; layer-1 B fragments of x = normalised (state, action) ---------------
+        bf16x8 xf[2][KS1];
 #pragma unroll
-            for (int k = 0; k < kMaxIn; ++k) xs[k] = (k < g.in) ? g.A[rowc * g.in + k] : 0.0f;
-        } else {
-            if (valid && half == 0) {
+        for (int nt = 0; nt < 2; ++nt) {
+            float xs[KIN];
+            if (g.fwd_mode) {
 #pragma unroll
-                for (int k = 0; k < SSC_MAX_STATE; ++k)
-                    if (k < g.d) g.S[((int64_t)t * g.m + row) * g.d + k] = st[k];  // dynamics_model.py:225
-            }
+                for (int k = 0; k < KIN; ++k) xs[k] = (k < g.in) ? g.A[rowc[nt] * g.in + k] : 0.0f;
+            } else {
+                if (valid[nt] && kg == 0) {
 #pragma unroll
-            for (int k = 0; k < kMaxIn; ++k) {
-                float v = 0.0f;
-                if (k < g.d) {
-                    v = nan_to_num_div(st[k < SSC_MAX_STATE ? k : 0], l_nm[0 * 8 + (k & 7)], l_nm[1 * 8 + (k & 7)]);
-                } else if (k < g.in) {
-                    const int ai = (k - g.d) & 3;
-                    v = nan_to_num_div(g.A[(rowc * g.H + t) * g.a + ai], l_nm[2 * 8 + ai], l_nm[3 * 8 + ai]);
+                    for (int k = 0; k < DS; ++k)
+                        if (k < g.d) g.S[((int64_t)t * g.m + row[nt]) * g.d + k] = st[nt][k];  // dynamics_model.py:225
                 }
-                xs[k] = v;
+#pragma unroll
+                for (int k = 0; k < KIN; ++k) {
+                    float v = 0.0f;
+                    if (k < g.d) {
+                        v = zscore(st[nt][k < DS ? k : 0], l_nm[0 * 8 + (k & 7)], l_nm[1 * 8 + (k & 7)]);
+                    } else if (k < g.in) {
+                        const int ai = (k - g.d) & 3;
+                        v = zscore(g.A[(rowc[nt] * g.H + t) * g.a + ai], l_nm[2 * 8 + ai], l_nm[3 * 8 + ai]);
+                    }
+                    xs[k] = v;
+                }
             }
-        }
-        // ---- layer-1 B fragments: this lane's 8 k slots per k-step (slot layout above) -------------
-        bf16x8 xf[kMaxKS1];
-        {
-            uint32_t xh[kMaxIn], xl[kMaxIn];
+            uint32_t xh[KIN], xl[KIN];
 #pragma unroll
-            for (int k = 0; k < kMaxIn; ++k) split_bf16(xs[k], xh[k], xl[k]);
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            for (int k = 0; k < KIN; ++k) split_bf16(xs[k], xh[k], xl[k]);
+            // this lane's 8 k slots of k-step ks are slots 32 ks + 8 kg + j (slot layout at l1_ksteps)
 #pragma unroll
-            for (int ks = 0; ks < kMaxKS1; ++ks) {
-                u32x4 w;
+            for (int ks = 0; ks < KS1; ++ks) {
+                vu32x4 w;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    uint32_t dw[2];
+                    uint32_t dw[4];
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
+                    for (int gq = 0; gq < 4; ++gq) {
                         uint32_t v16[2];
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            const int q = 16 * ks + 8 * hf + 2 * jj + e;
-                            const int i = (q - 2) / 3, c = (q - 2) % 3;
-                            v16[e] = (q < 2) ? 0x3F80u : (i < kMaxIn ? (c == 1 ? xl[i] : xh[i]) : 0u);
+                            const int q = 32 * ks + 8 * gq + 2 * jj + e;
+                            const int i = (q - 2) / 3, c3 = (q - 2) % 3;
+                            v16[e] = (q < 2) ? 0x3F80u : (i < KIN ? (c3 == 1 ? xl[i] : xh[i]) : 0u);
                         }
-                        dw[hf] = v16[0] | (v16[1] << 16);
+                        dw[gq] = v16[0] | (v16[1] << 16);
                     }
-                    w[jj] = half ? dw[1] : dw[0];
+                    w[jj] = (kg & 1) ? ((kg & 2) ? dw[3] : dw[1]) : ((kg & 2) ? dw[2] : dw[0]);
                 }
-                xf[ks] = __builtin_bit_cast(bf16x8, w);
+                xf[nt][ks] = __builtin_bit_cast(bf16x8, w);
             }
         }
         // ---- layer 1: D[unit][row] = W1^T x + b1 -> ReLU -> bf16 B fragments of the next layer ------
-        bf16x8 h1f[UT][2];
-        auto layer1_tile = [&](int ut) {
-            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bf16x8 h1f[2][UT];
+        struct L1 { f32x4 d[2][2]; };  // [16-unit half][column tile]
+        auto layer1_pair = [&](int p) {
+            L1 o;
 #pragma unroll
-            for (int ks = 0; ks < kMaxKS1; ++ks)
-                if (ks < g.ks1) {  // block-uniform
-                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a1 + ((ks * UT + ut) * 64 + lane) * 16);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[ks], acc, 0, 0, 0);
+            for (int mh = 0; mh < 2; ++mh) {
+                o.d[mh][0] = f32x4{0, 0, 0, 0};
+                o.d[mh][1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {  // no runtime bound: a branch here would serialise every LDS read
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a1 + ((ks * MT + 2 * p + mh) * 64 + lane) * 16);
+                    o.d[mh][0] = mfma16(a, xf[0][ks], o.d[mh][0]);
+                    o.d[mh][1] = mfma16(a, xf[1][ks], o.d[mh][1]);
                 }
-            return acc;
+            }
+            return o;
         };
         {
-            f32x16 accn = layer1_tile(0);
+            L1 pp[2];  // ping-pong: pair p+1's MFMAs run under pair p's ReLU/convert
+            pp[0] = layer1_pair(0);
 #pragma unroll
-            for (int ut = 0; ut < UT; ++ut) {
-                const f32x16 acc = accn;
-                if (ut + 1 < UT) accn = layer1_tile(ut + 1);  // its MFMA runs under this tile's ReLU/convert
-                relu_to_frags(acc, h1f[ut][0], h1f[ut][1]);
+            for (int p = 0; p < UT; ++p) {
+                if (p + 1 < UT) pp[(p + 1) & 1] = layer1_pair(p + 1);
+                h1f[0][p] = relu_to_frag(pp[p & 1].d[0][0], pp[p & 1].d[1][0]);
+                h1f[1][p] = relu_to_frag(pp[p & 1].d[0][1], pp[p & 1].d[1][1]);
                 // Pin the conversion HERE.  The fragments are first used inside the jt loop, so the
                 // optimiser otherwise sinks ReLU+convert down to that loop's preheader and keeps all
-                // UT fp32 accumulator tiles (16 VGPRs each) alive until then -> hundreds of spills.
-                asm volatile("" : "+v"(h1f[ut][0]), "+v"(h1f[ut][1]));
-                __builtin_amdgcn_sched_barrier(0);  // and one unit tile at a time in the machine scheduler
+                // fp32 accumulator tiles alive until then -> hundreds of spills.
+                asm volatile("" : "+v"(h1f[0][p]), "+v"(h1f[1][p]));
+                __builtin_amdgcn_sched_barrier(0);  // and one unit pair at a time in the machine scheduler
             }
         }
         // ---- hidden layer 2 (+ output layer fused per tile) -------------------------------------
-        f32x16 acc3 = lds_tile16(l_b3 + half * 16);
+        f32x4 acc3[2];
+        acc3[0] = acc3[1] = *reinterpret_cast<const f32x4 *>(l_b3 + kg * 4);
         if (NFC == 2) {
-            // One 32-unit output tile jt of hidden layer 2: NK k-steps over the W2^T fragments of the current
-            // LDS slot, then ReLU and the two output-layer MFMAs.
+            // One 32-unit output tile jt of hidden layer 2: NF fragments (k-step p = f>>1, 16-unit half f&1)
+            // from the current LDS slot, two MFMAs each (the wave's two 16-row column tiles), then ReLU and
+            // the output-layer MFMAs.
             //  * The body is ONE basic block (no branch between the k-steps), so hipcc's s_waitcnt insertion
             //    keeps counted lgkmcnt waits and the fragment ring really stays RING deep.
-            //  * The fragment ring runs on ACROSS tiles: the last RING k-steps of a tile already fetch the
+            //  * The fragment ring runs on ACROSS tiles: the last RING reads of a tile already fetch the
             //    first fragments of the next one (and of the next step's first tile), so a tile starts with
-            //    its operands in registers; with BIASK the accumulator starts from the inline constant 0.
+            //    its operands in registers; with BIASK the accumulators start from the inline constant 0.
             //  * STREAM: 3 LDS slots hold tiles tl (being read), tl+1 (landed) and the one in flight.
-            //    Barrier number tl -- taken in tile tl after k-step X0 by group 0 and X1 = X0 - NK/2 by group
-            //    1, which keeps the two waves of a SIMD half a tile out of phase -- retires every read of tile
-            //    tl-1 and publishes tile tl+1; after it a wave issues its PPW pieces of tile tl+2 into the
-            //    slot of tile tl-1, a few k-steps apart so that their issue cost hides under MFMAs.  The
-            //    issue is unconditional: past the last tile it re-loads a tile nobody reads, and group 0 in
-            //    tile 0 re-loads the (identical) bytes of tile 1.
+            //    Barrier number tl -- taken in tile tl after fragment X0 by group 0 and X1 = X0 - NF/2 by
+            //    group 1, which keeps the two waves of a SIMD half a tile out of phase -- retires every read
+            //    of tile tl-1 and publishes tile tl+1; after it a wave issues its PPW pieces of tile tl+2 into
+            //    the slot of tile tl-1, a few fragments apart so that their issue cost hides under MFMAs.
+            //    The issue is unconditional: past the last tile it re-loads a tile nobody reads, and group 0
+            //    in tile 0 re-loads the (identical) bytes of tile 1.
             auto tile_body = [&](auto group_tag, int jt) {
                 constexpr int GROUP = decltype(group_tag)::value;
-                constexpr int X0 = NK - RING - 1, X1 = X0 - NK / 2;   // barrier k-step of group 0 / group 1
-                static_assert(!STREAM || (UT == 16 && X1 + 2 + 4 * (PPW - 1) < NK), "LDS-DMA issue slots");
+                constexpr int X0 = NF - RING - 1, X1 = X0 - NF / 2;   // barrier fragment of group 0 / group 1
+                static_assert(!STREAM || (UT == 16 && X1 + 2 + 4 * (PPW - 1) < NF), "LDS-DMA issue slots");
                 const int nsel = STREAM ? (bsel == 2 ? 0 : bsel + 1) : ((jt + 1) & (UT - 1));
                 const unsigned char *buf = l_a2 + (STREAM ? bsel : jt) * A2_TILE + lane * 16;
                 const unsigned char *nbuf = l_a2 + nsel * A2_TILE + lane * 16;
@@ -423,49 +433,37 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 const int dma_slot = (bsel + 1 + GROUP) % 3;
                 const int dma_src = dma_jn * A2_TILE + wave * 1024;
                 unsigned char *dma_dst = l_a2 + dma_slot * A2_TILE + wave * 1024;
-                f32x16 acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                if (!BIASK) acc2 = lds_tile16(l_b2 + (jt * 2 + half) * 16);
+                f32x4 acc[2][2];  // [16-unit half][column tile]
 #pragma unroll
-                for (int i = 0; i < NK; ++i) {
-                    const bf16x8 a = ring[i % RING];
-                    ring[i % RING] = (i + RING < NK) ? *reinterpret_cast<const bf16x8 *>(buf + (i + RING) * 1024)
-                                                     : *reinterpret_cast<const bf16x8 *>(nbuf + (i + RING - NK) * 1024);
-#if SSC_DYN_ABLATE & 32   // timing only: the same k-step as two v_mfma_f32_16x16x32_bf16 (operand layout NOT adapted)
-                    {
-                        f32x4 q0 = {acc2[0], acc2[1], acc2[2], acc2[3]}, q1 = {acc2[4], acc2[5], acc2[6], acc2[7]};
-                        f32x4 q2 = {acc2[8], acc2[9], acc2[10], acc2[11]}, q3 = {acc2[12], acc2[13], acc2[14], acc2[15]};
-                        if (i & 1) {
-                            q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, h1f[i >> 1][1], q2, 0, 0, 0);
-                            q3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, h1f[(i >> 1) ^ 1][1], q3, 0, 0, 0);
-                        } else {
-                            q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, h1f[i >> 1][0], q0, 0, 0, 0);
-                            q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, h1f[(i >> 1) ^ 1][0], q1, 0, 0, 0);
-                        }
+                for (int mh = 0; mh < 2; ++mh) {
+                    acc[mh][0] = f32x4{0, 0, 0, 0};
+                    if (!BIASK) acc[mh][0] = *reinterpret_cast<const f32x4 *>(l_b2 + ((jt * 2 + mh) * 4 + kg) * 4);
+                    acc[mh][1] = acc[mh][0];
+                }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { acc2[e] = q0[e]; acc2[4 + e] = q1[e]; acc2[8 + e] = q2[e]; acc2[12 + e] = q3[e]; }
-                    }
-#else
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[i >> 1][i & 1], acc2, 0, 0, 0);
-#endif
+                for (int f = 0; f < NF; ++f) {
+                    const bf16x8 a = ring[f % RING];
+                    ring[f % RING] = (f + RING < NF) ? *reinterpret_cast<const bf16x8 *>(buf + (f + RING) * 1024)
+                                                     : *reinterpret_cast<const bf16x8 *>(nbuf + (f + RING - NF) * 1024);
+                    acc[f & 1][0] = mfma16(a, h1f[0][f >> 1], acc[f & 1][0]);
+                    acc[f & 1][1] = mfma16(a, h1f[1][f >> 1], acc[f & 1][1]);
                     if (STREAM) {
-                        const int i0 = GROUP ? X1 + 2 : 1;  // first issue slot after this group's barrier
-                        if (i >= i0 && (i - i0) % 4 == 0 && (i - i0) / 4 < PPW) {
-                            const int p = (i - i0) / 4;
+                        const int f0 = GROUP ? X1 + 2 : 1;  // first issue slot after this group's barrier
+                        if (f >= f0 && (f - f0) % 4 == 0 && (f - f0) / 4 < PPW) {
+                            const int p = (f - f0) / 4;
                             lds_dma_1k(a2_rsrc, lane * 16, dma_src + p * kNW * 1024, dma_dst + p * kNW * 1024);
                         }
-                        if (i == (GROUP ? X1 : X0)) {  // barrier tl
+                        if (f == (GROUP ? X1 : X0)) {  // barrier tl
                             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tl+1 landed
                             __syncthreads();
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const bf16x8 a30 = *reinterpret_cast<const bf16x8 *>(a3_lane + (jt * 2 + 0) * a3_step);
-                const bf16x8 a31 = *reinterpret_cast<const bf16x8 *>(a3_lane + (jt * 2 + 1) * a3_step);
-                bf16x8 f0, f1;
-                relu_to_frags(acc2, f0, f1);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, f0, acc3, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, f1, acc3, 0, 0, 0);
+                const bf16x8 a3f = *reinterpret_cast<const bf16x8 *>(a3_lane + jt * a3_step);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc3[nt] = mfma16(a3f, relu_to_frag(acc[0][nt], acc[1][nt]), acc3[nt]);
                 if (STREAM) bsel = nsel;
             };
             if (!STREAM || group == 0) {
@@ -477,38 +475,43 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < UT * 2; ++i) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(a3_lane + i * a3_step);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, h1f[i >> 1][i & 1], acc3, 0, 0, 0);
-                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            for (int p = 0; p < UT; ++p) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(a3_lane + p * a3_step);
+                acc3[0] = mfma16(a, h1f[0][p], acc3[0]);
+                acc3[1] = mfma16(a, h1f[1][p], acc3[1]);
+                if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- z[o]: rows 0..3 sit in regs 0..3 of half 0, rows 4..7 in regs 0..3 of half 1 ------------
-        float z[SSC_MAX_STATE];
+        // ---- z[o]: output row o = 4 kg + r sits in register r of the row's k-group-kg lane -----------
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const float mine = acc3[o], other = __shfl_xor(acc3[o], 32);
-            z[o] = half ? other : mine;
-            z[4 + o] = half ? mine : other;
-        }
-        if (g.fwd_mode) {
-            if (valid && half == 0) {
+        for (int nt = 0; nt < 2; ++nt) {
+            float z[8];
 #pragma unroll
-                for (int o = 0; o < SSC_MAX_STATE; ++o)
-                    if (o < g.out) g.S[row * g.out + o] = z[o];
+            for (int r = 0; r < 4; ++r) {
+                z[r] = __shfl(acc3[nt][r], c);
+                z[4 + r] = (DS > 4 && g.out > 4) ? __shfl(acc3[nt][r], 16 + c) : 0.0f;
             }
-        } else {
+            if (g.fwd_mode) {
+                if (valid[nt] && kg == 0) {
 #pragma unroll
-            for (int k = 0; k < SSC_MAX_STATE; ++k)
-                if (k < g.d) st[k] = st[k] + (z[k] * l_nm[5 * 8 + k] + l_nm[4 * 8 + k]);  // :234-237
+                    for (int o = 0; o < DS; ++o)
+                        if (o < g.out) g.S[row[nt] * g.out + o] = z[o];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < DS; ++k)
+                    if (k < g.d) st[nt][k] = st[nt][k] + (z[k] * l_nm[5 * 8 + k] + l_nm[4 * 8 + k]);  // :234-237
+            }
         }
     }
     if (!g.fwd_mode) {
-        if (valid && half == 0) {
 #pragma unroll
-            for (int k = 0; k < SSC_MAX_STATE; ++k)
-                if (k < g.d) g.S[((int64_t)g.H * g.m + row) * g.d + k] = st[k];  // :240
-        }
+        for (int nt = 0; nt < 2; ++nt)
+            if (valid[nt] && kg == 0) {
+#pragma unroll
+                for (int k = 0; k < DS; ++k)
+                    if (k < g.d) g.S[((int64_t)g.H * g.m + row[nt]) * g.d + k] = st[nt][k];  // :240
+            }
     }
     // group 1 issued LDS-DMA after its last barrier: it must land before this workgroup's LDS is released
     if (STREAM) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -530,6 +533,8 @@ bool dyn_mfma_supported(const ssc_mlp_desc *mlp, int state_dim, int act_dim) {
     const int depth = mlp->dims[1];
     if (depth > 512 || (nfc == 2 && mlp->dims[2] != depth)) return false;
     if (mlp->dims[0] > kMaxIn || mlp->dims[mlp->n_layers] > SSC_MAX_STATE) return false;
+    // streamed W2 (depth > 128) leaves LDS room for one layer-1 k-step only: 2 + 3*in <= 32
+    if (nfc == 2 && tiles_for(depth) > 4 && l1_ksteps(mlp->dims[0]) > 1) return false;
     return true;
 }
 
@@ -539,11 +544,11 @@ size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp) {
     return make_pack(tiles_for(mlp->dims[1]), nfc).total;
 }
 
-template <int UT, int NFC, bool BIASK>
+template <int UT, int NFC, bool BIASK, int KIN>
 static int launch_sim(const DynSimArgs &g, hipStream_t s) {
-    const size_t lds = (size_t)dyn_a2_bufs<UT, NFC>() * UT * 2048 + (size_t)g.ks1 * UT * 1024 + (size_t)UT * 512 + 16 +
-                       (size_t)UT * 128 + 128 + 192;
-    auto kern = dyn_mfma_sim_kernel<UT, NFC, BIASK>;
+    const size_t lds = (size_t)dyn_a2_bufs<UT, NFC>() * UT * 2048 + (size_t)l1_ksteps(KIN) * UT * 2048 + (size_t)UT * 512 + 16 +
+                       (size_t)UT * 128 + 64 + 192;
+    auto kern = dyn_mfma_sim_kernel<UT, NFC, BIASK, KIN>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -567,16 +572,19 @@ static int run_mfma(const ssc_mlp_desc *mlp, const ssc_norm *norm, DynSimArgs &g
     n.W2 = (nfc == 2) ? mlp->W[1] : nullptr; n.b2 = (nfc == 2) ? mlp->b[1] : nullptr;
     n.W3 = mlp->W[nfc]; n.b3 = mlp->b[nfc];
     unsigned char *ws = static_cast<unsigned char *>(wsv);
-    const int64_t n_pack = (nfc == 2 ? (int64_t)UT * UT * 1024 : 0) + (int64_t)UT * 256 + (int64_t)kMaxKS1 * UT * 512 +
-                           (int64_t)UT * 32 + 32;
+    const int64_t n_pack = (nfc == 2 ? (int64_t)UT * UT * 1024 : 0) + (int64_t)UT * 256 + (int64_t)kMaxKS1 * UT * 1024 +
+                           (int64_t)UT * 32 + 16;
     ssc_norm nm{};
     if (norm) nm = *norm;
     hipLaunchKernelGGL(dyn_pack_kernel, dim3(blocks_for(n_pack)), dim3(256), 0, s, n, UT, pk, nm, ws);
-    g.in = n.in; g.out = n.out; g.ks1 = l1_ksteps(n.in);
+    g.in = n.in; g.out = n.out;
     g.a1 = ws + pk.a1; g.a2 = ws + pk.a2; g.a3 = ws + pk.a3;
     g.b2 = reinterpret_cast<const float *>(ws + pk.b2); g.b3 = reinterpret_cast<const float *>(ws + pk.b3);
     g.nm = reinterpret_cast<const float *>(ws + pk.nm);
-#define SSC_DYN_CASE(U, F, B) if (UT == U && nfc == F && n.biask == B) return launch_sim<U, F, B>(g, s)
+    const int kin = (n.in <= 4 && n.out <= 4) ? 4 : (n.in <= 10 ? 10 : kMaxIn);
+#define SSC_DYN_CASE(U, F, B)                                                                 \
+    if (UT == U && nfc == F && n.biask == B)                                                  \
+        return kin == 4 ? launch_sim<U, F, B, 4>(g, s) : kin == 10 ? launch_sim<U, F, B, 10>(g, s) : launch_sim<U, F, B, kMaxIn>(g, s)
     SSC_DYN_CASE(1, 1, false); SSC_DYN_CASE(4, 1, false); SSC_DYN_CASE(16, 1, false);
     SSC_DYN_CASE(1, 2, false); SSC_DYN_CASE(4, 2, false); SSC_DYN_CASE(16, 2, false);
     SSC_DYN_CASE(1, 2, true); SSC_DYN_CASE(4, 2, true); SSC_DYN_CASE(16, 2, true);
