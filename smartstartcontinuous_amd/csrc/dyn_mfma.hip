@@ -45,7 +45,8 @@ constexpr int kNW = kDynThreads / 64;
 constexpr int kMaxIn = 12;        // network inputs (state + action)
 constexpr int kMaxKS1 = 2;        // layer-1 k-steps of 32 slots: 2 bias slots + 3 per input
 // Diagnostic builds for tools/exp_dyn_clock.py (results are WRONG when set; never in libssc.so):
-// 16 clock stamps: every block overwrites S[4*block .. +3] with {d_memtime, d_memrealtime} of its step loop
+// 16 clock stamps: every block overwrites S[24*block .. +23] with {d_memtime, d_memrealtime} of its step loop and
+//    the cycles of its phases, for one wave of each group
 #ifndef SSC_DYN_ABLATE
 #define SSC_DYN_ABLATE 0
 #endif
@@ -77,7 +78,7 @@ __host__ __device__ __forceinline__ int l1_ksteps(int in) { return (2 + 3 * in +
 // Packed weight image in the workspace (all offsets in bytes, 256-aligned); UT = 32-unit tiles of a hidden layer
 struct DynPack {
     size_t a2;   // bf16 [UT jt][2*UT f = 2p+mh][64 lane][8]  W2^T fragments: units 32jt+16mh+(lane&15), k-step p (NFC == 2)
-    size_t a3;   // bf16 [UT p][4 g][8 o][8]                  Wout^T fragments, only the 8 possible output rows
+    size_t a3;   // bf16 [UT p][4 g][8 o][8]                  Wout^T fragments: MFMA rows m and m+8 share entry o = m & 7
     size_t a1;   // bf16 [KS1][2*UT mt][64 lane][8]           layer-1 fragments (bias + split W1, see above)
     size_t b2;   // f32  [UT jt][2 mh][4 g][4 r]              b2 in accumulator layout (when not in the k slots)
     size_t b3;   // f32  [4 g][4 r]
@@ -141,8 +142,10 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
     }
     e -= n_a2;
     if (e < n_a3) {
-        const int j = e & 7, o = (e >> 3) & 7, g = (e >> 6) & 3, p = (int)(e >> 8);
-        const int u = frag_unit(p, g, j);
+        // MFMA row m = 0..15 of the output layer computes output (m & omask): with <= 4 outputs every k-group lane
+        // of a batch row then ends up holding ALL outputs in its 4 accumulator registers (no lane exchange)
+        const int j = e & 7, o8 = (e >> 3) & 7, g = (e >> 6) & 3, p = (int)(e >> 8);
+        const int u = frag_unit(p, g, j), o = o8 & (n.out <= 4 ? 3 : 7);
         const float v = (u < n.depth && o < n.out) ? n.W3[(int64_t)u * n.out + o] : 0.0f;
         reinterpret_cast<__bf16 *>(ws + pk.a3)[e] = (__bf16)v;
         return;
@@ -176,8 +179,9 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
         return;
     }
     e -= n_b;
-    if (e < 16) {  // b3: [g][r], output row o = 4g + r
-        reinterpret_cast<float *>(ws + pk.b3)[e] = ((int)e < n.out) ? n.b3[e] : 0.0f;
+    if (e < 16) {  // b3: [g][r], MFMA row 4g + r computes output (4g + r) & omask
+        const int o = (int)e & (n.out <= 4 ? 3 : 7);
+        reinterpret_cast<float *>(ws + pk.b3)[e] = (o < n.out) ? n.b3[o] : 0.0f;
     }
 }
 
@@ -220,11 +224,16 @@ __device__ __forceinline__ void split_bf16(float x, uint32_t &hi, uint32_t &lo) 
     lo = __builtin_bit_cast(unsigned short, l);
 }
 
+// a block-uniform value, moved to an SGPR
+__device__ __forceinline__ float uniform_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
 __device__ __forceinline__ f32x4 mfma16(const bf16x8 &a, const bf16x8 &b, const f32x4 &c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// LDS carve (bytes): [a2: NBUF x UT*2048] [a1: KS1*UT*2048] [a3: UT*512] [zero 16] [b2 UT*128] [b3 64] [nm 192]
+// LDS carve (bytes): [a2: NBUF x UT*2048] [a1: KS1*UT*2048] [a3: UT*512] [b2 UT*128] [b3 64]
 // W2 (NFC == 2): resident when it fits (UT <= 4: all UT tiles), otherwise streamed through a ring of 3.
 template <int UT, int NFC>
 __host__ __device__ constexpr int dyn_a2_bufs() { return NFC == 2 ? (UT <= 4 ? UT : 3) : 0; }
@@ -248,10 +257,8 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     unsigned char *l_a2 = lds;
     unsigned char *l_a1 = l_a2 + NBUF * A2_TILE;
     unsigned char *l_a3 = l_a1 + KS1 * MT * 1024;
-    unsigned char *l_zero = l_a3 + UT * 512;
-    float *l_b2 = reinterpret_cast<float *>(l_zero + 16);
+    float *l_b2 = reinterpret_cast<float *>(l_a3 + UT * 512);
     float *l_b3 = l_b2 + UT * 32;
-    float *l_nm = l_b3 + 16;  // [6][8]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -271,8 +278,6 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         for (int e = tid; e < KS1 * MT * 1024 / 16; e += kDynThreads) d1[e] = s1[e];
         for (int e = tid; e < UT * 32; e += kDynThreads) l_b2[e] = g.b2[e];
         if (tid < 16) l_b3[tid] = g.b3[tid];
-        if (tid < 48) l_nm[tid] = g.nm[tid];
-        if (tid < 4) reinterpret_cast<float *>(l_zero)[tid] = 0.0f;
     }
     // raw buffer over the W2^T fragment image (reads past the end return 0)
     const __amdgpu_buffer_rsrc_t a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -285,9 +290,9 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA pieces above
     __syncthreads();
 
-    // output-layer A fragments: output row o = lane & 15 < 8 reads its 16 B, the others a zero line
-    const unsigned char *a3_lane = (c < 8) ? l_a3 + (kg * 8 + c) * 16 : l_zero;
-    const int a3_step = (c < 8) ? 512 : 0;
+    // output-layer A fragments: MFMA row (lane & 15) reads entry (lane & 7) of its k group
+    const unsigned char *a3_lane = l_a3 + (kg * 8 + (c & 7)) * 16;
+    constexpr int a3_step = 512;
 
     // ---- this lane's rows: one per 16-row column tile; the 4 k-group lanes of a row carry it redundantly ----
     int64_t row[2], rowc[2];
@@ -305,6 +310,32 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         }
     }
 
+    // the actions of step t+1 are fetched during step t (a global load costs ~1-2 k cycles even from L2)
+    constexpr int AMAX = KIN < 4 ? KIN : 4;
+    float act[2][AMAX];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ai = 0; ai < AMAX; ++ai)
+            act[nt][ai] = (!g.fwd_mode && ai < g.a) ? g.A[rowc[nt] * g.H * g.a + ai] : 0.0f;
+
+    // Normalisation constants per network input (input k = state k for k < d, else action k-d) and per state
+    // delta, read once through scalar loads: block-uniform, so they live in SGPRs and the per-step input code
+    // below is straight-line VALU code with no branch and no LDS access.  Inputs >= in get inv = 0 -> x = 0.
+    float n_mean[KIN], n_inv[KIN], z_mean[DS], z_std[DS];
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) {
+        const bool is_state = k < g.d;
+        const int ai = (k - g.d) & 3;
+        n_mean[k] = uniform_f32(g.nm[is_state ? 0 * 8 + (k & 7) : 2 * 8 + ai]);
+        n_inv[k] = (k < g.in) ? uniform_f32(g.nm[is_state ? 1 * 8 + (k & 7) : 3 * 8 + ai]) : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < DS; ++k) {
+        z_mean[k] = (k < g.d) ? uniform_f32(g.nm[4 * 8 + k]) : 0.0f;
+        z_std[k] = (k < g.d) ? uniform_f32(g.nm[5 * 8 + k]) : 0.0f;
+    }
+
     int bsel = 0;  // LDS slot of the current W2 tile (STREAM)
     constexpr int NF = 2 * UT;                // W2^T fragments (ring entries) per hidden tile: k-step p = f>>1, half f&1
     constexpr int RING = (NF >= 4) ? 4 : 2;   // fragment reads in flight per wave
@@ -315,7 +346,10 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     }
     const uint64_t stamp_c0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memtime() : 0;
     const uint64_t stamp_r0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
+    uint64_t ph[4] = {0, 0, 0, 0};  // diagnostic: cycles in input code / layer 1 / hidden tiles / step tail
+#define SSC_STAMP(var) uint64_t var = 0; if (SSC_DYN_ABLATE & 16) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     for (int t = 0; t < g.H; ++t) {
+        SSC_STAMP(stamp_a)
         // ---- inputs: record S[t]; layer-1 B fragments of x = normalised (state, action) ---------------
         bf16x8 xf[2][KS1];
 #pragma unroll
@@ -326,20 +360,17 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 for (int k = 0; k < KIN; ++k) xs[k] = (k < g.in) ? g.A[rowc[nt] * g.in + k] : 0.0f;
             } else {
                 if (valid[nt] && kg == 0) {
+                    float *sp = g.S + ((int64_t)t * g.m + row[nt]) * g.d;
 #pragma unroll
                     for (int k = 0; k < DS; ++k)
-                        if (k < g.d) g.S[((int64_t)t * g.m + row[nt]) * g.d + k] = st[nt][k];  // dynamics_model.py:225
+                        if (k < g.d) sp[k] = st[nt][k];  // dynamics_model.py:225
                 }
 #pragma unroll
                 for (int k = 0; k < KIN; ++k) {
-                    float v = 0.0f;
-                    if (k < g.d) {
-                        v = zscore(st[nt][k < DS ? k : 0], l_nm[0 * 8 + (k & 7)], l_nm[1 * 8 + (k & 7)]);
-                    } else if (k < g.in) {
-                        const int ai = (k - g.d) & 3;
-                        v = zscore(g.A[(rowc[nt] * g.H + t) * g.a + ai], l_nm[2 * 8 + ai], l_nm[3 * 8 + ai]);
-                    }
-                    xs[k] = v;
+                    float av = act[nt][0];  // action component k - d (block-uniform index)
+#pragma unroll
+                    for (int ai = 1; ai < AMAX; ++ai) av = (k - g.d == ai) ? act[nt][ai] : av;
+                    xs[k] = zscore((k < g.d) ? st[nt][k < DS ? k : 0] : av, n_mean[k], n_inv[k]);
                 }
             }
             uint32_t xh[KIN], xl[KIN];
@@ -368,6 +399,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 xf[nt][ks] = __builtin_bit_cast(bf16x8, w);
             }
         }
+        SSC_STAMP(stamp_l)
         // ---- layer 1: D[unit][row] = W1^T x + b1 -> ReLU -> bf16 B fragments of the next layer ------
         bf16x8 h1f[2][UT];
         struct L1 { f32x4 d[2][2]; };  // [16-unit half][column tile]
@@ -399,6 +431,17 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 // fp32 accumulator tiles alive until then -> hundreds of spills.
                 asm volatile("" : "+v"(h1f[0][p]), "+v"(h1f[1][p]));
                 __builtin_amdgcn_sched_barrier(0);  // and one unit pair at a time in the machine scheduler
+            }
+        }
+        // the actions of the next step: issued here, behind layer 1's scheduling fences, so that the loads fly
+        // under the hidden tiles (hoisted to the top of the step they were waited for at once)
+        if (!g.fwd_mode && t + 1 < g.H) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float *ap = g.A + (rowc[nt] * g.H + t + 1) * g.a;
+#pragma unroll
+                for (int ai = 0; ai < AMAX; ++ai)
+                    if (ai < g.a) act[nt][ai] = ap[ai];
             }
         }
         // ---- hidden layer 2 (+ output layer fused per tile) -------------------------------------
@@ -466,6 +509,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                     acc3[nt] = mfma16(a3f, relu_to_frag(acc[0][nt], acc[1][nt]), acc3[nt]);
                 if (STREAM) bsel = nsel;
             };
+            SSC_STAMP(stamp_b)
             if (!STREAM || group == 0) {
 #pragma unroll 1
                 for (int jt = 0; jt < UT; ++jt) tile_body(std::integral_constant<int, 0>{}, jt);
@@ -473,6 +517,8 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
 #pragma unroll 1
                 for (int jt = 0; jt < UT; ++jt) tile_body(std::integral_constant<int, 1>{}, jt);
             }
+            SSC_STAMP(stamp_d)
+            if (SSC_DYN_ABLATE & 16) { ph[0] += stamp_l - stamp_a; ph[1] += stamp_b - stamp_l; ph[2] += stamp_d - stamp_b; ph[3] -= stamp_d; }
         } else {
 #pragma unroll
             for (int p = 0; p < UT; ++p) {
@@ -482,14 +528,19 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- z[o]: output row o = 4 kg + r sits in register r of the row's k-group-kg lane -----------
+        // ---- z[o]: register r of every lane holds output r (<= 4 outputs) or output (4 kg + r) & 7 -----------
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float z[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                z[r] = __shfl(acc3[nt][r], c);
-                z[4 + r] = (DS > 4 && g.out > 4) ? __shfl(acc3[nt][r], 16 + c) : 0.0f;
+                z[r] = acc3[nt][r];
+                z[4 + r] = 0.0f;
+                if (DS > 4 && g.out > 4) {  // block-uniform; k groups 0/2 hold outputs 0..3, 1/3 hold 4..7
+                    const float other = __shfl_xor(acc3[nt][r], 16);
+                    z[r] = (kg & 1) ? other : acc3[nt][r];
+                    z[4 + r] = (kg & 1) ? acc3[nt][r] : other;
+                }
             }
             if (g.fwd_mode) {
                 if (valid[nt] && kg == 0) {
@@ -499,10 +550,10 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < DS; ++k)
-                    if (k < g.d) st[nt][k] = st[nt][k] + (z[k] * l_nm[5 * 8 + k] + l_nm[4 * 8 + k]);  // :234-237
+                for (int k = 0; k < DS; ++k) st[nt][k] = st[nt][k] + (z[k] * z_std[k] + z_mean[k]);  // :234-237 (0 for k >= d)
             }
         }
+        if ((SSC_DYN_ABLATE & 16) && NFC == 2) { SSC_STAMP(stamp_e) ph[3] += stamp_e; }
     }
     if (!g.fwd_mode) {
 #pragma unroll
@@ -517,9 +568,11 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     if (STREAM) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (SSC_DYN_ABLATE & 16) {
         const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c0, dr = __builtin_amdgcn_s_memrealtime() - stamp_r0;
-        if (tid == 0) {
-            uint32_t *o = reinterpret_cast<uint32_t *>(g.S) + 4 * blockIdx.x;
+        if (lane == 0 && (wave == 0 || wave == 4)) {  // per block 24 dwords: {dc, dr} + 4 phase sums of wave 0, then of wave 4
+            uint32_t *o = reinterpret_cast<uint32_t *>(g.S) + 24 * blockIdx.x + 12 * group;
             o[0] = (uint32_t)dc; o[1] = (uint32_t)(dc >> 32); o[2] = (uint32_t)dr; o[3] = (uint32_t)(dr >> 32);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[4 + 2 * k] = (uint32_t)ph[k]; o[5 + 2 * k] = (uint32_t)(ph[k] >> 32); }
         }
     }
 }
@@ -546,8 +599,8 @@ size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp) {
 
 template <int UT, int NFC, bool BIASK, int KIN>
 static int launch_sim(const DynSimArgs &g, hipStream_t s) {
-    const size_t lds = (size_t)dyn_a2_bufs<UT, NFC>() * UT * 2048 + (size_t)l1_ksteps(KIN) * UT * 2048 + (size_t)UT * 512 + 16 +
-                       (size_t)UT * 128 + 64 + 192;
+    const size_t lds = (size_t)dyn_a2_bufs<UT, NFC>() * UT * 2048 + (size_t)l1_ksteps(KIN) * UT * 2048 + (size_t)UT * 512 +
+                       (size_t)UT * 128 + 64;
     auto kern = dyn_mfma_sim_kernel<UT, NFC, BIASK, KIN>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

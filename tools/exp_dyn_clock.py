@@ -19,9 +19,13 @@ while time.time() - t0 < 2.0:
     torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); model.do_forward_sim(s0, A, precision="bf16_mfma", out=S); e1.record(); torch.cuda.synchronize()
-st = S.view(torch.int32).flatten()[: 4 * (M // 256)].cpu().numpy().astype(np.uint32).reshape(-1, 4).astype(np.uint64)
-dc = st[:, 0] | (st[:, 1] << np.uint64(32)); dr = st[:, 2] | (st[:, 3] << np.uint64(32))
+raw = S.view(torch.int32).flatten()[: 24 * (M // 256)].cpu().numpy().astype(np.uint32).reshape(-1, 2, 6, 2).astype(np.uint64)
+v = raw[..., 0] | (raw[..., 1] << np.uint64(32))       # [block][group][dc, dr, input, layer 1, hidden tiles, tail]
+dc, dr = v[:, 0, 0], v[:, 0, 1]
 clk = dc / dr * 100.0
-mf = 560 * 2 * 32 * H   # MFMA pipe cycles per SIMD for the step loop (2 waves x 560 MFMAs x 32 cyc per step)
+mf = 560 * 2 * 32 * H   # MFMA pipe cycles per SIMD for the step loop (2 waves x 17920 cyc of MFMAs per step)
 print("launch %.4f ms; blocks %d; step-loop cycles median %.0f (%.0f per step); realtime median %.1f us; clock median %.0f MHz (min %.0f max %.0f); MFMA floor %.0f cyc -> pipe busy %.1f %%"
       % (e0.elapsed_time(e1), len(dc), np.median(dc), np.median(dc) / H, np.median(dr) / 100.0, np.median(clk), clk.min(), clk.max(), mf, 100.0 * mf / np.median(dc)))
+for gi in range(2):
+    ph = np.median(v[:, gi, 2:].astype(np.int64), axis=0) / H
+    print("group %d per step: input code %.0f, layer 1 %.0f, hidden tiles %.0f (%.0f each), step tail %.0f cycles" % (gi, ph[0], ph[1], ph[2], ph[2] / 16, ph[3]))
