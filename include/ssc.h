@@ -41,7 +41,7 @@ enum {
 
 enum { SSC_ENV_MOUNTAINCAR = 0, SSC_ENV_PENDULUM = 1 };
 enum { SSC_POLICY_RANDOM = 0, SSC_POLICY_ACTOR = 1 };
-enum { SSC_PREC_F32 = 0, SSC_PREC_BF16_MFMA = 1 };
+enum { SSC_PREC_F32 = 0, SSC_PREC_BF16_MFMA = 1, SSC_PREC_BF16_MFMA_PREPARED = 2 };
 
 #define SSC_MAX_OBS 3
 #define SSC_MAX_LAYERS 4
@@ -220,6 +220,15 @@ int ssc_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float 
  * d_s0 is [s0_rows][state_dim] with s0_rows == m, or s0_rows == 1 (one start state tiled to all
  * rows, :215-217).  d_A is [m][H][act_dim]; d_S is [H+1][m][state_dim]. */
 size_t ssc_dyn_workspace_bytes(const ssc_mlp_desc *mlp, int64_t m, int precision);
+/* The MFMA path works from a packed bf16 image of the weights (and of the statistics) in the workspace.
+ * ssc_dyn_forward_sim / ssc_mlp_forward with SSC_PREC_BF16_MFMA write that image on every call; a caller
+ * whose weights stay put between calls -- the navigator between two Dyn_Model.train() rounds
+ * (NND_MB_agent.py:421-423), like TF variables that live in the session across sess.run calls
+ * (dynamics_model.py:226-233) -- writes it ONCE with ssc_dyn_prepare() and then passes
+ * SSC_PREC_BF16_MFMA_PREPARED with the same workspace (which nothing else may touch in between).
+ * norm may be NULL for ssc_mlp_forward use.  Workspace size: ssc_dyn_workspace_bytes(.., SSC_PREC_BF16_MFMA). */
+int ssc_dyn_prepare(const ssc_mlp_desc *mlp, const ssc_norm *norm, void *d_workspace, size_t workspace_bytes,
+                    ssc_stream_t stream);
 int ssc_dyn_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m, int32_t H,
                         int32_t state_dim, int32_t act_dim, const float *d_s0, int64_t s0_rows,
                         const float *d_A, float *d_S, int precision, void *d_workspace,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libssc.so")
 SSC_OK, SSC_EINVAL, SSC_EUNSUPPORTED, SSC_EHIP = 0, -1, -2, -3
 SSC_ENV_MOUNTAINCAR, SSC_ENV_PENDULUM = 0, 1
 SSC_POLICY_RANDOM, SSC_POLICY_ACTOR = 0, 1
-SSC_PREC_F32, SSC_PREC_BF16_MFMA = 0, 1
+SSC_PREC_F32, SSC_PREC_BF16_MFMA, SSC_PREC_BF16_MFMA_PREPARED = 0, 1, 2
 SSC_MAX_OBS, SSC_MAX_LAYERS, SSC_MAX_STATE, SSC_MAX_ACT = 3, 4, 8, 4
 
 
@@ -145,6 +145,7 @@ _SIGNATURES = {
     "ssc_mlp_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),
     "ssc_mlp_forward": (c_int, [POINTER(MlpDesc), c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "ssc_dyn_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),
+    "ssc_dyn_prepare": (c_int, [POINTER(MlpDesc), POINTER(Norm), c_void_p, c_size_t, c_void_p]),
     "ssc_dyn_forward_sim": (c_int, [POINTER(MlpDesc), POINTER(Norm), c_int64, c_int32, c_int32, c_int32, c_void_p,
                                     c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "ssc_mpc_sample_actions": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float),

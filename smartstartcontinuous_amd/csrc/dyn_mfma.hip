@@ -45,7 +45,7 @@ constexpr int kNW = kDynThreads / 64;
 constexpr int kMaxIn = 12;        // network inputs (state + action)
 constexpr int kMaxKS1 = 2;        // layer-1 k-steps of 32 slots: 2 bias slots + 3 per input
 // Diagnostic builds for tools/exp_dyn_clock.py (results are WRONG when set; never in libssc.so):
-// 16 clock stamps: every block overwrites S[24*block .. +23] with {d_memtime, d_memrealtime} of its step loop and
+// 16 clock stamps: every block overwrites S[32*block .. +31] with {d_memtime, d_memrealtime} of its step loop and
 //    the cycles of its phases, for one wave of each group
 #ifndef SSC_DYN_ABLATE
 #define SSC_DYN_ABLATE 0
@@ -248,6 +248,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     constexpr int DS = KIN < SSC_MAX_STATE ? KIN : SSC_MAX_STATE;  // state / output registers per row
     constexpr int KS1 = (2 + 3 * KIN + 31) / 32;                   // layer-1 k-steps compiled in
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint64_t stamp_entry = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
     constexpr int MT = 2 * UT;          // 16-unit tiles of a hidden layer
     constexpr int A2_TILE = UT * 2048;  // W2^T fragments of one 32-unit output tile: NF fragments of 1 KiB
     constexpr int NBUF = dyn_a2_bufs<UT, NFC>();
@@ -568,11 +569,12 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     if (STREAM) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (SSC_DYN_ABLATE & 16) {
         const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c0, dr = __builtin_amdgcn_s_memrealtime() - stamp_r0;
-        if (lane == 0 && (wave == 0 || wave == 4)) {  // per block 24 dwords: {dc, dr} + 4 phase sums of wave 0, then of wave 4
-            uint32_t *o = reinterpret_cast<uint32_t *>(g.S) + 24 * blockIdx.x + 12 * group;
+        if (lane == 0 && (wave == 0 || wave == 4)) {  // per block 2 x 16 dwords (wave 0, wave 4): {dc, dr}, 4 phase sums, entry and loop-start realtime
+            uint32_t *o = reinterpret_cast<uint32_t *>(g.S) + 32 * blockIdx.x + 16 * group;
             o[0] = (uint32_t)dc; o[1] = (uint32_t)(dc >> 32); o[2] = (uint32_t)dr; o[3] = (uint32_t)(dr >> 32);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { o[4 + 2 * k] = (uint32_t)ph[k]; o[5 + 2 * k] = (uint32_t)(ph[k] >> 32); }
+            o[12] = (uint32_t)stamp_entry; o[13] = (uint32_t)(stamp_entry >> 32); o[14] = (uint32_t)stamp_r0; o[15] = (uint32_t)(stamp_r0 >> 32);
         }
     }
 }
@@ -613,23 +615,38 @@ static int launch_sim(const DynSimArgs &g, hipStream_t s) {
     return check_launch("dyn_mfma_sim_kernel");
 }
 
-static int run_mfma(const ssc_mlp_desc *mlp, const ssc_norm *norm, DynSimArgs &g, void *wsv, hipStream_t s) {
+static DynNet make_net(const ssc_mlp_desc *mlp, int UT) {
     const int nfc = mlp->n_layers - 1;
-    const int depth = mlp->dims[1];
-    const int UT = tiles_for(depth);
-    const DynPack pk = make_pack(UT, nfc);
     DynNet n;
-    n.in = mlp->dims[0]; n.depth = depth; n.out = mlp->dims[mlp->n_layers]; n.nfc = nfc;
-    n.biask = (nfc == 2) && (depth + 2 <= 32 * UT);
+    n.in = mlp->dims[0]; n.depth = mlp->dims[1]; n.out = mlp->dims[mlp->n_layers]; n.nfc = nfc;
+    n.biask = (nfc == 2) && (n.depth + 2 <= 32 * UT);
     n.W1 = mlp->W[0]; n.b1 = mlp->b[0];
     n.W2 = (nfc == 2) ? mlp->W[1] : nullptr; n.b2 = (nfc == 2) ? mlp->b[1] : nullptr;
     n.W3 = mlp->W[nfc]; n.b3 = mlp->b[nfc];
-    unsigned char *ws = static_cast<unsigned char *>(wsv);
+    return n;
+}
+
+// write the packed weight image (ssc_dyn_prepare, or the first half of an unprepared call)
+int dyn_mfma_prepare(const ssc_mlp_desc *mlp, const ssc_norm *norm, void *wsv, hipStream_t s) {
+    const int nfc = mlp->n_layers - 1;
+    const int UT = tiles_for(mlp->dims[1]);
+    const DynPack pk = make_pack(UT, nfc);
+    const DynNet n = make_net(mlp, UT);
     const int64_t n_pack = (nfc == 2 ? (int64_t)UT * UT * 1024 : 0) + (int64_t)UT * 256 + (int64_t)kMaxKS1 * UT * 1024 +
                            (int64_t)UT * 32 + 16;
     ssc_norm nm{};
     if (norm) nm = *norm;
-    hipLaunchKernelGGL(dyn_pack_kernel, dim3(blocks_for(n_pack)), dim3(256), 0, s, n, UT, pk, nm, ws);
+    hipLaunchKernelGGL(dyn_pack_kernel, dim3(blocks_for(n_pack)), dim3(256), 0, s, n, UT, pk, nm,
+                       static_cast<unsigned char *>(wsv));
+    return check_launch("dyn_pack_kernel");
+}
+
+static int run_mfma(const ssc_mlp_desc *mlp, DynSimArgs &g, void *wsv, hipStream_t s) {
+    const int nfc = mlp->n_layers - 1;
+    const int UT = tiles_for(mlp->dims[1]);
+    const DynPack pk = make_pack(UT, nfc);
+    const DynNet n = make_net(mlp, UT);
+    unsigned char *ws = static_cast<unsigned char *>(wsv);
     g.in = n.in; g.out = n.out;
     g.a1 = ws + pk.a1; g.a2 = ws + pk.a2; g.a3 = ws + pk.a3;
     g.b2 = reinterpret_cast<const float *>(ws + pk.b2); g.b3 = reinterpret_cast<const float *>(ws + pk.b3);
@@ -647,18 +664,23 @@ static int run_mfma(const ssc_mlp_desc *mlp, const ssc_norm *norm, DynSimArgs &g
 
 int dyn_mfma_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m, int32_t H, int32_t state_dim,
                          int32_t act_dim, const float *d_s0, int64_t s0_rows, const float *d_A, float *d_S,
-                         void *ws, hipStream_t s) {
+                         void *ws, bool prepared, hipStream_t s) {
+    if (!prepared)
+        if (int rc = dyn_mfma_prepare(mlp, norm, ws, s)) return rc;
     DynSimArgs g{};
     g.m = m; g.H = H; g.d = state_dim; g.a = act_dim; g.fwd_mode = 0;
     g.s0 = d_s0; g.s0_rows = s0_rows; g.A = d_A; g.S = d_S;
-    return run_mfma(mlp, norm, g, ws, s);
+    return run_mfma(mlp, g, ws, s);
 }
 
-int dyn_mfma_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float *d_y, void *ws, hipStream_t s) {
+int dyn_mfma_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float *d_y, void *ws, bool prepared,
+                         hipStream_t s) {
+    if (!prepared)
+        if (int rc = dyn_mfma_prepare(mlp, nullptr, ws, s)) return rc;
     DynSimArgs g{};
     g.m = m; g.H = 1; g.d = 0; g.a = 0; g.fwd_mode = 1;
     g.s0 = nullptr; g.s0_rows = 1; g.A = d_x; g.S = d_y;
-    return run_mfma(mlp, nullptr, g, ws, s);
+    return run_mfma(mlp, g, ws, s);
 }
 
 }  // namespace ssc

@@ -169,10 +169,14 @@ int mlp_forward_f32(const ssc_mlp_desc *mlp, int64_t m, const float *x, float *y
 // bf16-MFMA path (dyn_mfma.hip)
 bool dyn_mfma_supported(const ssc_mlp_desc *mlp, int state_dim, int act_dim);
 size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp);
+int dyn_mfma_prepare(const ssc_mlp_desc *mlp, const ssc_norm *norm, void *ws, hipStream_t s);
 int dyn_mfma_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m, int32_t H, int32_t state_dim,
                          int32_t act_dim, const float *d_s0, int64_t s0_rows, const float *d_A, float *d_S,
-                         void *ws, hipStream_t s);
-int dyn_mfma_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float *d_y, void *ws, hipStream_t s);
+                         void *ws, bool prepared, hipStream_t s);
+int dyn_mfma_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float *d_y, void *ws, bool prepared,
+                         hipStream_t s);
+
+static bool is_mfma(int precision) { return precision == SSC_PREC_BF16_MFMA || precision == SSC_PREC_BF16_MFMA_PREPARED; }
 
 }  // namespace ssc
 
@@ -182,7 +186,7 @@ extern "C" {
 
 size_t ssc_mlp_workspace_bytes(const ssc_mlp_desc *mlp, int64_t m, int precision) {
     if (mlp == nullptr || m < 0 || mlp->n_layers < 1 || mlp->n_layers > SSC_MAX_LAYERS) return 0;
-    if (precision == SSC_PREC_BF16_MFMA) return dyn_mfma_workspace_bytes(mlp);
+    if (is_mfma(precision)) return dyn_mfma_workspace_bytes(mlp);
     return 2 * align256((size_t)m * max_width(mlp) * sizeof(float));
 }
 
@@ -195,11 +199,12 @@ int ssc_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float 
     const size_t need = ssc_mlp_workspace_bytes(mlp, m, precision);
     SSC_REQUIRE(d_workspace != nullptr && workspace_bytes >= need, "ssc_mlp_forward: workspace %zu < %zu bytes",
                 workspace_bytes, need);
-    if (precision == SSC_PREC_BF16_MFMA) {
+    if (is_mfma(precision)) {
         if (!dyn_mfma_supported(mlp, mlp->dims[0], 0))
             return set_error(SSC_EUNSUPPORTED, "ssc_mlp_forward: MFMA path needs 1-2 hidden layers of equal depth "
-                                               "<= 512, in <= 12, out <= 8");
-        return dyn_mfma_mlp_forward(mlp, m, d_x, d_y, d_workspace, as_stream(stream));
+                                               "<= 512, in <= 12 (<= 10 with 2 layers deeper than 128), out <= 8");
+        return dyn_mfma_mlp_forward(mlp, m, d_x, d_y, d_workspace, precision == SSC_PREC_BF16_MFMA_PREPARED,
+                                    as_stream(stream));
     }
     SSC_REQUIRE(precision == SSC_PREC_F32, "ssc_mlp_forward: unknown precision %d", precision);
     float *a0 = static_cast<float *>(d_workspace);
@@ -207,9 +212,20 @@ int ssc_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float 
     return mlp_forward_f32(mlp, m, d_x, d_y, a0, a1, as_stream(stream));
 }
 
+int ssc_dyn_prepare(const ssc_mlp_desc *mlp, const ssc_norm *norm, void *d_workspace, size_t workspace_bytes,
+                    ssc_stream_t stream) {
+    if (int rc = validate_mlp(mlp, "ssc_dyn_prepare")) return rc;
+    if (!dyn_mfma_supported(mlp, mlp->dims[0], 0))
+        return set_error(SSC_EUNSUPPORTED, "ssc_dyn_prepare: the MFMA path does not cover this network");
+    const size_t need = dyn_mfma_workspace_bytes(mlp);
+    SSC_REQUIRE(d_workspace != nullptr && workspace_bytes >= need, "ssc_dyn_prepare: workspace %zu < %zu bytes",
+                workspace_bytes, need);
+    return dyn_mfma_prepare(mlp, norm, d_workspace, as_stream(stream));
+}
+
 size_t ssc_dyn_workspace_bytes(const ssc_mlp_desc *mlp, int64_t m, int precision) {
     if (mlp == nullptr || m < 0 || mlp->n_layers < 1 || mlp->n_layers > SSC_MAX_LAYERS) return 0;
-    if (precision == SSC_PREC_BF16_MFMA) return dyn_mfma_workspace_bytes(mlp);
+    if (is_mfma(precision)) return dyn_mfma_workspace_bytes(mlp);
     // x [m][in] + z [m][out] + two activation buffers
     return align256((size_t)m * mlp->dims[0] * 4) + align256((size_t)m * mlp->dims[mlp->n_layers] * 4) +
            2 * align256((size_t)m * max_width(mlp) * 4);
@@ -233,11 +249,12 @@ int ssc_dyn_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m
     SSC_REQUIRE(d_workspace != nullptr && workspace_bytes >= need,
                 "ssc_dyn_forward_sim: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t s = as_stream(stream);
-    if (precision == SSC_PREC_BF16_MFMA) {
+    if (is_mfma(precision)) {
         if (!dyn_mfma_supported(mlp, state_dim, act_dim))
             return set_error(SSC_EUNSUPPORTED, "ssc_dyn_forward_sim: MFMA path needs 1-2 hidden layers of equal "
-                                               "depth <= 512");
-        return dyn_mfma_forward_sim(mlp, norm, m, H, state_dim, act_dim, d_s0, s0_rows, d_A, d_S, d_workspace, s);
+                                               "depth <= 512 (inputs <= 10 when 2 layers deeper than 128)");
+        return dyn_mfma_forward_sim(mlp, norm, m, H, state_dim, act_dim, d_s0, s0_rows, d_A, d_S, d_workspace,
+                                    precision == SSC_PREC_BF16_MFMA_PREPARED, s);
     }
     SSC_REQUIRE(precision == SSC_PREC_F32, "ssc_dyn_forward_sim: unknown precision %d", precision);
     char *w = static_cast<char *>(d_workspace);

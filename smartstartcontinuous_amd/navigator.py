@@ -37,9 +37,11 @@ class DynamicsModel:
         self.lib = _ffi.lib()
         self.state_dim, self.act_dim = int(state_dim), int(act_dim)
         self.precision = precision
+        self._ws = None
+        self._image = None          # packed bf16 weight image of the MFMA path (ssc_dyn_prepare)
+        self._image_stale = True
         self.set_weights(weights, biases)
         self.set_norm(norm)
-        self._ws = None
 
     def set_weights(self, weights, biases):
         """Weights are kernel ARGUMENTS, not baked in: the navigator retrains the model every
@@ -58,6 +60,13 @@ class DynamicsModel:
             d.W[l], d.b[l] = w.data_ptr(), b.data_ptr()
         self.desc = d
         self.in_dim, self.out_dim = d.dims[0], d.dims[d.n_layers]
+        self.invalidate()
+
+    def invalidate(self):
+        """The weights or statistics changed: the packed image of the MFMA path is rebuilt on the next
+        call.  ``set_weights``, ``set_norm`` and ``train_step`` call this; code that writes into
+        ``self.W`` / ``self.b`` in place must call it too."""
+        self._image_stale = True
 
     def set_norm(self, norm):
         nm = _ffi.Norm()
@@ -70,6 +79,7 @@ class DynamicsModel:
             for i in range(n):
                 arr[i] = float(v[i])
         self.norm = nm
+        self.invalidate()
 
     # ---- training (Dyn_Model.train, dynamics_model.py:52-171) ----------------------------------------
     def _train_desc(self, lr):
@@ -98,6 +108,7 @@ class DynamicsModel:
             ws = self._workspace(self.lib.ssc_mlp_train_workspace_bytes(ctypes.byref(d), B))
             _ffi.check(self.lib.ssc_mlp_train_step(ctypes.byref(d), _ffi.ptr(X), _ffi.ptr(Z), _ffi.ptr(idx), B,
                                                    _ffi.ptr(loss), _ffi.ptr(ws), ws.numel(), _stream()))
+        self.invalidate()
 
     def train(self, dataX, dataZ, dataX_new, dataZ_new, nEpoch, fraction_use_new, batchsize=512, lr=0.001,
               rng=None):
@@ -138,6 +149,19 @@ class DynamicsModel:
             self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def _mfma_image(self):
+        """Workspace holding the packed weight image, (re)written only after the weights changed -- the
+        weights stay resident between calls like TF variables across ``sess.run`` (dynamics_model.py:226-233)."""
+        nbytes = self.lib.ssc_dyn_workspace_bytes(ctypes.byref(self.desc), 1, _ffi.SSC_PREC_BF16_MFMA)
+        if self._image is None or self._image.numel() < nbytes:
+            self._image = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self._image_stale = True
+        if self._image_stale:
+            _ffi.check(self.lib.ssc_dyn_prepare(ctypes.byref(self.desc), ctypes.byref(self.norm),
+                                                _ffi.ptr(self._image), self._image.numel(), _stream()))
+            self._image_stale = False
+        return self._image
+
     def forward(self, x, precision=None):
         """z = feedforward_network(x): x [m, in] -> [m, out]."""
         prec = _PREC[precision or self.precision]
@@ -145,7 +169,10 @@ class DynamicsModel:
         m = x.shape[0]
         y = torch.empty((m, self.out_dim), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            ws = self._workspace(self.lib.ssc_mlp_workspace_bytes(ctypes.byref(self.desc), m, prec))
+            if prec == _ffi.SSC_PREC_BF16_MFMA:
+                ws, prec = self._mfma_image(), _ffi.SSC_PREC_BF16_MFMA_PREPARED
+            else:
+                ws = self._workspace(self.lib.ssc_mlp_workspace_bytes(ctypes.byref(self.desc), m, prec))
             _ffi.check(self.lib.ssc_mlp_forward(ctypes.byref(self.desc), m, _ffi.ptr(x), _ffi.ptr(y), prec,
                                                 _ffi.ptr(ws), ws.numel(), _stream()))
         return y
@@ -161,7 +188,10 @@ class DynamicsModel:
         S = out if out is not None else torch.empty((H + 1, m, self.state_dim), dtype=torch.float32,
                                                     device=self.device)
         with torch.cuda.device(self.device):
-            ws = self._workspace(self.lib.ssc_dyn_workspace_bytes(ctypes.byref(self.desc), m, prec))
+            if prec == _ffi.SSC_PREC_BF16_MFMA:
+                ws, prec = self._mfma_image(), _ffi.SSC_PREC_BF16_MFMA_PREPARED
+            else:
+                ws = self._workspace(self.lib.ssc_dyn_workspace_bytes(ctypes.byref(self.desc), m, prec))
             _ffi.check(self.lib.ssc_dyn_forward_sim(ctypes.byref(self.desc), ctypes.byref(self.norm), m, H,
                                                     self.state_dim, self.act_dim, _ffi.ptr(s0), s0_rows,
                                                     _ffi.ptr(A), _ffi.ptr(S), prec, _ffi.ptr(ws), ws.numel(),

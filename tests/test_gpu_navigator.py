@@ -354,3 +354,49 @@ def test_vecenv_rollout_with_mpc_policy(nav, golden_dir):
                 done_act[p] = 0
     assert ps.cur_idx.cpu().tolist() == idx and batch.actions_done.cpu().tolist() == done_act
     assert env.stats.cpu().numpy()[2] == P * K and env.t == K
+
+
+def test_mfma_prepared_image_matches_per_call_pack_and_tracks_weight_changes(nav):
+    """ssc_dyn_prepare + SSC_PREC_BF16_MFMA_PREPARED (what DynamicsModel uses) == the per-call pack of
+    SSC_PREC_BF16_MFMA, bit for bit; the image follows set_weights / set_norm / train_step."""
+    import ctypes
+    from smartstartcontinuous_amd import _ffi
+    rng = np.random.default_rng(5)
+    dims, H, m = (4, 500, 500, 3), 3, 700
+    Ws, bs = make_mlp(rng, dims)
+    norm = make_norm(rng, 3, 1)
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=3, act_dim=1, precision="bf16_mfma")
+    A = torch.as_tensor(rng.uniform(-1, 1, size=(m, H, 1)).astype(np.float32), device="cuda")
+    s0 = torch.as_tensor(rng.normal(size=(m, 3)).astype(np.float32) * 0.3, device="cuda")
+
+    def per_call_pack():
+        lib = _ffi.lib()
+        S = torch.empty((H + 1, m, 3), dtype=torch.float32, device="cuda")
+        nbytes = lib.ssc_dyn_workspace_bytes(ctypes.byref(model.desc), m, _ffi.SSC_PREC_BF16_MFMA)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        _ffi.check(lib.ssc_dyn_forward_sim(ctypes.byref(model.desc), ctypes.byref(model.norm), m, H, 3, 1,
+                                           _ffi.ptr(s0), m, _ffi.ptr(A), _ffi.ptr(S), _ffi.SSC_PREC_BF16_MFMA,
+                                           _ffi.ptr(ws), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        return S.cpu().numpy()
+
+    S1 = model.do_forward_sim(s0, A).cpu().numpy()
+    assert not model._image_stale and np.array_equal(S1, per_call_pack())
+    assert np.array_equal(model.do_forward_sim(s0, A).cpu().numpy(), S1)          # image reused
+    # new weights -> new image
+    Ws2, bs2 = make_mlp(rng, dims)
+    model.set_weights(Ws2, bs2)
+    S2 = model.do_forward_sim(s0, A).cpu().numpy()
+    assert not np.array_equal(S2, S1) and np.array_equal(S2, per_call_pack())
+    ref = O.dyn_forward_sim(s0.cpu().numpy(), A.cpu().numpy(), norm32(norm), Ws2, bs2)
+    assert np.max(np.abs(S2 - ref)) <= 3e-2 * max(1.0, np.abs(ref).max())
+    # new statistics -> new image
+    norm2 = make_norm(rng, 3, 1)
+    model.set_norm(norm2)
+    S3 = model.do_forward_sim(s0, A).cpu().numpy()
+    assert not np.array_equal(S3, S2) and np.array_equal(S3, per_call_pack())
+    # a training step moves the weights in place -> the image follows
+    X = torch.as_tensor(rng.normal(size=(64, 4)).astype(np.float32), device="cuda")
+    Z = torch.as_tensor(rng.normal(size=(64, 3)).astype(np.float32), device="cuda")
+    model.train_step(X, Z, torch.arange(64, dtype=torch.int32, device="cuda"), lr=0.01)
+    S4 = model.do_forward_sim(s0, A).cpu().numpy()
+    assert not np.array_equal(S4, S3) and np.array_equal(S4, per_call_pack())

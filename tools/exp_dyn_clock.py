@@ -19,13 +19,19 @@ while time.time() - t0 < 2.0:
     torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); model.do_forward_sim(s0, A, precision="bf16_mfma", out=S); e1.record(); torch.cuda.synchronize()
-raw = S.view(torch.int32).flatten()[: 24 * (M // 256)].cpu().numpy().astype(np.uint32).reshape(-1, 2, 6, 2).astype(np.uint64)
-v = raw[..., 0] | (raw[..., 1] << np.uint64(32))       # [block][group][dc, dr, input, layer 1, hidden tiles, tail]
+raw = S.view(torch.int32).flatten()[: 32 * (M // 256)].cpu().numpy().astype(np.uint32).reshape(-1, 2, 8, 2).astype(np.uint64)
+v = raw[..., 0] | (raw[..., 1] << np.uint64(32))       # [block][group][dc, dr, input, layer 1, hidden tiles, tail, entry_rt, loop_rt]
 dc, dr = v[:, 0, 0], v[:, 0, 1]
 clk = dc / dr * 100.0
 mf = 560 * 2 * 32 * H   # MFMA pipe cycles per SIMD for the step loop (2 waves x 17920 cyc of MFMAs per step)
 print("launch %.4f ms; blocks %d; step-loop cycles median %.0f (%.0f per step); realtime median %.1f us; clock median %.0f MHz (min %.0f max %.0f); MFMA floor %.0f cyc -> pipe busy %.1f %%"
       % (e0.elapsed_time(e1), len(dc), np.median(dc), np.median(dc) / H, np.median(dr) / 100.0, np.median(clk), clk.min(), clk.max(), mf, 100.0 * mf / np.median(dc)))
 for gi in range(2):
-    ph = np.median(v[:, gi, 2:].astype(np.int64), axis=0) / H
+    ph = np.median(v[:, gi, 2:6].astype(np.int64), axis=0) / H
     print("group %d per step: input code %.0f, layer 1 %.0f, hidden tiles %.0f (%.0f each), step tail %.0f cycles" % (gi, ph[0], ph[1], ph[2], ph[2] / 16, ph[3]))
+entry, loop0 = v[:, 0, 6].astype(np.int64), v[:, 0, 7].astype(np.int64)
+exit_ = loop0 + v[:, 0, 1].astype(np.int64)
+t0 = entry.min()
+print("realtime (us): kernel span first entry -> last exit %.1f; block entry stagger median %.1f max %.1f; entry -> step loop median %.1f max %.1f; step loop median %.1f max %.1f; last exit - median exit %.1f"
+      % ((exit_.max() - t0) / 100.0, np.median(entry - t0) / 100.0, (entry - t0).max() / 100.0, np.median(loop0 - entry) / 100.0, (loop0 - entry).max() / 100.0,
+         np.median(exit_ - loop0) / 100.0, (exit_ - loop0).max() / 100.0, (exit_.max() - np.median(exit_)) / 100.0))
