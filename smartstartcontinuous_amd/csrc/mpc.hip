@@ -10,9 +10,9 @@
 // of the problem.  Hence two passes:
 //   pass A  per sample: waypoint-index trajectory + per-t partial sums of a.b and b.b (f64)
 //           -> deterministic per-block partials (no float atomics: bitwise reproducible)
-//   pass B  per block: fixed-order reduction of the partials -> G1_t, G2_t; per sample: replay the
-//           trajectory, add progress and penalty terms -> score; block argmax (lowest index wins)
-//   pass C  per problem: argmax over blocks.
+//   pass B  per block: fixed-order reduction of the partials -> G1_t / G2_t; per sample: replay the
+//           trajectory, add progress and penalty terms -> score; block argmax (lowest index wins);
+//           the block of a problem that finishes last (atomic ticket) reduces the per-block winners.
 // HBM traffic is the [H+1][P*N][d] trajectory read twice (8 B/sample-step for d=2) -- negligible
 // next to the forward simulation that produced it.
 #include "ssc_device.h"
@@ -43,62 +43,114 @@ __device__ __forceinline__ float ell_dist(const float *x, const float *y, const 
     return sqrtf(s);
 }
 
-// One sample's walk over the horizon.  PASS 0: accumulate a.b / b.b per t into sums[t][2].
-// PASS 1: compute the score using the global G1/G2 per t.
+// State of one sample's walk over the horizon
+struct WalkState {
+    int idx;
+    float score, prev, gpow;
+    bool live;  // false: a lane past the last sample; it walks along (wave reductions) and contributes nothing
+};
+
+// One horizon step t of one sample at point pt.  PASS 0: accumulate a.b / b.b into sums[t][2].
+// PASS 1: add the progress and penalty terms to the score using the global G1/G2 of step t.
 template <int PASS>
-__device__ __forceinline__ float mpc_walk(const MpcArgs &a, const float *__restrict__ S, int64_t row, int64_t M,
-                                          const float *wps, const float *lefts, int W, int idx0,
-                                          const float *inv_r, double (*sums)[2], const double (*G)[2]) {
+__device__ __forceinline__ void walk_step(const MpcArgs &a, const float *pt, int t, const float *wps, const float *lefts,
+                                          int W, const float *inv_r, double *wave_sums, const float *cproj,
+                                          WalkState &w) {
     const int d = a.d;
-    float pt[SSC_MAX_STATE];
-    int idx = idx0;
-    float score = 0.0f;
-    float prev = 0.0f;
-    float gpow = 1.0f;
-    for (int t = 0; t <= a.H; ++t) {
-        const float *p = S + ((int64_t)t * M + row) * d;
+    if (t == 0) w.prev = lefts[w.idx] + ell_dist(pt, wps + w.idx * d, inv_r, d);  // NND_MB_agent.py:573-576
+    const int nxt = min(w.idx + 1, W - 1);
+    float dc = ell_dist(wps + w.idx * d, pt, inv_r, d);   // :589
+    const float dn = ell_dist(wps + nxt * d, pt, inv_r, d);  // :590
+    const bool move = (dc <= a.theta || dn <= dc) && w.idx != W - 1;  // move_to_next :491-496
+    w.idx += move ? 1 : 0;                                // :600
+    dc = move ? dn : dc;                                  // :603
+    const float end = lefts[w.idx] + dc;                  // :606
+    if (PASS == 1) w.score += (w.prev - end) * w.gpow;    // :609
+    w.prev = end;                                         // :610
+    const int b = max(w.idx - 1, 0);                      // :615
+    // dist_line_seg_to_point (numerical.py:74-81) in radii-scaled coordinates
+    float ab = 0.0f, bb = 0.0f;
+    float av[SSC_MAX_STATE], bv[SSC_MAX_STATE];
 #pragma unroll
-        for (int k = 0; k < SSC_MAX_STATE; ++k) pt[k] = (k < d) ? p[k] : 0.0f;
-        if (t == 0) prev = lefts[idx] + ell_dist(pt, wps + idx * d, inv_r, d);  // NND_MB_agent.py:573-576
-        const int nxt = min(idx + 1, W - 1);
-        float dc = ell_dist(wps + idx * d, pt, inv_r, d);   // :589
-        const float dn = ell_dist(wps + nxt * d, pt, inv_r, d);  // :590
-        const bool move = (dc <= a.theta || dn <= dc) && idx != W - 1;  // move_to_next :491-496
-        idx += move ? 1 : 0;                                // :600
-        dc = move ? dn : dc;                                // :603
-        const float end = lefts[idx] + dc;                  // :606
-        if (PASS == 1) score += (prev - end) * gpow;        // :609
-        prev = end;                                         // :610
-        const int b = max(idx - 1, 0);                      // :615
-        // dist_line_seg_to_point (numerical.py:74-81) in radii-scaled coordinates
-        float ab = 0.0f, bb = 0.0f;
-        float av[SSC_MAX_STATE], bv[SSC_MAX_STATE];
+    for (int k = 0; k < SSC_MAX_STATE; ++k)
+        if (k < d) {
+            av[k] = (pt[k] - wps[b * d + k]) * inv_r[k];
+            bv[k] = (wps[(b + 1) * d + k] - wps[b * d + k]) * inv_r[k];
+            ab = fmaf(av[k], bv[k], ab);
+            bb = fmaf(bv[k], bv[k], bb);
+        }
+    if (PASS == 0) {
+        // every lane of the wave is at the same t: reduce now (fixed butterfly order) instead of keeping a
+        // per-thread [H+1][2] array of doubles, which a runtime t would push into scratch memory
+        double v0 = w.live ? (double)ab : 0.0, v1 = w.live ? (double)bb : 0.0;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            v0 += __shfl_xor(v0, m);
+            v1 += __shfl_xor(v1, m);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            wave_sums[t * 2 + 0] = v0;
+            wave_sums[t * 2 + 1] = v1;
+        }
+    } else {
+        // proj = (sum(a.b) / sum(b.b)) * b ; distance(proj, a)   (numerical.py:84-98 + :116-124)
+        const float c = a.per_row ? ab / bb : cproj[t];
+        float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < SSC_MAX_STATE; ++k)
             if (k < d) {
-                av[k] = (pt[k] - wps[b * d + k]) * inv_r[k];
-                bv[k] = (wps[(b + 1) * d + k] - wps[b * d + k]) * inv_r[k];
-                ab = fmaf(av[k], bv[k], ab);
-                bb = fmaf(bv[k], bv[k], bb);
+                const float v = fmaf(c, bv[k], -av[k]);
+                s = fmaf(v, v, s);
             }
-        if (PASS == 0) {
-            sums[t][0] += (double)ab;
-            sums[t][1] += (double)bb;
-        } else {
-            // proj = (sum(a.b) / sum(b.b)) * b ; distance(proj, a)   (numerical.py:84-98 + :116-124)
-            const float c = a.per_row ? ab / bb : (float)(G[t][0] / G[t][1]);
-            float s = 0.0f;
-#pragma unroll
-            for (int k = 0; k < SSC_MAX_STATE; ++k)
-                if (k < d) {
-                    const float v = fmaf(c, bv[k], -av[k]);
-                    s = fmaf(v, v, s);
-                }
-            score -= sqrtf(s) * a.hpf * a.gamma;  // :622 (gamma, not gamma^t)
-            gpow *= a.gamma;
-        }
+        w.score -= sqrtf(s) * a.hpf * a.gamma;  // :622 (gamma, not gamma^t)
+        w.gpow *= a.gamma;
     }
-    return score;
+}
+
+// One sample's walk, trajectory points read from S step by step (any horizon / state dim)
+template <int PASS>
+__device__ __forceinline__ float mpc_walk(const MpcArgs &a, const float *__restrict__ S, int64_t row, int64_t M,
+                                          const float *wps, const float *lefts, int W, int idx0,
+                                          const float *inv_r, bool live, double *wave_sums, const float *cproj) {
+    const int d = a.d;
+    float pt[SSC_MAX_STATE];
+    WalkState w{idx0, 0.0f, 0.0f, 1.0f, live};
+    for (int t = 0; t <= a.H; ++t) {
+        const float *p = S + ((int64_t)t * M + row) * d;
+#pragma unroll
+        for (int k = 0; k < SSC_MAX_STATE; ++k) pt[k] = (live && k < d) ? p[k] : 0.0f;
+        walk_step<PASS>(a, pt, t, wps, lefts, W, inv_r, wave_sums, cproj, w);
+    }
+    return w.score;
+}
+
+// The same walk with the whole trajectory of the sample fetched up front (H + 1 <= kPreT, d <= kPreD): all
+// loads are in flight together, one memory latency per sample instead of one per horizon step.
+constexpr int kPreT = 8, kPreD = 4;
+template <int PASS>
+__device__ __forceinline__ float mpc_walk_pre(const MpcArgs &a, const float *__restrict__ S, int64_t row, int64_t M,
+                                              const float *wps, const float *lefts, int W, int idx0,
+                                              const float *inv_r, bool live, double *wave_sums, const float *cproj) {
+    float pts[kPreT][SSC_MAX_STATE];
+#pragma unroll
+    for (int t = 0; t < kPreT; ++t)
+#pragma unroll
+        for (int k = 0; k < SSC_MAX_STATE; ++k)
+            pts[t][k] = (live && k < kPreD && t <= a.H && k < a.d) ? S[((int64_t)t * M + row) * a.d + k] : 0.0f;
+    WalkState w{idx0, 0.0f, 0.0f, 1.0f, live};
+#pragma unroll
+    for (int t = 0; t < kPreT; ++t)
+        if (t <= a.H) walk_step<PASS>(a, pts[t], t, wps, lefts, W, inv_r, wave_sums, cproj, w);
+    return w.score;
+}
+
+template <int PASS>
+__device__ __forceinline__ float mpc_walk_any(const MpcArgs &a, const float *__restrict__ S, int64_t row, int64_t M,
+                                              const float *wps, const float *lefts, int W, int idx0,
+                                              const float *inv_r, bool live, double *wave_sums, const float *cproj) {
+    if (a.H + 1 <= kPreT && a.d <= kPreD)  // block-uniform
+        return mpc_walk_pre<PASS>(a, S, row, M, wps, lefts, W, idx0, inv_r, live, wave_sums, cproj);
+    return mpc_walk<PASS>(a, S, row, M, wps, lefts, W, idx0, inv_r, live, wave_sums, cproj);
 }
 
 __device__ __forceinline__ void load_problem(const MpcArgs &a, int p, float *wps, float *lefts, float *inv_r,
@@ -112,71 +164,8 @@ __device__ __forceinline__ void load_problem(const MpcArgs &a, int p, float *wps
     __syncthreads();
 }
 
-// dynamic LDS: wps [Wmax*d] | lefts [Wmax] | inv_r [8] | (pass B) G [(H+1)][2] doubles | reduction scratch
-__global__ __launch_bounds__(kMpcBlock) void mpc_pass_a_kernel(MpcArgs a, int Wmax, const float *__restrict__ S,
-                                                               double *__restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *red = reinterpret_cast<double *>(smem);  // [4 waves][H+1][2]
-    float *wps = reinterpret_cast<float *>(red + 4 * kMaxH1 * 2);
-    float *lefts = wps + Wmax * a.d;
-    float *inv_r = lefts + Wmax;
-    const int p = blockIdx.y;
-    int W, idx0;
-    load_problem(a, p, wps, lefts, inv_r, W, idx0);
-    const int n = blockIdx.x * kMpcBlock + threadIdx.x;
-    double sums[kMaxH1][2];
-    for (int t = 0; t <= a.H; ++t) sums[t][0] = sums[t][1] = 0.0;
-    if (n < a.N)
-        mpc_walk<0>(a, S, (int64_t)p * a.N + n, (int64_t)a.P * a.N, wps, lefts, W, idx0, inv_r, sums, nullptr);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int t = 0; t <= a.H; ++t)
-        for (int q = 0; q < 2; ++q) {
-            double v = sums[t][q];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-            if (lane == 0) red[(wave * kMaxH1 + t) * 2 + q] = v;
-        }
-    __syncthreads();
-    for (int e = threadIdx.x; e < (a.H + 1) * 2; e += kMpcBlock) {
-        const int t = e >> 1, q = e & 1;
-        double v = 0.0;
-        for (int w = 0; w < kMpcBlock / 64; ++w) v += red[(w * kMaxH1 + t) * 2 + q];
-        partial[(((int64_t)p * a.nblk + blockIdx.x) * (a.H + 1) + t) * 2 + q] = v;
-    }
-}
-
-__global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wmax, const float *__restrict__ S,
-                                                               const double *__restrict__ partial,
-                                                               float *__restrict__ scores,
-                                                               float *__restrict__ blk_best_score,
-                                                               int32_t *__restrict__ blk_best_idx) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double(*G)[2] = reinterpret_cast<double(*)[2]>(smem);  // [H+1][2]
-    float *rs = reinterpret_cast<float *>(G + kMaxH1);      // [4] block argmax scratch
-    int *ri = reinterpret_cast<int *>(rs + 4);
-    float *wps = reinterpret_cast<float *>(ri + 4);
-    float *lefts = wps + Wmax * a.d;
-    float *inv_r = lefts + Wmax;
-    const int p = blockIdx.y;
-    // fixed-order reduction of the per-block partials of this problem
-    for (int e = threadIdx.x; e < (a.H + 1) * 2; e += kMpcBlock) {
-        const int t = e >> 1, q = e & 1;
-        double v = 0.0;
-        for (int b = 0; b < a.nblk; ++b) v += partial[(((int64_t)p * a.nblk + b) * (a.H + 1) + t) * 2 + q];
-        G[t][q] = v;
-    }
-    int W, idx0;
-    load_problem(a, p, wps, lefts, inv_r, W, idx0);  // ends with __syncthreads()
-    const int n = blockIdx.x * kMpcBlock + threadIdx.x;
-    float score = -INFINITY;
-    int best = 0x7fffffff;
-    if (n < a.N) {
-        score = mpc_walk<1>(a, S, (int64_t)p * a.N + n, (int64_t)a.P * a.N, wps, lefts, W, idx0, inv_r, nullptr, G);
-        scores[(int64_t)p * a.N + n] = score;
-        best = n;
-        if (isnan(score)) score = -INFINITY;  // np.argmax would return the first NaN; we skip NaNs
-    }
-    // argmax, lowest index on ties (np.argmax, NND_MB_agent.py:626)
+// argmax over the block, lowest index on ties (np.argmax, NND_MB_agent.py:626); result valid in thread 0
+__device__ __forceinline__ void block_argmax(float &score, int &best, float *rs, int *ri) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const float os = __shfl_xor(score, m);
@@ -186,29 +175,96 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wm
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) { rs[wave] = score; ri[wave] = best; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0)
         for (int w = 1; w < kMpcBlock / 64; ++w)
             if (rs[w] > score || (rs[w] == score && ri[w] < best)) { score = rs[w]; best = ri[w]; }
-        blk_best_score[p * a.nblk + blockIdx.x] = score;
-        blk_best_idx[p * a.nblk + blockIdx.x] = best;
+}
+
+// dynamic LDS: reduction scratch | wps [Wmax*d] | lefts [Wmax] | inv_r [8]
+__global__ __launch_bounds__(kMpcBlock) void mpc_pass_a_kernel(MpcArgs a, int Wmax, const float *__restrict__ S,
+                                                               double *__restrict__ partial,
+                                                               int32_t *__restrict__ ticket) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);  // [4 waves][H+1][2]
+    float *wps = reinterpret_cast<float *>(red + 4 * kMaxH1 * 2);
+    float *lefts = wps + Wmax * a.d;
+    float *inv_r = lefts + Wmax;
+    const int p = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ticket[p] = 0;  // pass B elects its last block with it
+    int W, idx0;
+    load_problem(a, p, wps, lefts, inv_r, W, idx0);
+    const int n = blockIdx.x * kMpcBlock + threadIdx.x;
+    const bool live = n < a.N;
+    mpc_walk_any<0>(a, S, (int64_t)p * a.N + (live ? n : 0), (int64_t)a.P * a.N, wps, lefts, W, idx0, inv_r, live,
+                    red + (threadIdx.x >> 6) * kMaxH1 * 2, nullptr);
+    __syncthreads();
+    for (int e = threadIdx.x; e < (a.H + 1) * 2; e += kMpcBlock) {
+        double v = 0.0;
+        for (int w = 0; w < kMpcBlock / 64; ++w) v += red[w * kMaxH1 * 2 + e];
+        partial[((int64_t)p * a.nblk + blockIdx.x) * (a.H + 1) * 2 + e] = v;
     }
 }
 
-__global__ __launch_bounds__(64) void mpc_pass_c_kernel(int P, int nblk, const float *__restrict__ blk_best_score,
-                                                        const int32_t *__restrict__ blk_best_idx,
-                                                        int32_t *__restrict__ best_idx,
-                                                        float *__restrict__ best_score) {
-    const int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= P) return;
-    float s = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int b = 0; b < nblk; ++b) {
-        const float os = blk_best_score[p * nblk + b];
-        const int oi = blk_best_idx[p * nblk + b];
-        if (os > s || (os == s && oi < bi)) { s = os; bi = oi; }
+__global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wmax, const float *__restrict__ S,
+                                                               const double *__restrict__ partial,
+                                                               float *__restrict__ scores,
+                                                               float *blk_best_score, int32_t *blk_best_idx,
+                                                               int32_t *__restrict__ ticket,
+                                                               int32_t *__restrict__ best_idx,
+                                                               float *__restrict__ best_score) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *cproj = reinterpret_cast<float *>(smem);  // [H+1] sum(a.b) / sum(b.b) of the whole problem
+    float *rs = cproj + kMaxH1 + 1;                   // [4] block argmax scratch
+    int *ri = reinterpret_cast<int *>(rs + 4);
+    int *last = ri + 4;
+    float *wps = reinterpret_cast<float *>(last + 2);
+    float *lefts = wps + Wmax * a.d;
+    float *inv_r = lefts + Wmax;
+    const int p = blockIdx.y;
+    // fixed-order reduction of the per-block partials of this problem
+    for (int t = threadIdx.x; t <= a.H; t += kMpcBlock) {
+        double g0 = 0.0, g1 = 0.0;
+        for (int b = 0; b < a.nblk; ++b) {
+            g0 += partial[(((int64_t)p * a.nblk + b) * (a.H + 1) + t) * 2 + 0];
+            g1 += partial[(((int64_t)p * a.nblk + b) * (a.H + 1) + t) * 2 + 1];
+        }
+        cproj[t] = (float)(g0 / g1);
     }
-    best_idx[p] = (bi == 0x7fffffff) ? 0 : bi;
-    if (best_score) best_score[p] = s;
+    int W, idx0;
+    load_problem(a, p, wps, lefts, inv_r, W, idx0);  // ends with __syncthreads()
+    const int n = blockIdx.x * kMpcBlock + threadIdx.x;
+    float score = -INFINITY;
+    int best = 0x7fffffff;
+    if (n < a.N) {
+        score = mpc_walk_any<1>(a, S, (int64_t)p * a.N + n, (int64_t)a.P * a.N, wps, lefts, W, idx0, inv_r, true,
+                                nullptr, cproj);
+        scores[(int64_t)p * a.N + n] = score;
+        best = n;
+        if (isnan(score)) score = -INFINITY;  // np.argmax would return the first NaN; we skip NaNs
+    }
+    block_argmax(score, best, rs, ri);
+    // the block that finishes last reduces the per-block winners of its problem (no third launch)
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&blk_best_score[p * a.nblk + blockIdx.x], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&blk_best_idx[p * a.nblk + blockIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int tk = __hip_atomic_fetch_add(&ticket[p], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last[0] = (tk == a.nblk - 1);
+    }
+    __syncthreads();
+    if (!last[0]) return;
+    score = -INFINITY;
+    best = 0x7fffffff;
+    for (int b = threadIdx.x; b < a.nblk; b += kMpcBlock) {
+        const float os = __hip_atomic_load(&blk_best_score[p * a.nblk + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int oi = __hip_atomic_load(&blk_best_idx[p * a.nblk + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (os > score || (os == score && oi < best)) { score = os; best = oi; }
+    }
+    __syncthreads();  // rs/ri are reused
+    block_argmax(score, best, rs, ri);
+    if (threadIdx.x == 0) {
+        best_idx[p] = (best == 0x7fffffff) ? 0 : best;
+        if (best_score) best_score[p] = score;
+    }
 }
 
 struct ActBounds {
@@ -322,7 +378,7 @@ size_t ssc_mpc_score_workspace_bytes(int32_t P, int32_t N, int32_t H) {
     if (P <= 0 || N <= 0 || H < 0) return 256;
     const size_t nblk = (size_t)(N + kMpcBlock - 1) / kMpcBlock;
     return align256((size_t)P * nblk * (H + 1) * 2 * sizeof(double)) + align256((size_t)P * nblk * 4) +
-           align256((size_t)P * nblk * 4);
+           align256((size_t)P * nblk * 4) + align256((size_t)P * 4);
 }
 
 int ssc_mpc_score(const ssc_mpc_problems *pr, const float *d_S, float *d_scores, int32_t *d_best_idx,
@@ -353,14 +409,15 @@ int ssc_mpc_score(const ssc_mpc_problems *pr, const float *d_S, float *d_scores,
     float *bbs = reinterpret_cast<float *>(w);
     w += align256((size_t)a.P * a.nblk * 4);
     int32_t *bbi = reinterpret_cast<int32_t *>(w);
+    w += align256((size_t)a.P * a.nblk * 4);
+    int32_t *ticket = reinterpret_cast<int32_t *>(w);
     const size_t lds_common = (size_t)Wmax * (a.d + 1) * 4 + 8 * 4;
     const size_t lds_a = 4 * kMaxH1 * 2 * sizeof(double) + lds_common;
-    const size_t lds_b = kMaxH1 * 2 * sizeof(double) + 8 * 4 + lds_common;
+    const size_t lds_b = (kMaxH1 + 1 + 4 + 4 + 2) * 4 + lds_common;
     const dim3 grid(a.nblk, a.P);
-    hipLaunchKernelGGL(mpc_pass_a_kernel, grid, dim3(kMpcBlock), lds_a, s, a, Wmax, d_S, partial);
-    hipLaunchKernelGGL(mpc_pass_b_kernel, grid, dim3(kMpcBlock), lds_b, s, a, Wmax, d_S, partial, d_scores, bbs, bbi);
-    hipLaunchKernelGGL(mpc_pass_c_kernel, dim3((a.P + 63) / 64), dim3(64), 0, s, a.P, a.nblk, bbs, bbi, d_best_idx,
-                       d_best_score);
+    hipLaunchKernelGGL(mpc_pass_a_kernel, grid, dim3(kMpcBlock), lds_a, s, a, Wmax, d_S, partial, ticket);
+    hipLaunchKernelGGL(mpc_pass_b_kernel, grid, dim3(kMpcBlock), lds_b, s, a, Wmax, d_S, partial, d_scores, bbs, bbi,
+                       ticket, d_best_idx, d_best_score);
     return check_launch("ssc_mpc_score");
 }
 

@@ -133,10 +133,12 @@ def test_mpc_score_reference_kats(nav, golden_dir):
         assert ref[int(np.argmax(scores[0]))] >= ref.max() - 1e-3 * np.maximum(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("per_row", [False, True])
-def test_mpc_score_multi_problem(nav, per_row):
+@pytest.mark.parametrize("per_row,P,N", [(False, 5, 1000), (True, 5, 1000), (False, 3, 37), (False, 2, 8192),
+                                         (False, 2, 9001), (True, 2, 9001)])
+def test_mpc_score_multi_problem(nav, per_row, P, N):
+    """N <= 8192 takes the fused one-block-per-problem kernel, larger N the three-pass path."""
     rng = np.random.default_rng(11)
-    P, N, H, d = 5, 1000, 4, 2
+    H, d = 4, 2
     wps, lefts, radii, cur = [], [], [], []
     S = np.empty((H + 1, P, N, d))
     for p in range(P):
