@@ -343,6 +343,32 @@ typedef struct ssc_replay_view {
     int64_t capacity;
 } ssc_replay_view;
 
+/* The same storage, writable: a device-resident replay ring fed straight from rollout chunks.  Record
+ * number j (counted since the ring was created) lives at row j % capacity -- the FIFO of the reference's
+ * deque (replay_buffer.py:53-72): once full, the oldest record is overwritten.  act_dim must be 1. */
+typedef struct ssc_replay_ring {
+    float *s, *a, *r;
+    uint8_t *t;
+    float *s2;
+    int64_t capacity;
+    int32_t obs_dim, act_dim;
+} ssc_replay_ring;
+
+/* ReplayBuffer.add for a whole rollout chunk (replay_buffer.py:49-74; called per step from
+ * DDPG_Baselines_agent.observe, DDPG_Baselines_agent.py:238-240, which scales the reward): appends the
+ * K*n records of `log` ([K][n] SoA columns as ssc_rollout wrote them; record order = step-major, then env)
+ * after the `start` records appended so far.  The caller keeps the running count (start += K*n); it is
+ * deterministic, so no device counter and no host sync is needed. */
+int ssc_replay_append(const ssc_replay_ring *ring, const ssc_transition_log *log, int32_t K, int64_t n,
+                      int64_t start, float reward_scale, ssc_stream_t stream);
+
+/* ReplayBuffer.sample_batch (replay_buffer.py:79-91: random.sample, i.e. uniform WITHOUT replacement
+ * inside a batch) for n_batches batches at once: d_idx [n_batches][batch_size] row indices in
+ * [0, size), size = min(records appended, capacity) >= batch_size, batch_size <= 64.
+ * Philox(seed; counter0 + batch, attempt << 8 | slot, TAG_REPLAY); oracle: replay_sample_indices. */
+int ssc_replay_sample(uint64_t seed, uint64_t counter0, int64_t size, int32_t n_batches, int32_t batch_size,
+                      int32_t *d_idx, ssc_stream_t stream);
+
 /* n_iters sequential training iterations in ONE launch (one workgroup: the iterations are a serial
  * chain through the parameters).  d_batch_idx [n_iters][batch_size] are record indices
  * (ReplayBuffer.sample_batch, replay_buffer.py:79-91, draws them on the host).  d_losses

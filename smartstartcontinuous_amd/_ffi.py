@@ -113,6 +113,11 @@ class ReplayView(Structure):
                 ("capacity", c_int64)]
 
 
+class ReplayRing(Structure):
+    _fields_ = [("s", c_void_p), ("a", c_void_p), ("r", c_void_p), ("t", c_void_p), ("s2", c_void_p),
+                ("capacity", c_int64), ("obs_dim", c_int32), ("act_dim", c_int32)]
+
+
 # symbol -> (restype, argtypes); every function include/ssc.h declares must be listed here
 # (tests/test_abi.py cross-checks the header against this table and the built library).
 _SIGNATURES = {
@@ -138,6 +143,9 @@ _SIGNATURES = {
                                  c_void_p]),
     "ssc_ucb_argmax": (c_int, [c_int64, c_void_p, c_void_p, c_float, c_float, c_double, c_double, c_void_p, c_void_p,
                                c_void_p]),
+    "ssc_replay_append": (c_int, [POINTER(ReplayRing), POINTER(TransitionLog), c_int32, c_int64, c_int64, c_float,
+                                  c_void_p]),
+    "ssc_replay_sample": (c_int, [c_uint64, c_uint64, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ssc_ddpg_train": (c_int, [POINTER(DdpgDesc), POINTER(ReplayView), c_void_p, c_int32, c_void_p, c_void_p]),
     "ssc_mlp_train_workspace_bytes": (c_size_t, [POINTER(MlpTrainDesc), c_int32]),
     "ssc_mlp_train_step": (c_int, [POINTER(MlpTrainDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,

@@ -315,6 +315,16 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
                                                _ffi.ptr(losses), _stream()))
         return losses
 
+    def train_from(self, device_replay, n_iters=None):
+        """``train()`` on a :class:`DeviceReplayBuffer`: batch indices drawn on the device, the records read
+        where the rollout left them -- nothing crosses PCIe.  Returns the loss tensor [n_iters, 2] or None."""
+        if len(device_replay) < self.batch_size:
+            return None                                          # DDPG_Baselines_agent.py:265-266
+        n = self.num_train_iterations if n_iters is None else int(n_iters)
+        idx = device_replay.sample_indices(n, self.batch_size)
+        r = device_replay
+        return self.train_on(r.s, r.a, r.r, r.t, r.s2, idx, n)
+
     def train(self):
         """DDPG_Baselines_agent.train (:264-273): ``num_train_iterations`` x (train + update_target_net),
         each on a fresh uniform batch -- all iterations in one kernel launch."""

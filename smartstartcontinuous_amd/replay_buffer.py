@@ -186,3 +186,80 @@ class _BufferView:
         p = int(self.rb._phys(i))
         rb = self.rb
         return (rb._s[p], rb._a[p], rb._r[p], bool(rb._t[p]), rb._s2[p])
+
+
+class DeviceReplayBuffer:
+    """Device-resident replay ring for the vectorised loop: the storage of :class:`ReplayBuffer`
+    (replay_buffer.py:49-74 of the reference -- FIFO of (s, a, r, t, s2) records, oldest overwritten) kept in
+    HBM and fed straight from rollout chunks (``ssc_replay_append``); minibatch indices are drawn on the
+    device too (``ssc_replay_sample``, uniform without replacement inside a batch like ``random.sample``,
+    replay_buffer.py:79-83), so rollout -> replay -> ``ssc_ddpg_train`` never goes through the host.
+
+    The SmartStart index queries (episode starts, smart-start paths) stay with the host
+    :class:`ReplayBuffer`; this ring serves the learner's data path."""
+
+    def __init__(self, capacity, obs_dim, act_dim=1, device="cuda", seed=0):
+        import ctypes
+        import torch
+        from . import _ffi
+        self._ctypes, self._torch, self._ffi = ctypes, torch, _ffi
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceReplayBuffer lives on the GPU; the host ring is ReplayBuffer")
+        if act_dim != 1:
+            raise ValueError("the transition log carries one action column")
+        self.lib = _ffi.lib()
+        self.capacity, self.obs_dim, self.act_dim = int(capacity), int(obs_dim), int(act_dim)
+        f = lambda *shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=self.device)
+        self.s, self.s2 = f(self.capacity, obs_dim), f(self.capacity, obs_dim)
+        self.a, self.r = f(self.capacity, act_dim), f(self.capacity)
+        self.t = f(self.capacity, dt=torch.uint8)
+        self.count = 0            # records appended so far (the reference's running next_episode_number-like count)
+        self.seed, self._batches_drawn = int(seed), 0
+
+    def __len__(self):
+        return min(self.count, self.capacity)
+
+    size = __len__
+
+    def _stream(self):
+        return self._ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def ring_struct(self):
+        r = self._ffi.ReplayRing()
+        r.s, r.a, r.r, r.t, r.s2 = (x.data_ptr() for x in (self.s, self.a, self.r, self.t, self.s2))
+        r.capacity, r.obs_dim, r.act_dim = self.capacity, self.obs_dim, self.act_dim
+        return r
+
+    def append_chunk(self, chunk, reward_scale=1.0, last_steps=None):
+        """``ReplayBuffer.add`` for every record of a :class:`TransitionChunk` (step-major, then env);
+        ``last_steps`` keeps only the newest steps of the chunk."""
+        K = chunk.K if last_steps is None else min(int(last_steps), chunk.K)
+        log = chunk.as_struct()
+        if K < chunk.K:                       # skip the first chunk.K - K steps: advance every column pointer
+            skip = chunk.K - K
+            for c in range(chunk.obs_dim):
+                log.obs[c] = chunk.obs[c][skip:].data_ptr()
+                log.obs2[c] = chunk.obs2[c][skip:].data_ptr()
+            log.act, log.rew, log.done = chunk.act[skip:].data_ptr(), chunk.rew[skip:].data_ptr(), chunk.done[skip:].data_ptr()
+        ring = self.ring_struct()
+        with self._torch.cuda.device(self.device):
+            self._ffi.check(self.lib.ssc_replay_append(self._ctypes.byref(ring), self._ctypes.byref(log), K, chunk.N,
+                                                       self.count, float(reward_scale), self._stream()))
+        self.count += K * chunk.N
+
+    def sample_indices(self, n_batches, batch_size):
+        """int32 [n_batches, batch_size] row indices, distinct inside a batch."""
+        if len(self) < batch_size:
+            raise ValueError("fewer records than one batch (the reference trains only once len >= batch_size)")
+        idx = self._torch.empty((n_batches, batch_size), dtype=self._torch.int32, device=self.device)
+        with self._torch.cuda.device(self.device):
+            self._ffi.check(self.lib.ssc_replay_sample(self.seed, self._batches_drawn, len(self), n_batches, batch_size,
+                                                       self._ffi.ptr(idx), self._stream()))
+        self._batches_drawn += n_batches
+        return idx
+
+    def sample_batch(self, batch_size):
+        """(s, a, r, t, s2) device tensors of one batch -- the ReplayBuffer.sample_batch tuple."""
+        i = self.sample_indices(1, batch_size)[0].long()
+        return self.s[i], self.a[i], self.r[i], self.t[i].bool(), self.s2[i]

@@ -205,3 +205,35 @@ def rl_train_vec(env, policy, num_chunks, chunk_steps=1024, ring_capacity=1 << 2
             summary.append_record(length, ret)
     summary.dropped_episode_records = dropped
     return summary
+
+
+def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1 << 20, train_iters=None,
+                      replay_last_steps=None, seed=0, ring_capacity=1 << 20):
+    """Actor-learner loop entirely in HBM: every chunk is a fused rollout of ``chunk_steps`` steps of all
+    ``env.n`` envs under the agent's current actor (+ OU noise), appended to a device replay ring, followed
+    by ``train_iters`` DDPG iterations (default ``agent.num_train_iterations``) on batches drawn from it.
+    The vectorised counterpart of rlTrain + DDPG_Baselines_agent.observe/train
+    (rlTrain.py:75-100, DDPG_Baselines_agent.py:238-273).  Returns (Summary, losses per chunk, replay)."""
+    from .replay_buffer import DeviceReplayBuffer
+    from .vec_env import EpisodeRing, TransitionChunk
+    summary = Summary("vec_ddpg_" + env.spec.id)
+    ring = EpisodeRing(ring_capacity, env.device)
+    chunk = TransitionChunk(env.obs_dim, chunk_steps, env.n, env.device)
+    replay = DeviceReplayBuffer(replay_capacity, env.obs_dim, 1, env.device, seed=seed)
+    losses = []
+    generations = 0.0   # finished episodes / env.n: epsilon decays once per episode PER ENV (DDPG_Baselines_agent.py:255-258)
+    for _ in range(num_chunks):
+        pd = env.policy_desc(agent.as_policy())          # weights are views into the flat parameter arrays
+        out = env.rollout(chunk_steps, out=chunk, ring=ring, policy_desc=pd)
+        replay.append_chunk(out, reward_scale=agent.reward_scale, last_steps=replay_last_steps)
+        l = agent.train_from(replay, train_iters)
+        if l is not None:
+            losses.append(l)
+        (ids, lens, rets), _d = ring.drain()
+        for length, ret in zip(lens.tolist(), rets.tolist()):
+            summary.append_record(length, ret)
+        generations += len(lens) / float(env.n)
+        while generations >= 1.0:
+            agent.decaying_ou_action_noise.reduce_epsilon()
+            generations -= 1.0
+    return summary, losses, replay

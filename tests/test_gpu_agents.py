@@ -271,3 +271,56 @@ def test_ddpg_training_reduces_critic_loss(ssc):
     losses = agent.train_on(dev(s, torch.float32), dev(a, torch.float32), dev(r, torch.float32), dev(t, torch.uint8),
                             dev(s, torch.float32), idx, 600).cpu().numpy()
     assert losses[-50:, 0].mean() < 0.2 * losses[:20, 0].mean()
+
+
+def test_device_replay_ring_matches_oracle(ssc):
+    """ssc_replay_append / ssc_replay_sample against the restatement: ring contents bit-exact (wrap-around,
+    chunk larger than the ring, last_steps), indices bit-exact."""
+    from smartstartcontinuous_amd.replay_buffer import DeviceReplayBuffer
+    for (N, K, cap, last) in [(50, 7, 1000, None), (64, 33, 500, None), (300, 5, 256, None), (40, 20, 333, 6)]:
+        env = ssc.VecEnv("MountainCarContinuous-v0", N, seed=11)
+        env.reset()
+        replay = DeviceReplayBuffer(cap, 2, 1, seed=5)
+        ring = dict(s=np.zeros((cap, 2), np.float32), a=np.zeros((cap, 1), np.float32), r=np.zeros(cap, np.float32),
+                    t=np.zeros(cap, np.uint8), s2=np.zeros((cap, 2), np.float32))
+        count = 0
+        for c in range(3):
+            chunk = env.rollout(K, ssc.RandomPolicy())
+            replay.append_chunk(chunk, reward_scale=0.25, last_steps=last)
+            s, a, r, t, s2 = (x.cpu().numpy() for x in chunk.records())
+            first = 0 if last is None else (K - last) * N
+            count = O.replay_append(ring, count, s[first:], a[first:], r[first:], t[first:].astype(np.uint8), s2[first:],
+                                    reward_scale=0.25)
+            assert replay.count == count and len(replay) == min(count, cap)
+            live = np.arange(min(count, cap)) if count <= cap else np.arange(cap)
+            for key in ("s", "a", "r", "t", "s2"):
+                assert np.array_equal(getattr(replay, key).cpu().numpy()[live], ring[key][live]), (N, K, cap, c, key)
+        idx = replay.sample_indices(9, 64).cpu().numpy()
+        assert np.array_equal(idx, O.replay_sample_indices(5, 0, len(replay), 9, 64))
+        idx2 = replay.sample_indices(2, 17).cpu().numpy()                  # the batch counter runs on
+        assert np.array_equal(idx2, O.replay_sample_indices(5, 9, len(replay), 2, 17))
+    tiny = DeviceReplayBuffer(64, 2, 1, seed=1)
+    with pytest.raises(ValueError):
+        tiny.sample_indices(1, 64)
+
+
+def test_rl_train_vec_ddpg_loop_in_hbm(ssc):
+    """rollout (actor + OU) -> device replay -> DDPG iterations, repeated: the learner's parameters move,
+    the replay holds what the rollouts produced, the losses are finite, episodes are recorded."""
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    N, K = 256, 40
+    env = ssc.VecEnv("MountainCarContinuous-v0", N, seed=2, max_episode_steps=50)
+    env.reset()
+    agent = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, batch_size=64, num_train_iterations=5,
+                                 actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32, lastLayerTanh=True, seed=3,
+                                 reward_scale=0.5)
+    before = agent.actor_flat.clone()
+    summary, losses, replay = ssc.rl_train_vec_ddpg(env, agent, num_chunks=3, chunk_steps=K, replay_capacity=20000, seed=9)
+    assert replay.count == 3 * K * N and len(replay) == 20000
+    assert len(losses) == 3 and all(l.shape == (5, 2) and torch.isfinite(l).all() for l in losses)
+    assert not torch.equal(agent.actor_flat, before)
+    assert len(summary.episodes) == 2 * N and all(e[0] == 50 for e in summary.episodes)   # 120 steps, TimeLimit 50
+    assert abs(agent.decaying_ou_action_noise.epsilon - 0.99 ** 2) < 1e-12               # one decay per env-generation
+    # the newest records in the ring are the last rollout's: rewards scaled, dynamics consistent
+    r = replay.r.cpu().numpy(); a = replay.a.cpu().numpy()[:, 0]; t = replay.t.cpu().numpy()
+    assert np.allclose(r[t == 0], 0.5 * (-0.1 * a[t == 0] ** 2), atol=1e-6)

@@ -171,3 +171,39 @@ def test_summary_reads_and_writes_the_reference_json_schema(golden_dir, tmp_path
     assert set(json.load(open(f0)).keys()) == set(raw.keys())
     assert [tuple(e) for e in back.episodes] == s.episodes and back.best_reward == s.best_reward == (3 + 6) * 5.0
     assert len(back.last_paths) == 5 and len(back.best_path) == 3 + 6 + 1 and back.smart_start_episodes == [7]
+
+
+def test_oracle_replay_ring_and_sampler():
+    """The restated FIFO ring equals the reference-pinned host ReplayBuffer's content order, and the sampler
+    returns distinct in-range indices (random.sample semantics, replay_buffer.py:79-83)."""
+    from oracle import ssc_oracle as O
+    rng = np.random.default_rng(0)
+    cap, n = 37, 100
+    ring = dict(s=np.zeros((cap, 2), np.float32), a=np.zeros((cap, 1), np.float32), r=np.zeros(cap, np.float32),
+                t=np.zeros(cap, np.uint8), s2=np.zeros((cap, 2), np.float32))
+    s, s2 = rng.normal(size=(n, 2)).astype(np.float32), rng.normal(size=(n, 2)).astype(np.float32)
+    a, r = rng.normal(size=(n, 1)).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    t = (rng.random(n) < 0.1).astype(np.uint8)
+    count = O.replay_append(ring, 0, s[:60], a[:60], r[:60], t[:60], s2[:60], reward_scale=0.5)
+    count = O.replay_append(ring, count, s[60:], a[60:], r[60:], t[60:], s2[60:], reward_scale=0.5)
+    assert count == n
+    # the ring holds exactly the newest `cap` records, record j at row j % cap
+    for j in range(n - cap, n):
+        assert np.array_equal(ring["s"][j % cap], s[j]) and ring["r"][j % cap] == np.float32(r[j]) * np.float32(0.5)
+        assert ring["t"][j % cap] == t[j] and np.array_equal(ring["s2"][j % cap], s2[j])
+    # the host ReplayBuffer (pinned by the reference's own tests) keeps the same records, oldest first
+    from smartstartcontinuous_amd.replay_buffer import ReplayBuffer
+    rb = ReplayBuffer(None, cap)
+    for j in range(n):
+        rb.add(None, s[j], a[j], float(np.float32(r[j]) * np.float32(0.5)), bool(t[j]), s2[j])
+    hs, ha, hr, ht, hs2 = rb.all_batch()
+    order = [(j % cap) for j in range(n - cap, n)]
+    assert np.allclose(hs, ring["s"][order]) and np.allclose(hr, ring["r"][order]) and np.allclose(hs2, ring["s2"][order])
+    # sampler: distinct, in range, reproducible, and the degenerate size == batch case is a permutation
+    idx = O.replay_sample_indices(7, 3, 1000, 5, 64)
+    assert idx.shape == (5, 64) and idx.min() >= 0 and idx.max() < 1000
+    assert all(len(set(row.tolist())) == 64 for row in idx)
+    assert np.array_equal(idx, O.replay_sample_indices(7, 3, 1000, 5, 64))
+    assert not np.array_equal(idx[0], idx[1])
+    full = O.replay_sample_indices(1, 0, 64, 2, 64)
+    assert all(sorted(row.tolist()) == list(range(64)) for row in full)
