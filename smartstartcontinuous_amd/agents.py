@@ -347,6 +347,21 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
 
 
 # ---------------------------------------------------------------------------- navigator --
+def add_noise(data_inp, noiseToSignal, rng=None):
+    """NN_Dynamics_Model/helper_funcs.py:10-17: per column, Gaussian noise of std ``mean(column) * noiseToSignal``
+    -- applied only where that product is > 0, so columns with a negative or zero mean get none (the
+    reference's behaviour, kept)."""
+    rng = rng if rng is not None else np.random
+    data = np.array(data_inp, dtype=np.float64, copy=True)
+    if data.size == 0:
+        return data
+    std_of_noise = np.mean(data, axis=0) * noiseToSignal
+    for j in range(std_of_noise.shape[0]):
+        if std_of_noise[j] > 0:
+            data[:, j] = data[:, j] + rng.normal(0, np.absolute(std_of_noise[j]), (data.shape[0],))
+    return data
+
+
 def init_dynamics_weights(in_dim, out_dim, num_fc_layers, depth_fc_layers, generator=None):
     """xavier-NORMAL weights and biases (feedforward_network.py:8, 14-23)."""
     dims = [in_dim] + [depth_fc_layers] * num_fc_layers + [out_dim]
@@ -373,6 +388,7 @@ class NND_MB_agent(NavigationRLAgent):
                  steps_before_giving_up_on_waypoint=5,
                  num_fc_layers=1, depth_fc_layers=500,
                  training_data=None, weights=None, biases=None, norm=None,
+                 make_aggregated_dataset_noisy=True, nEpochs=30, fraction_use_new=0.9,
                  device="cuda", precision="bf16_mfma", seed=1234, per_row_projection=False, **unused):
         self.env = env
         self.device = torch.device(device)
@@ -384,6 +400,8 @@ class NND_MB_agent(NavigationRLAgent):
         self.horizon, self.N = horizon, num_control_samples
         self.path_shortcutting = path_shortcutting
         self.steps_before_giving_up_on_waypoint = steps_before_giving_up_on_waypoint
+        self.make_aggregated_dataset_noisy = make_aggregated_dataset_noisy   # NND_MB_agent.py:66
+        self.nEpochs, self.fraction_use_new = nEpochs, fraction_use_new      # :64, :68
         self.theta = 1                      # NND_MB_agent.py:143
         self.noise_amount = 0.005           # :188-191
         self.per_row_projection = per_row_projection
@@ -506,15 +524,43 @@ class NND_MB_agent(NavigationRLAgent):
     def get_param_dict(self):
         return self.param_dict
 
-    def train_dynamics_model(self, dataX_new=None, dataZ_new=None, nEpoch=30, fraction_use_new=0.9, batchsize=512,
-                             lr=0.001):
-        """NND_MB_agent.train_dynamics_model (:437-480) without the noise injection / TF saver: trains the
-        model on the stored (normalised) initial data set mixed with the aggregated ``*_new`` rows through
-        ``Dyn_Model.train``'s batching (DynamicsModel.train -> ssc_mlp_train_step)."""
+    def aggregated_dataset(self, rng=None):
+        """NND_MB_agent.train_dynamics_model :442-460: the replay buffer's (s, a, s2 - s) rows, optionally with
+        ``add_noise`` on states and deltas (:451-453), z-scored with the statistics of the initial data set."""
+        if len(self.replay_buffer) == 0:
+            s = np.zeros((0, self.state_dim)); a = np.zeros((0, self.act_dim)); s2 = np.zeros((0, self.state_dim))
+        else:
+            s, a, _, _, s2 = self.replay_buffer.all_batch()
+            s, a, s2 = (np.asarray(v, np.float64).reshape(len(s), -1) for v in (s, a, s2))
+        new_x, new_z = s, s2 - s
+        if self.make_aggregated_dataset_noisy:
+            new_x = add_noise(new_x, self.noiseToSignal, rng)
+            new_z = add_noise(new_z, self.noiseToSignal, rng)
+        nm = self.dyn_model.norm
+        col = lambda name, n: np.asarray([getattr(nm, name)[i] for i in range(n)], np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            nz = lambda v, m, sd: np.nan_to_num((v - m) / sd)
+            x = nz(new_x, col("mean_x", self.state_dim), col("std_x", self.state_dim))
+            y = nz(a, col("mean_y", self.act_dim), col("std_y", self.act_dim))
+            z = nz(new_z, col("mean_z", self.state_dim), col("std_z", self.state_dim))
+        return np.concatenate([x, y], axis=1), z
+
+    def train_dynamics_model(self, dataX_new=None, dataZ_new=None, nEpoch=None, fraction_use_new=None, batchsize=512,
+                             lr=0.001, rng=None):
+        """NND_MB_agent.train_dynamics_model (:437-480; no TF saver): trains the model on the stored
+        (normalised) initial data set mixed with the aggregated rows through ``Dyn_Model.train``'s batching
+        (DynamicsModel.train -> ssc_mlp_train_step).  Without arguments the aggregated rows come from the
+        replay buffer exactly as in the reference (``aggregated_dataset``); ``dataX_new`` / ``dataZ_new`` pass
+        already normalised (x||y, z) rows instead."""
         if self._train_inputs is None:
             raise RuntimeError("NND_MB_agent was built without training_data")
-        in_dim, out_dim = self.dyn_model.in_dim, self.dyn_model.out_dim
-        xn = np.zeros((0, in_dim)) if dataX_new is None else np.asarray(dataX_new)
-        zn = np.zeros((0, out_dim)) if dataZ_new is None else np.asarray(dataZ_new)
+        if dataX_new is None and dataZ_new is None:
+            xn, zn = self.aggregated_dataset(rng)
+        else:
+            in_dim, out_dim = self.dyn_model.in_dim, self.dyn_model.out_dim
+            xn = np.zeros((0, in_dim)) if dataX_new is None else np.asarray(dataX_new)
+            zn = np.zeros((0, out_dim)) if dataZ_new is None else np.asarray(dataZ_new)
+        nEpoch = self.nEpochs if nEpoch is None else nEpoch
+        fraction_use_new = self.fraction_use_new if fraction_use_new is None else fraction_use_new
         return self.dyn_model.train(self._train_inputs, self._train_outputs, xn, zn, nEpoch, fraction_use_new,
-                                    batchsize=batchsize, lr=lr)
+                                    batchsize=batchsize, lr=lr, rng=rng)

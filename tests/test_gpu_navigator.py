@@ -299,6 +299,20 @@ def test_dynamics_model_training_learns_mountaincar(nav, golden_dir):
     last_loss = agent.train_dynamics_model(nEpoch=12, fraction_use_new=0.0, batchsize=512, lr=0.001)
     after = one_step_err()
     assert last_loss < 0.05 and (after < 0.35).all() and (after < 0.3 * before).all(), (before, after, last_loss)
+    # aggregation round as in the reference (train_dynamics_model :437-480): the replay buffer's transitions,
+    # add_noise on states and deltas, z-scored with the initial statistics, mixed 50/50 into every batch
+    for ep in range(3):
+        agent.replay_buffer.start_new_episode(agent)
+        for t in range(S.shape[1] - 1):
+            agent.replay_buffer.add(agent, S[ep, t], A[ep, t], 0.0, False, S[ep, t + 1])
+    xn, zn = agent.aggregated_dataset(np.random.RandomState(1))
+    assert xn.shape == (3 * (S.shape[1] - 1), 3) and zn.shape == (xn.shape[0], 2)
+    clean = (S[:3, :-1].reshape(-1, 2) - np.asarray([agent.dyn_model.norm.mean_x[i] for i in range(2)])) / \
+        np.asarray([agent.dyn_model.norm.std_x[i] for i in range(2)])
+    # helper_funcs.add_noise only touches columns with a positive mean: position (mean < 0) stays exact
+    assert np.allclose(xn[:, 0], clean[:, 0], atol=1e-6)
+    loss2 = agent.train_dynamics_model(nEpoch=3, fraction_use_new=0.5, rng=np.random.RandomState(2))
+    assert np.isfinite(loss2) and (one_step_err() < 0.35).all()
 
 
 def test_vecenv_rollout_with_mpc_policy(nav, golden_dir):

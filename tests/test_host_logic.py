@@ -207,3 +207,16 @@ def test_oracle_replay_ring_and_sampler():
     assert not np.array_equal(idx[0], idx[1])
     full = O.replay_sample_indices(1, 0, 64, 2, 64)
     assert all(sorted(row.tolist()) == list(range(64)) for row in full)
+
+
+def test_add_noise_matches_reference_rule():
+    """helper_funcs.add_noise (NN_Dynamics_Model/helper_funcs.py:10-17): noise std = column mean * ratio, and ONLY
+    for columns whose mean is positive."""
+    from smartstartcontinuous_amd.agents import add_noise
+    rng = np.random.RandomState(0)
+    data = np.stack([np.full(20000, 2.0), np.full(20000, -3.0), np.zeros(20000), np.linspace(0.0, 1.0, 20000)], axis=1)
+    out = add_noise(data, 0.01, rng)
+    assert out is not data and np.array_equal(out[:, 1], data[:, 1]) and np.array_equal(out[:, 2], data[:, 2])
+    assert abs((out[:, 0] - data[:, 0]).std() - 0.02) < 1e-3 and abs((out[:, 0] - data[:, 0]).mean()) < 1e-3
+    assert abs((out[:, 3] - data[:, 3]).std() - 0.005) < 3e-4
+    assert add_noise(np.zeros((0, 3)), 0.01).shape == (0, 3)
