@@ -40,6 +40,7 @@ class DynamicsModel:
         self._ws = None
         self._image = None          # packed bf16 weight image of the MFMA path (ssc_dyn_prepare)
         self._image_stale = True
+        self._mfma_ok = None        # does the MFMA kernel cover this network (decided on first use)
         self.set_weights(weights, biases)
         self.set_norm(norm)
 
@@ -60,6 +61,8 @@ class DynamicsModel:
             d.W[l], d.b[l] = w.data_ptr(), b.data_ptr()
         self.desc = d
         self.in_dim, self.out_dim = d.dims[0], d.dims[d.n_layers]
+        self._mfma_ok = None
+        self._image = None
         self.invalidate()
 
     def invalidate(self):
@@ -162,9 +165,27 @@ class DynamicsModel:
             self._image_stale = False
         return self._image
 
+    def _resolve(self, precision):
+        """SSC_PREC_* for a call.  A network the MFMA kernel does not cover (more than 2 hidden layers, depth >
+        512, ...) runs on the fp32 GPU kernels instead when the model's DEFAULT precision asked for MFMA; an
+        explicit ``precision="bf16_mfma"`` argument still raises SSC_EUNSUPPORTED."""
+        prec = _PREC[precision or self.precision]
+        if prec == _ffi.SSC_PREC_BF16_MFMA and precision is None:
+            if self._mfma_ok is None:
+                try:
+                    self._mfma_image()
+                    self._mfma_ok = True
+                except _ffi.SscError as e:
+                    if e.code != _ffi.SSC_EUNSUPPORTED:
+                        raise
+                    self._mfma_ok = False
+            if not self._mfma_ok:
+                return _ffi.SSC_PREC_F32
+        return prec
+
     def forward(self, x, precision=None):
         """z = feedforward_network(x): x [m, in] -> [m, out]."""
-        prec = _PREC[precision or self.precision]
+        prec = self._resolve(precision)
         x = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
         m = x.shape[0]
         y = torch.empty((m, self.out_dim), dtype=torch.float32, device=self.device)
@@ -180,7 +201,7 @@ class DynamicsModel:
     def do_forward_sim(self, state0, actions, precision=None, out=None):
         """``Dyn_Model.do_forward_sim(..., many_in_parallel=True)``: state0 [d] (tiled, :215-217) or
         [m, d]; actions [m, H, act] -> states [H+1, m, d]."""
-        prec = _PREC[precision or self.precision]
+        prec = self._resolve(precision)
         A = torch.as_tensor(actions, dtype=torch.float32, device=self.device).contiguous()
         m, H = A.shape[0], A.shape[1]
         s0 = torch.as_tensor(state0, dtype=torch.float32, device=self.device).contiguous()

@@ -416,3 +416,43 @@ def test_mfma_prepared_image_matches_per_call_pack_and_tracks_weight_changes(nav
     model.train_step(X, Z, torch.arange(64, dtype=torch.int32, device="cuda"), lr=0.01)
     S4 = model.do_forward_sim(s0, A).cpu().numpy()
     assert not np.array_equal(S4, S3) and np.array_equal(S4, per_call_pack())
+
+
+def test_default_mfma_precision_falls_back_to_fp32_kernels_for_uncovered_networks(nav):
+    """A model whose DEFAULT precision is bf16_mfma but whose shape the MFMA kernel does not cover (3 hidden
+    layers) runs on the fp32 GPU kernels; asking for MFMA explicitly still raises."""
+    from smartstartcontinuous_amd import _ffi
+    rng = np.random.default_rng(2)
+    dims = (3, 40, 40, 40, 2)
+    Ws, bs = make_mlp(rng, dims)
+    model = nav.DynamicsModel(Ws, bs, make_norm(rng, 2, 1), state_dim=2, act_dim=1, precision="bf16_mfma")
+    x = rng.normal(size=(100, 3)).astype(np.float32)
+    got = model.forward(x).cpu().numpy()
+    assert np.max(np.abs(got - O.mlp_forward(x, Ws, bs))) <= 1e-4
+    with pytest.raises(_ffi.SscError):
+        model.forward(x, precision="bf16_mfma")
+    # 12 inputs with two 500-unit layers: also outside the MFMA kernel (one layer-1 k-step holds 10)
+    dims = (12, 500, 500, 8)
+    Ws, bs = make_mlp(rng, dims)
+    model = nav.DynamicsModel(Ws, bs, make_norm(rng, 8, 4), state_dim=8, act_dim=4, precision="bf16_mfma")
+    x = rng.normal(size=(50, 12)).astype(np.float32)
+    ref = O.mlp_forward(x, Ws, bs)
+    assert np.max(np.abs(model.forward(x).cpu().numpy() - ref)) <= 1e-4 * max(1.0, np.abs(ref).max())
+    # 10 inputs: covered (KIN = 10 instantiation)
+    dims = (10, 500, 500, 7)
+    Ws, bs = make_mlp(rng, dims)
+    model = nav.DynamicsModel(Ws, bs, make_norm(rng, 7, 3), state_dim=7, act_dim=3, precision="bf16_mfma")
+    x = rng.normal(size=(300, 10)).astype(np.float32)
+    ref = O.mlp_forward(x, Ws, bs)
+    got = model.forward(x).cpu().numpy()
+    assert model._mfma_ok and np.max(np.abs(got - ref)) <= 3e-2 * max(1.0, np.abs(ref).max())
+    emu = O.mlp_forward_bf16emu(x, Ws, bs)
+    assert np.max(np.abs(got - emu)) <= 2e-3 * max(1.0, np.abs(ref).max())
+    # ... and as a forward simulation with 7 state + 3 action dims
+    A = rng.uniform(-1, 1, size=(200, 3, 3)).astype(np.float32)
+    s0 = rng.normal(size=(200, 7)).astype(np.float32) * 0.3
+    nm = make_norm(rng, 7, 3)
+    model = nav.DynamicsModel(Ws, bs, nm, state_dim=7, act_dim=3, precision="bf16_mfma")
+    S = model.do_forward_sim(s0, A).cpu().numpy()
+    ref = O.dyn_forward_sim(s0, A, norm32(nm), Ws, bs)
+    assert np.max(np.abs(S - ref)) <= 3e-2 * max(1.0, np.abs(ref).max())
