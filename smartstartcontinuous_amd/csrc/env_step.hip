@@ -99,13 +99,15 @@ __global__ __launch_bounds__(kBlock) void env_observe_kernel(int kind, int64_t n
     }
 }
 
-// One launch instead of 2*obs_dim+3 strided copies: thread e of column c copies element e of the tail.
+// One launch instead of 2*obs_dim+3 strided copies: thread e of column c copies VEC consecutive elements of the
+// tail (VEC = 4: 16-byte accesses, n % 4 == 0 keeps a vector inside one step's row; the u8 column moves 4 bytes).
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void pack_tail_kernel(ssc_transition_log log, int obs_dim, int K, int g,
                                                            int64_t n, const double *__restrict__ stats,
                                                            unsigned char *__restrict__ out) {
     const int64_t per = (int64_t)g * n;
     const int ncol = 2 * obs_dim + 2;             // fp32 columns; the u8 done column follows
-    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
     const int col = blockIdx.y;
     const int64_t step = e / n, i = e - step * n;
     const int64_t rs = log.row_stride ? log.row_stride : n, drs = log.done_row_stride ? log.done_row_stride : n;
@@ -115,14 +117,19 @@ __global__ __launch_bounds__(kBlock) void pack_tail_kernel(ssc_transition_log lo
             const float *p = col < obs_dim ? log.obs[col]
                              : col == obs_dim ? log.act
                              : col == obs_dim + 1 ? log.rew : log.obs2[col - obs_dim - 2];
-            reinterpret_cast<float *>(out)[(int64_t)col * per + e] = p[src];
+            float *dst = reinterpret_cast<float *>(out) + (int64_t)col * per + e;
+            if (VEC == 4) *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(p + src);
+            else *dst = p[src];
         } else {
-            out[(int64_t)ncol * per * 4 + e] = log.done[(int64_t)(K - g + step) * drs + i];
+            const uint8_t *ps = log.done + (int64_t)(K - g + step) * drs + i;
+            unsigned char *dst = out + (int64_t)ncol * per * 4 + e;
+            if (VEC == 4) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(ps);
+            else *dst = *ps;
         }
     }
-    if (stats != nullptr && col == 0 && e < 4) {
+    if (stats != nullptr && col == 0 && blockIdx.x == 0 && threadIdx.x < 4) {
         const int64_t off = (((int64_t)ncol * per * 4 + per) + 7) & ~(int64_t)7;
-        reinterpret_cast<double *>(out + off)[e] = stats[e];
+        reinterpret_cast<double *>(out + off)[threadIdx.x] = stats[threadIdx.x];
     }
 }
 
@@ -194,9 +201,22 @@ int ssc_pack_transitions(const ssc_transition_log *log, int32_t obs_dim, int32_t
     if (g == 0 || n == 0) return SSC_OK;
     for (int c = 0; c < obs_dim; ++c) SSC_REQUIRE(log->obs[c] && log->obs2[c], "ssc_pack_transitions: NULL column");
     SSC_REQUIRE(log->act && log->rew && log->done, "ssc_pack_transitions: NULL column");
-    const dim3 grid(blocks_for((int64_t)g * n), 2 * obs_dim + 3);
-    hipLaunchKernelGGL(pack_tail_kernel, grid, dim3(kBlock), 0, as_stream(stream), *log, obs_dim, K, g, n, d_stats,
-                       static_cast<unsigned char *>(d_out));
+    // 16-byte path: rows and every column base 16-byte aligned (the u8 column: 4-byte)
+    const int64_t rs = log->row_stride ? log->row_stride : n, drs = log->done_row_stride ? log->done_row_stride : n;
+    bool vec = (n % 4 == 0) && (rs % 4 == 0) && (drs % 4 == 0) && (reinterpret_cast<uintptr_t>(d_out) % 16 == 0) &&
+               (reinterpret_cast<uintptr_t>(log->act) % 16 == 0) && (reinterpret_cast<uintptr_t>(log->rew) % 16 == 0) &&
+               (reinterpret_cast<uintptr_t>(log->done) % 4 == 0);
+    for (int c = 0; c < obs_dim; ++c)
+        vec = vec && (reinterpret_cast<uintptr_t>(log->obs[c]) % 16 == 0) && (reinterpret_cast<uintptr_t>(log->obs2[c]) % 16 == 0);
+    if (vec) {
+        const dim3 grid(blocks_for((int64_t)g * n / 4), 2 * obs_dim + 3);
+        hipLaunchKernelGGL(pack_tail_kernel<4>, grid, dim3(kBlock), 0, as_stream(stream), *log, obs_dim, K, g, n, d_stats,
+                           static_cast<unsigned char *>(d_out));
+    } else {
+        const dim3 grid(blocks_for((int64_t)g * n), 2 * obs_dim + 3);
+        hipLaunchKernelGGL(pack_tail_kernel<1>, grid, dim3(kBlock), 0, as_stream(stream), *log, obs_dim, K, g, n, d_stats,
+                           static_cast<unsigned char *>(d_out));
+    }
     return check_launch("ssc_pack_transitions");
 }
 

@@ -56,7 +56,8 @@ class TransitionGather:
         self.recv = None
         if rank == dst:
             self.recv = [torch.empty(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(world)]
-        self.global_stats = torch.zeros(4, dtype=torch.float64, device=self.device)
+        self._global_stats = torch.zeros(4, dtype=torch.float64, device=self.device)
+        self._stats_from_payload = False
         self.side = torch.cuda.Stream(self.device) if self.cuda else None
         self.packed = [None, None]
         self.chunks_gathered = 0
@@ -114,12 +115,23 @@ class TransitionGather:
         dist.gather(self.send[slot], self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
         if self.allreduce_stats:
             # every rank learns the global statistics (the analogue of training_editted.py:173)
-            self.global_stats.copy_(self._stats_view(self.send[slot]))
-            dist.all_reduce(self.global_stats, op=dist.ReduceOp.SUM, group=self.group)
-        elif self.rank == self.dst:
-            # the statistics ride in the gathered payload: the learner sums them, no second collective
-            self.global_stats.copy_(torch.stack([self._stats_view(r) for r in self.recv]).sum(dim=0))
+            self._global_stats.copy_(self._stats_view(self.send[slot]))
+            dist.all_reduce(self._global_stats, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            # the (cumulative) statistics ride in the gathered payload: the learner sums the newest snapshots
+            # when somebody asks (global_stats) -- no second collective and no per-chunk reduction kernels
+            self._stats_from_payload = True
         self.chunks_gathered += 1
+
+    @property
+    def global_stats(self):
+        """[sum of rewards, #done, #env-steps, #episodes] over all ranks as of the last gathered chunk
+        (float64 [4]; on the learner rank, or on every rank with ``allreduce_stats``)."""
+        if self._stats_from_payload and self.rank == self.dst:
+            self.finish()
+            self._global_stats.copy_(torch.stack([self._stats_view(r) for r in self.recv]).sum(dim=0))
+            self._stats_from_payload = False
+        return self._global_stats
 
     def submit(self, chunk, slot, stats):
         """Call right after the rollout that filled ``chunk`` was enqueued (same stream).

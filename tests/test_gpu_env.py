@@ -276,9 +276,12 @@ def test_pack_transitions_kernel_matches_layout(ssc):
     """ssc_pack_transitions == the column-by-column pack of sharding.TransitionGather (the layout the
     world-2 gloo test exercises on the CPU)."""
     from smartstartcontinuous_amd.sharding import TransitionGather
-    for env_name, n, K, g in [("MountainCarContinuous-v0", 1000, 24, 5), ("Pendulum-v0", 257, 8, 8)]:
+    # n % 4 == 0 takes the 16-byte path, 257 / 1002 the scalar one; dense and packed chunk layouts
+    for env_name, n, K, g, packed in [("MountainCarContinuous-v0", 1000, 24, 5, True), ("Pendulum-v0", 257, 8, 8, True),
+                                      ("MountainCarContinuous-v0", 1002, 9, 3, True), ("Pendulum-v0", 4096, 6, 2, False),
+                                      ("MountainCarContinuous-v0", 65536, 4, 4, True)]:
         env = ssc.VecEnv(env_name, n, seed=3)
-        chunk = env.rollout(K, ssc.RandomPolicy())
+        chunk = env.rollout(K, ssc.RandomPolicy(), out=ssc.TransitionChunk(env.obs_dim, K, n, "cuda", packed=packed))
         tg = TransitionGather(env.obs_dim, g, n, 1, 0, "cuda")
         tg.pack(chunk, 0, env.stats)
         torch.cuda.synchronize()

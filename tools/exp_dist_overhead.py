@@ -29,7 +29,7 @@ def run(mode, steps=40):
         elif mode == "allreduce_only":
             ev = torch.cuda.Event(); ev.record()
             with torch.cuda.stream(tg.side):
-                tg.side.wait_event(ev); dist.all_reduce(tg.global_stats)
+                tg.side.wait_event(ev); dist.all_reduce(tg._global_stats)
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize(); t_all = time.perf_counter() - t0
     print(f"{mode:15s} host enqueue {t_host/steps*1e3:.3f} ms/step   total {t_all/steps*1e3:.3f} ms/step", flush=True)
