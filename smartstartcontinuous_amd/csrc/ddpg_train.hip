@@ -3,11 +3,19 @@
 // 64-32 actor / critic of the shipped runs.
 //
 // The iterations form a serial chain through the parameters (the reference runs one per env step),
-// so ONE workgroup executes `n_iters` of them per launch: 4 waves, lane = sample, every activation and
-// every back-propagated delta of the batch lives in LDS as [unit][68]; in the dense passes a lane owns a
-// unit (its weights arrive as one coalesced load per input row), a wave owns 16 samples whose
-// activations are broadcast float4 LDS reads.  fp32, plain
-// FMA chains in k order; the Adam moments, step counters and target networks are updated in place.
+// so ONE workgroup executes `n_iters` of them per launch.  Design:
+//   * everything lives in LDS for the whole launch: the four parameter vectors (actor, critic, their
+//     targets; written back once at the end) and every activation / delta of the batch as [unit][68]
+//     rows; only the Adam moments stay in global memory (one coalesced pass per iteration);
+//   * an iteration is a LIST OF STEPS (built on the host, ~40 entries: dense forward, dense backward,
+//     activation derivative, weight gradient + Adam, and a few special ones) run by one interpreter loop,
+//     so each dense routine exists ONCE in the binary.  The first versions inlined the dense code at
+//     every call site: 15 k -- later 90 k -- instructions, several times the 64 KB instruction cache, and the
+//     kernel was bound by instruction fetch (70 us per iteration whatever the data path looked like);
+//   * dense passes use LANE = SAMPLE (64 lanes busy whatever the layer width); the output units
+//     (forward) or input rows (backward) are dealt to the 4 waves in groups of 4, and a weight is one
+//     broadcast LDS read -- a float4 of 4 consecutive units where the row length allows.
+// fp32, plain FMA chains in k order; MpiAdam's bias-corrected step size is computed in f64.
 #include "ssc_device.h"
 #include "ssc_host.h"
 
@@ -17,87 +25,183 @@ constexpr int kB = 64;       // batch size = lanes of a wave
 constexpr int kP = kB + 4;   // padded LDS row: 16-B aligned rows (float4 access over 4 samples); a stride of
                              // 68 dwords keeps both ds_read_b128 column gathers and ds_write_b128 conflict-free
 constexpr int kTrainThreads = 256;
-
-struct NetDims {
-    int in, h1, h2, out;     // actor: obs -> h1 -> h2 -> act ; critic: obs -> h1 (+act) -> h2 -> 1
-    int extra;               // rows concatenated to the first hidden layer (critic: act_dim, actor: 0)
-    __device__ int oW1() const { return 0; }
-    __device__ int ob1() const { return in * h1; }
-    __device__ int oW2() const { return ob1() + h1; }
-    __device__ int ob2() const { return oW2() + (h1 + extra) * h2; }
-    __device__ int oW3() const { return ob2() + h2; }
-    __device__ int ob3() const { return oW3() + h2 * out; }
-    __device__ int total() const { return ob3() + out; }
-};
+constexpr int kMaxSteps = 44;
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+enum {
+    ST_GATHER = 0,   // batch rows -> S, S2, action rows of X2, r, terminal
+    ST_FWD,          // Z = act(b + W^T X)                       w, b, in, out, x, z, act, xtail, tail_from
+    ST_YTARGET,      // y = r + (1 - t) gamma q'                 x = q' row
+    ST_CLOSS,        // e = q - y; closs; dq = 2 e / B           x = q row, z = dq row
+    ST_FILL,         // rows z = constant c                      z, out rows, c
+    ST_BWD,          // dX[i - i0] = act'(A[i - i0]) sum_j W[i][j] dZ[j]    w, out, i0, i1, x = dZ, z = dX, act, xtail = A
+    ST_DERIV,        // D[j] *= act'(A[j])                       x = A, z = D, out rows, act
+    ST_ALOSS,        // aloss = -q(s, pi(s))                     x = q row
+    ST_LOSSES,       // block reduction of the two losses, Adam step sizes
+    ST_WGRAD,        // dW = X dZ^T, db; Adam into theta         w, b, in, out, x = X, z = dZ, net, xtail, tail_from
+    ST_TUPDATE,      // theta' <- (1 - tau) theta' + tau theta, losses out
+};
+
+// One step.  x, z, xtail (and w, b of the dense steps) are offsets in floats from the start of the dynamic LDS
+// array; for ST_WGRAD w, b index the flat parameter / moment arrays of the net.
+struct Step {
+    int16_t kind, barrier;          // barrier: __syncthreads() after the step
+    int16_t in, out, act, net;      // net: 0 actor / 1 critic (ST_WGRAD)
+    int16_t i0, i1, tail_from, pad;
+    int32_t w, b, x, z, xtail;
+    float c;
+};
+
+struct TrainArgs {   // passed by value: must stay below the 4 KB kernel-argument limit
+    ssc_ddpg_desc d;
+    ssc_replay_view rp;
+    const int32_t *batch_idx;
+    float *losses;
+    int32_t n_iters, n_steps;
+    int32_t off_theta[4];   // LDS offsets of actor, critic, target actor, target critic
+    int32_t n_actor, n_critic;
+    int32_t off_S, off_S2, off_RT, off_X2act;   // gather targets: state rows, next-state rows, (r, t, y) rows, action rows
+    Step steps[kMaxSteps];
+};
+static_assert(sizeof(TrainArgs) <= 4000, "TrainArgs must fit the kernel-argument segment");
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-constexpr int kSPW = kB / (kTrainThreads / 64);   // samples per wave = 16
 
-// Z[j][b] = act(bias[j] + sum_i W[i][j] X[i][b]).  Lane = output unit j (W[i][j] is one coalesced load
-// per input row i), wave w = samples [16w, 16w+16) (X rows are broadcast float4 reads).
-__device__ __forceinline__ void dense_fwd(const float *__restrict__ W, const float *__restrict__ bias, int in, int out,
-                                          const float *X, float *Z, int act) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, b0 = wave * kSPW;
-    for (int j0 = 0; j0 < out; j0 += 64) {
-        const int j = j0 + lane;
-        const bool valid = j < out;
-        const int jc = valid ? j : out - 1;
-        f4 acc[kSPW / 4];
-        const float bj = bias[jc];
+template <bool AL4>
+__device__ __forceinline__ f4 weights4(const float *w, int j, int out) {
+    if (AL4) return *reinterpret_cast<const f4 *>(w + j);
+    f4 r;
 #pragma unroll
-        for (int q = 0; q < kSPW / 4; ++q) acc[q] = (f4)(bj);
+    for (int e = 0; e < 4; ++e) r[e] = (j + e < out) ? w[j + e] : 0.0f;
+    return r;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// Z[j][b] = act(bias[j] + sum_i W[i][j] X[i][b]) for the NQ unit groups {4 (wave + 4 q)} of this wave.
+// Input rows i >= tail_from come from Xtail (the critic's action rows live apart from relu(layer 1)).
+template <int NQ, bool AL4>
+__device__ __forceinline__ void dense_fwd_groups(const float *W, const float *bias, int in, int out, const float *X,
+                                                 float *Z, int act, const float *Xtail, int tail_from) {
+    const int wave = threadIdx.x >> 6, b = threadIdx.x & 63;
+    f4 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = weights4<AL4>(bias, 4 * (wave + 4 * q), out);
+    const int n_head = in < tail_from ? in : tail_from;
+#pragma unroll 8
+    for (int i = 0; i < n_head; ++i) {
+        const float x = X[i * kP + b];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] += weights4<AL4>(W + i * out, 4 * (wave + 4 * q), out) * x;
+    }
+    for (int i = n_head; i < in; ++i) {
+        const float x = Xtail[(i - tail_from) * kP + b];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] += weights4<AL4>(W + i * out, 4 * (wave + 4 * q), out) * x;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * (wave + 4 * q) + e;
+            if (AL4 || j < out) Z[j * kP + b] = apply_act(acc[q][e], act);
+        }
+}
+
+// out == 1 (the critic's Q, a 1-d action): W is a column of `in` floats; wave 0 walks it 4 inputs per float4.
+__device__ __forceinline__ void dense_fwd_out1(const float *W, const float *bias, int in, const float *X, float *Z, int act) {
+    if (threadIdx.x >= 64) return;
+    const int b = threadIdx.x;
+    float acc = bias[0];
+    int i = 0;
+    if ((reinterpret_cast<uintptr_t>(W) & 15) == 0) {
 #pragma unroll 4
-        for (int i = 0; i < in; ++i) {
-            const float w = W[i * out + jc];
-#pragma unroll
-            for (int q = 0; q < kSPW / 4; ++q) acc[q] += w * *reinterpret_cast<const f4 *>(X + i * kP + b0 + 4 * q);
+        for (; i + 4 <= in; i += 4) {
+            const f4 w = *reinterpret_cast<const f4 *>(W + i);
+            acc += (w[0] * X[i * kP + b] + w[1] * X[(i + 1) * kP + b]) + (w[2] * X[(i + 2) * kP + b] + w[3] * X[(i + 3) * kP + b]);
         }
-        if (valid) {
+    }
+    for (; i < in; ++i) acc += W[i] * X[i * kP + b];
+    Z[b] = apply_act(acc, act);
+}
+
+template <bool AL4>
+__device__ __forceinline__ void dense_fwd(const float *W, const float *bias, int in, int out, const float *X, float *Z,
+                                          int act, const float *Xtail, int tail_from) {
+    const int wave = threadIdx.x >> 6;
+    const int groups = (out + 3) >> 2;
+    const int nq = (groups - wave + 3) >> 2;   // groups wave, wave + 4, ... < groups  (out <= 64: nq <= 4)
+    if (nq >= 4) dense_fwd_groups<4, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
+    else if (nq == 3) dense_fwd_groups<3, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
+    else if (nq == 2) dense_fwd_groups<2, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
+    else if (nq == 1) dense_fwd_groups<1, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
+}
+
+// dX[i - i0][b] = sum_j W[i][j] dZ[j][b] for the NR input rows {i0 + wave + 4 (qbase + r)} of this wave.
+// act != ACT_NONE: the result is multiplied by act'(A[i - i0]) (tanh: 1 - a^2, relu: a > 0) on the way out.
+__device__ __forceinline__ float act_deriv(float a, int act) {
+    return act == ACT_TANH ? 1.0f - a * a : (act == ACT_RELU ? (a > 0.0f ? 1.0f : 0.0f) : 1.0f);
+}
+
+template <int NR, bool AL4>
+__device__ __forceinline__ void dense_bwd_rows(const float *W, int out, int i0, int qbase, const float *dZ, float *dX,
+                                               const float *A, int act) {
+    const int wave = threadIdx.x >> 6, b = threadIdx.x & 63;
+    float acc[NR];
 #pragma unroll
-            for (int q = 0; q < kSPW / 4; ++q) {
-                f4 v = acc[q];
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0f;
+#pragma unroll 2
+    for (int j = 0; j < out; j += 4) {
+        f4 dz;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (act == ACT_RELU) v[e] = fmaxf(v[e], 0.0f);
-                    else if (act == ACT_TANH) v[e] = tanhf(v[e]);
-                }
-                *reinterpret_cast<f4 *>(Z + j * kP + b0 + 4 * q) = v;
-            }
+        for (int e = 0; e < 4; ++e) dz[e] = (AL4 || j + e < out) ? dZ[(j + e) * kP + b] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = i0 + wave + 4 * (qbase + r);
+            const f4 w = weights4<AL4>(W + i * out, j, out);
+            acc[r] += (w[0] * dz[0] + w[1] * dz[1]) + (w[2] * dz[2] + w[3] * dz[3]);
         }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int o = (wave + 4 * (qbase + r)) * kP + b;
+        dX[o] = acc[r] * act_deriv(A[o], act);
     }
 }
 
-// dX[i - i0][b] = sum_j W[i][j] dZ[j][b] for input rows i in [i0, i1).  Lane = input row.
-__device__ __forceinline__ void dense_bwd_in(const float *__restrict__ W, int out, int i0, int i1, const float *dZ,
-                                             float *dX) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, b0 = wave * kSPW;
-    for (int r0 = i0; r0 < i1; r0 += 64) {
-        const int i = r0 + lane;
-        const bool valid = i < i1;
-        const int ic = valid ? i : i1 - 1;
-        f4 acc[kSPW / 4];
-#pragma unroll
-        for (int q = 0; q < kSPW / 4; ++q) acc[q] = (f4)(0.0f);
-#pragma unroll 4
-        for (int j = 0; j < out; ++j) {
-            const float w = W[ic * out + j];
-#pragma unroll
-            for (int q = 0; q < kSPW / 4; ++q) acc[q] += w * *reinterpret_cast<const f4 *>(dZ + j * kP + b0 + 4 * q);
-        }
-        if (valid) {
-#pragma unroll
-            for (int q = 0; q < kSPW / 4; ++q) *reinterpret_cast<f4 *>(dX + (i - i0) * kP + b0 + 4 * q) = acc[q];
-        }
+template <bool AL4>
+__device__ __forceinline__ void dense_bwd_in(const float *W, int out, int i0, int i1, const float *dZ, float *dX,
+                                             const float *A, int act) {
+    const int wave = threadIdx.x >> 6;
+    const int nr = (i1 - i0 - wave + 3) >> 2;   // rows i0 + wave, i0 + wave + 4, ... of this wave
+    int q = 0;
+    for (; q + 4 <= nr; q += 4) dense_bwd_rows<4, AL4>(W, out, i0, q, dZ, dX, A, act);
+    if (nr - q == 3) dense_bwd_rows<3, AL4>(W, out, i0, q, dZ, dX, A, act);
+    else if (nr - q == 2) dense_bwd_rows<2, AL4>(W, out, i0, q, dZ, dX, A, act);
+    else if (nr - q == 1) dense_bwd_rows<1, AL4>(W, out, i0, q, dZ, dX, A, act);
+}
+
+// beta^n for an integer step count, by squaring in f64 (ocml's pow() alone is several thousand instructions)
+__device__ __forceinline__ double ipow(double base, int n) {
+    double r = 1.0;
+    while (n > 0) {
+        if (n & 1) r *= base;
+        base *= base;
+        n >>= 1;
     }
+    return r;
 }
 
 struct AdamCfg {
     float a, beta1, beta2, eps;   // a = stepsize * sqrt(1 - b2^t) / (1 - b1^t) with t already incremented
 };
 
-// MpiAdam.update (baselines common/mpi_adam.py [third-party], ddpg_editted.py:326-327) on one element
+// MpiAdam.update (baselines common/mpi_adam.py [third-party], ddpg_editted.py:326-327): theta in LDS, moments in
+// global memory, same index.
 __device__ __forceinline__ void adam_apply(float *theta, float *m, float *v, int idx, float g, const AdamCfg &c) {
     const float mi = c.beta1 * m[idx] + (1.0f - c.beta1) * g;
     const float vi = c.beta2 * v[idx] + (1.0f - c.beta2) * (g * g);
@@ -107,14 +211,18 @@ __device__ __forceinline__ void adam_apply(float *theta, float *m, float *v, int
 }
 
 // dW[i][j] = sum_b X[i][b] dZ[j][b]; db[j] = sum_b dZ[j][b]; applied straight into Adam.
+// (Fetching the moments of 4 elements ahead of their dot products was measured 2x SLOWER: the pass is bound by
+// the LDS reads of the dot products, not by the global latency of the moments.)
 __device__ __forceinline__ void weight_grad_adam(const float *X, const float *dZ, int in, int out, float *theta,
-                                                 float *m, float *v, int offW, int offb, const AdamCfg &c) {
+                                                 float *m, float *v, int offW, int offb, const AdamCfg &c,
+                                                 const float *Xtail, int tail_from) {
     for (int idx = threadIdx.x; idx < in * out; idx += kTrainThreads) {
         const int i = idx / out, j = idx - i * out;
+        const float *xr = (i >= tail_from) ? Xtail + (i - tail_from) * kP : X + i * kP;
         f4 g4 = (f4)(0.0f);
 #pragma unroll 4
         for (int q = 0; q < kB / 4; ++q)
-            g4 += *reinterpret_cast<const f4 *>(X + i * kP + 4 * q) * *reinterpret_cast<const f4 *>(dZ + j * kP + 4 * q);
+            g4 += *reinterpret_cast<const f4 *>(xr + 4 * q) * *reinterpret_cast<const f4 *>(dZ + j * kP + 4 * q);
         adam_apply(theta, m, v, offW + idx, (g4[0] + g4[1]) + (g4[2] + g4[3]), c);
     }
     for (int j = threadIdx.x; j < out; j += kTrainThreads) {
@@ -124,178 +232,183 @@ __device__ __forceinline__ void weight_grad_adam(const float *X, const float *dZ
     }
 }
 
-struct TrainArgs {
-    ssc_ddpg_desc d;
-    ssc_replay_view rp;
-    const int32_t *batch_idx;
-    int32_t n_iters;
-    float *losses;
-};
-
+// Diagnostic build (-DSSC_DDPG_DIAG, tools/exp_ddpg_phases.py): d_losses is [n_iters][kMaxSteps] and receives
+// the cycles thread 0 spent in each step instead of the losses.
 __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const ssc_ddpg_desc &d = g.d;
-    const NetDims A{d.obs_dim, d.actor_h1, d.actor_h2, d.act_dim, 0};
-    const NetDims C{d.obs_dim, d.critic_h1, d.critic_h2, 1, d.act_dim};
-    const bool llt = d.last_layer_tanh != 0;
-    const int act2 = llt ? ACT_TANH : ACT_RELU;
-    const int tid = threadIdx.x, b = tid & 63;
-
-    // ---- LDS carve (rows of kP floats) ------------------------------------------------------
-    float *p = lds;
-    auto take = [&](int rows) { float *q = p; p += rows * kP; return q; };
-    float *S = take(d.obs_dim), *S2 = take(d.obs_dim);
-    float *RT = take(3);                                  // r, terminal, y (target Q)
-    float *X2 = take(C.h1 + d.act_dim);                   // critic: relu(layer 1) rows, then the action rows
-    float *CA2 = take(C.h2), *DQ = take(1), *DZ2 = take(C.h2), *DZ1 = take(C.h1);
-    float *U1 = take(A.h1), *U2 = take(A.h2), *PI = take(d.act_dim);
-    float *DZ3A = take(d.act_dim), *DZ2A = take(A.h2), *DZ1A = take(A.h1);
-    float *X2B = take(C.h1 + d.act_dim), *CB2 = take(C.h2), *DZB2 = take(C.h2);   // also the target-pass scratch
     __shared__ float red[2][kTrainThreads / 64];
+    __shared__ AdamCfg cfg_s[2];
+    const ssc_ddpg_desc &d = g.d;
+    const int tid = threadIdx.x, b = tid & 63;
+    float *th_a = lds + g.off_theta[0], *th_c = lds + g.off_theta[1];
+    float *th_ta = lds + g.off_theta[2], *th_tc = lds + g.off_theta[3];
+    for (int e = tid; e < g.n_actor; e += kTrainThreads) { th_a[e] = d.actor[e]; th_ta[e] = d.target_actor[e]; }
+    for (int e = tid; e < g.n_critic; e += kTrainThreads) { th_c[e] = d.critic[e]; th_tc[e] = d.target_critic[e]; }
+    __syncthreads();
+    int tA = d.adam_t[0], tC = d.adam_t[1];
+    float closs = 0.0f, aloss = 0.0f;
 
     for (int it = 0; it < g.n_iters; ++it) {
-        // ---- gather the batch (ReplayBuffer.sample_batch rows) -------------------------------------
-        if (tid < kB) {
-            const int64_t rec = g.batch_idx[(int64_t)it * kB + tid];
-            for (int c = 0; c < d.obs_dim; ++c) {
-                S[c * kP + tid] = g.rp.s[rec * d.obs_dim + c];
-                S2[c * kP + tid] = g.rp.s2[rec * d.obs_dim + c];
-            }
-            for (int c = 0; c < d.act_dim; ++c) X2[(C.h1 + c) * kP + tid] = g.rp.a[rec * d.act_dim + c];
-            RT[0 * kP + tid] = g.rp.r[rec];
-            RT[1 * kP + tid] = g.rp.t[rec] ? 1.0f : 0.0f;
-        }
-        __syncthreads();
-        // ---- target_Q = r + (1 - terminal) * gamma * Q'(s2, pi'(s2))      (ddpg_editted.py:132-133) ----
-        {
-            const float *ta = d.target_actor, *tc = d.target_critic;
-            dense_fwd(ta + A.oW1(), ta + A.ob1(), A.in, A.h1, S2, DZ1A, ACT_RELU);
-            dense_fwd(tc + C.oW1(), tc + C.ob1(), C.in, C.h1, S2, X2B, ACT_RELU);
-            __syncthreads();
-            dense_fwd(ta + A.oW2(), ta + A.ob2(), A.h1, A.h2, DZ1A, DZ2A, act2);
-            __syncthreads();
-            dense_fwd(ta + A.oW3(), ta + A.ob3(), A.h2, A.out, DZ2A, X2B + C.h1 * kP, ACT_TANH);
-            __syncthreads();
-            dense_fwd(tc + C.oW2(), tc + C.ob2(), C.h1 + d.act_dim, C.h2, X2B, CB2, act2);
-            __syncthreads();
-            dense_fwd(tc + C.oW3(), tc + C.ob3(), C.h2, 1, CB2, DZB2, ACT_NONE);
-            __syncthreads();
-            if (tid < kB) RT[2 * kP + tid] = RT[tid] + (1.0f - RT[kP + tid]) * d.gamma * DZB2[tid];
-        }
-        // ---- critic on (s, a): loss = mean((Q - y)^2)                              (:181) --------------
-        dense_fwd(d.critic + C.oW1(), d.critic + C.ob1(), C.in, C.h1, S, X2, ACT_RELU);
-        // ---- actor on s (independent of the critic pass)                           (:127) --------------
-        dense_fwd(d.actor + A.oW1(), d.actor + A.ob1(), A.in, A.h1, S, U1, ACT_RELU);
-        __syncthreads();
-        dense_fwd(d.critic + C.oW2(), d.critic + C.ob2(), C.h1 + d.act_dim, C.h2, X2, CA2, act2);
-        dense_fwd(d.actor + A.oW2(), d.actor + A.ob2(), A.h1, A.h2, U1, U2, act2);
-        __syncthreads();
-        dense_fwd(d.critic + C.oW3(), d.critic + C.ob3(), C.h2, 1, CA2, DQ, ACT_NONE);
-        dense_fwd(d.actor + A.oW3(), d.actor + A.ob3(), A.h2, A.out, U2, PI, ACT_TANH);
-        __syncthreads();
-        float closs = 0.0f;
-        if (tid < kB) {
-            const float e = DQ[tid] - RT[2 * kP + tid];
-            closs = e * e;
-            DQ[tid] = 2.0f * e / (float)kB;                 // d loss / d q
-            // critic input for the actor loss: relu(layer 1) is the same, the action is pi(s)
-            for (int c = 0; c < d.act_dim; ++c) X2B[(C.h1 + c) * kP + tid] = PI[c * kP + tid];
-        }
-        for (int e = tid; e < C.h1 * kP; e += kTrainThreads) X2B[e] = X2[e];
-        __syncthreads();
-        // ---- critic backward (weights' deltas kept for the gradient pass) ---------------------------------
-        {   // dz2 = (W3 dq) * act'(z2)
-            const int wave = tid >> 6;
-            for (int j = wave; j < C.h2; j += 4) {
-                const float a2 = CA2[j * kP + b];
-                const float da2 = d.critic[C.oW3() + j] * DQ[b];
-                DZ2[j * kP + b] = da2 * (llt ? (1.0f - a2 * a2) : (a2 > 0.0f ? 1.0f : 0.0f));
-            }
-        }
-        // ---- critic forward on (s, pi(s)): actor loss = -mean(Q)                    (:168) --------------
-        dense_fwd(d.critic + C.oW2(), d.critic + C.ob2(), C.h1 + d.act_dim, C.h2, X2B, CB2, act2);
-        __syncthreads();
-        dense_bwd_in(d.critic + C.oW2(), C.h2, 0, C.h1, DZ2, DZ1);
-        dense_fwd(d.critic + C.oW3(), d.critic + C.ob3(), C.h2, 1, CB2, DZ3A, ACT_NONE);   // q(s, pi) -> DZ3A row 0 (temp)
-        __syncthreads();
-        float aloss = 0.0f;
-        if (tid < kB) aloss = -DZ3A[tid];
-        {   // relu mask of critic layer 1; dzb2 for the action gradient with dq = -1/B
-            for (int e = tid; e < C.h1 * kB; e += kTrainThreads) {
-                const int i = e >> 6, bb = e & 63;
-                if (!(X2[i * kP + bb] > 0.0f)) DZ1[i * kP + bb] = 0.0f;
-            }
-            const int wave = tid >> 6;
-            for (int j = wave; j < C.h2; j += 4) {
-                const float a2 = CB2[j * kP + b];
-                const float da2 = d.critic[C.oW3() + j] * (-1.0f / (float)kB);
-                DZB2[j * kP + b] = da2 * (llt ? (1.0f - a2 * a2) : (a2 > 0.0f ? 1.0f : 0.0f));
-            }
-        }
-        __syncthreads();
-        // d(-mean Q)/d(action) = rows h1.. of W2 dzb2, then through the actor's output tanh
-        dense_bwd_in(d.critic + C.oW2(), C.h2, C.h1, C.h1 + d.act_dim, DZB2, DZ3A);
-        __syncthreads();
-        for (int e = tid; e < d.act_dim * kB; e += kTrainThreads) {
-            const int c = e >> 6, bb = e & 63;
-            const float pi = PI[c * kP + bb];
-            DZ3A[c * kP + bb] *= (1.0f - pi * pi);
-        }
-        __syncthreads();
-        dense_bwd_in(d.actor + A.oW3(), A.out, 0, A.h2, DZ3A, DZ2A);
-        __syncthreads();
-        for (int e = tid; e < A.h2 * kB; e += kTrainThreads) {
-            const int j = e >> 6, bb = e & 63;
-            const float u2 = U2[j * kP + bb];
-            DZ2A[j * kP + bb] *= llt ? (1.0f - u2 * u2) : (u2 > 0.0f ? 1.0f : 0.0f);
-        }
-        __syncthreads();
-        dense_bwd_in(d.actor + A.oW2(), A.h2, 0, A.h1, DZ2A, DZ1A);
-        __syncthreads();
-        for (int e = tid; e < A.h1 * kB; e += kTrainThreads) {
-            const int i = e >> 6, bb = e & 63;
-            if (!(U1[i * kP + bb] > 0.0f)) DZ1A[i * kP + bb] = 0.0f;
-        }
-        __syncthreads();
-        // ---- losses (means over the batch) -----------------------------------------------------------
-        {
-            float v0 = closs, v1 = aloss;
+#ifdef SSC_DDPG_DIAG
+        uint64_t cp_prev = __builtin_amdgcn_s_memtime();
+#endif
+        for (int si = 0; si < g.n_steps; ++si) {
+            const Step &st = g.steps[si];   // kernel-argument segment: scalar loads, the whole block follows one step
+            const float *X = lds + st.x;
+            float *Z = lds + st.z;
+            switch (st.kind) {
+            case ST_GATHER:   // ReplayBuffer.sample_batch rows
+                if (tid < kB) {
+                    const int64_t rec = g.batch_idx[(int64_t)it * kB + tid];
+                    float *S = lds + g.off_S, *S2 = lds + g.off_S2, *RT = lds + g.off_RT, *XA = lds + g.off_X2act;
+                    for (int c = 0; c < d.obs_dim; ++c) {
+                        S[c * kP + tid] = g.rp.s[rec * d.obs_dim + c];
+                        S2[c * kP + tid] = g.rp.s2[rec * d.obs_dim + c];
+                    }
+                    for (int c = 0; c < d.act_dim; ++c) XA[c * kP + tid] = g.rp.a[rec * d.act_dim + c];
+                    RT[0 * kP + tid] = g.rp.r[rec];
+                    RT[1 * kP + tid] = g.rp.t[rec] ? 1.0f : 0.0f;
+                }
+                break;
+            case ST_FWD:
+                if (st.out == 1 && st.tail_from >= st.in)
+                    dense_fwd_out1(lds + st.w, lds + st.b, st.in, X, Z, st.act);
+                else if ((st.out & 3) == 0)
+                    dense_fwd<true>(lds + st.w, lds + st.b, st.in, st.out, X, Z, st.act, lds + st.xtail, st.tail_from);
+                else
+                    dense_fwd<false>(lds + st.w, lds + st.b, st.in, st.out, X, Z, st.act, lds + st.xtail, st.tail_from);
+                break;
+            case ST_YTARGET:  // target_Q = r + (1 - terminal) * gamma * Q'(s2, pi'(s2))      (ddpg_editted.py:132-133)
+                if (tid < kB) {
+                    float *RT = lds + g.off_RT;
+                    RT[2 * kP + tid] = RT[tid] + (1.0f - RT[kP + tid]) * d.gamma * X[tid];
+                }
+                break;
+            case ST_CLOSS:    // critic loss = mean((Q - y)^2)                                  (:181)
+                if (tid < kB) {
+                    const float e = X[tid] - (lds + g.off_RT)[2 * kP + tid];
+                    closs = e * e;
+                    Z[tid] = 2.0f * e / (float)kB;   // d loss / d q
+                }
+                break;
+            case ST_FILL:
+                for (int e = tid; e < st.out * kB; e += kTrainThreads) Z[(e >> 6) * kP + (e & 63)] = st.c;
+                break;
+            case ST_BWD:
+                if ((st.out & 3) == 0) dense_bwd_in<true>(lds + st.w, st.out, st.i0, st.i1, X, Z, lds + st.xtail, st.act);
+                else dense_bwd_in<false>(lds + st.w, st.out, st.i0, st.i1, X, Z, lds + st.xtail, st.act);
+                break;
+            case ST_DERIV:    // delta *= act'(activation): tanh -> 1 - a^2, relu -> a > 0
+                for (int e = tid; e < st.out * kB; e += kTrainThreads) {
+                    const int o = (e >> 6) * kP + (e & 63);
+                    const float a = X[o];
+                    Z[o] *= (st.act == ACT_TANH) ? (1.0f - a * a) : (a > 0.0f ? 1.0f : 0.0f);
+                }
+                break;
+            case ST_ALOSS:    // actor loss = -mean Q(s, pi(s))                                  (:168)
+                if (tid < kB) aloss = -X[tid];
+                break;
+            case ST_LOSSES: {
+                float v0 = (tid < kB) ? closs : 0.0f, v1 = (tid < kB) ? aloss : 0.0f;
 #pragma unroll
-            for (int msk = 32; msk >= 1; msk >>= 1) { v0 += __shfl_xor(v0, msk); v1 += __shfl_xor(v1, msk); }
-            if ((tid & 63) == 0) { red[0][tid >> 6] = v0; red[1][tid >> 6] = v1; }
-        }
-        // ---- gradients + MpiAdam, all from the OLD parameters' deltas               (:326-327) ------------
-        const int tA = g.d.adam_t[0] + 1, tC = g.d.adam_t[1] + 1;
-        // bias-correction factors in f64: 1 - 0.999^t loses 5 digits in fp32 for small t
-        const AdamCfg ca{(float)((double)d.actor_lr * sqrt(1.0 - pow((double)d.beta2, (double)tA)) /
-                                 (1.0 - pow((double)d.beta1, (double)tA))), d.beta1, d.beta2, d.epsilon};
-        const AdamCfg cc{(float)((double)d.critic_lr * sqrt(1.0 - pow((double)d.beta2, (double)tC)) /
-                                 (1.0 - pow((double)d.beta1, (double)tC))), d.beta1, d.beta2, d.epsilon};
-        __syncthreads();   // every read of the old parameters is done
-        weight_grad_adam(S, DZ1, C.in, C.h1, d.critic, d.adam_m_critic, d.adam_v_critic, C.oW1(), C.ob1(), cc);
-        weight_grad_adam(X2, DZ2, C.h1 + d.act_dim, C.h2, d.critic, d.adam_m_critic, d.adam_v_critic, C.oW2(), C.ob2(), cc);
-        weight_grad_adam(CA2, DQ, C.h2, 1, d.critic, d.adam_m_critic, d.adam_v_critic, C.oW3(), C.ob3(), cc);
-        weight_grad_adam(S, DZ1A, A.in, A.h1, d.actor, d.adam_m_actor, d.adam_v_actor, A.oW1(), A.ob1(), ca);
-        weight_grad_adam(U1, DZ2A, A.h1, A.h2, d.actor, d.adam_m_actor, d.adam_v_actor, A.oW2(), A.ob2(), ca);
-        weight_grad_adam(U2, DZ3A, A.h2, A.out, d.actor, d.adam_m_actor, d.adam_v_actor, A.oW3(), A.ob3(), ca);
-        __syncthreads();   // the block's own global writes are visible to itself after the barrier
-        // ---- update_target_net: theta' <- (1 - tau) theta' + tau theta              (:338-339) ------------
-        for (int e = tid; e < A.total(); e += kTrainThreads)
-            d.target_actor[e] = (1.0f - d.tau) * d.target_actor[e] + d.tau * d.actor[e];
-        for (int e = tid; e < C.total(); e += kTrainThreads)
-            d.target_critic[e] = (1.0f - d.tau) * d.target_critic[e] + d.tau * d.critic[e];
-        if (tid == 0) {
-            g.d.adam_t[0] = tA;
-            g.d.adam_t[1] = tC;
-            if (g.losses != nullptr) {
-                g.losses[2 * it + 0] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)kB;
-                g.losses[2 * it + 1] = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)kB;
+                for (int msk = 32; msk >= 1; msk >>= 1) { v0 += __shfl_xor(v0, msk); v1 += __shfl_xor(v1, msk); }
+                if (b == 0) { red[0][tid >> 6] = v0; red[1][tid >> 6] = v1; }
+                ++tA; ++tC;
+                if (tid == 0) {
+                    // MpiAdam step sizes of this iteration; bias correction in f64 (1 - 0.999^t loses 5 digits in fp32)
+                    cfg_s[0] = AdamCfg{(float)((double)d.actor_lr * sqrt(1.0 - ipow((double)d.beta2, tA)) /
+                                               (1.0 - ipow((double)d.beta1, tA))), d.beta1, d.beta2, d.epsilon};
+                    cfg_s[1] = AdamCfg{(float)((double)d.critic_lr * sqrt(1.0 - ipow((double)d.beta2, tC)) /
+                                               (1.0 - ipow((double)d.beta1, tC))), d.beta1, d.beta2, d.epsilon};
+                }
+                break;
             }
+            case ST_WGRAD:    // gradients + MpiAdam, all from the OLD parameters' deltas         (:326-327)
+                if (st.net == 0)
+                    weight_grad_adam(X, Z, st.in, st.out, th_a, d.adam_m_actor, d.adam_v_actor, st.w, st.b, cfg_s[0],
+                                     lds + st.xtail, st.tail_from);
+                else
+                    weight_grad_adam(X, Z, st.in, st.out, th_c, d.adam_m_critic, d.adam_v_critic, st.w, st.b, cfg_s[1],
+                                     lds + st.xtail, st.tail_from);
+                break;
+            case ST_TUPDATE:  // update_target_net: theta' <- (1 - tau) theta' + tau theta       (:338-339)
+                for (int e = tid; e < g.n_actor; e += kTrainThreads) th_ta[e] = (1.0f - d.tau) * th_ta[e] + d.tau * th_a[e];
+                for (int e = tid; e < g.n_critic; e += kTrainThreads) th_tc[e] = (1.0f - d.tau) * th_tc[e] + d.tau * th_c[e];
+#ifndef SSC_DDPG_DIAG
+                if (tid == 0 && g.losses != nullptr) {
+                    g.losses[2 * it + 0] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)kB;
+                    g.losses[2 * it + 1] = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)kB;
+                }
+#endif
+                break;
+            }
+            if (st.barrier) __syncthreads();
+#ifdef SSC_DDPG_DIAG
+            {
+                __builtin_amdgcn_sched_barrier(0);
+                const uint64_t now = __builtin_amdgcn_s_memtime();
+                if (tid == 0) g.losses[(int64_t)kMaxSteps * it + si] = (float)(now - cp_prev);
+                cp_prev = now;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
         }
-        __threadfence_block();
-        __syncthreads();
     }
+    // the forward kernels outside (ssc_actor_forward, ssc_critic_forward, rollouts) read the global arrays
+    for (int e = tid; e < g.n_actor; e += kTrainThreads) { d.actor[e] = th_a[e]; d.target_actor[e] = th_ta[e]; }
+    for (int e = tid; e < g.n_critic; e += kTrainThreads) { d.critic[e] = th_c[e]; d.target_critic[e] = th_tc[e]; }
+    if (tid == 0) { d.adam_t[0] = tA; d.adam_t[1] = tC; }
 }
+
+// ---- host: LDS carve and the step list of one iteration -----------------------------------------------------------
+struct NetDims {
+    int in, h1, h2, out;     // actor: obs -> h1 -> h2 -> act ; critic: obs -> h1 (+act) -> h2 -> 1
+    int extra;               // rows concatenated to the first hidden layer (critic: act_dim, actor: 0)
+    int oW1() const { return 0; }
+    int ob1() const { return in * h1; }
+    int oW2() const { return ob1() + h1; }
+    int ob2() const { return oW2() + (h1 + extra) * h2; }
+    int oW3() const { return ob2() + h2; }
+    int ob3() const { return oW3() + h2 * out; }
+    int total() const { return ob3() + out; }
+};
+
+struct StepList {
+    TrainArgs &g;
+    bool overflow = false;
+    explicit StepList(TrainArgs &a) : g(a) { g.n_steps = 0; }
+    Step &add(int kind, bool barrier) {
+        if (g.n_steps >= kMaxSteps) { overflow = true; g.n_steps = kMaxSteps - 1; }
+        Step &s = g.steps[g.n_steps++];
+        s = Step{};
+        s.kind = (int16_t)kind; s.barrier = barrier ? 1 : 0; s.tail_from = 0x7fff;
+        return s;
+    }
+    void fwd(int theta, const NetDims &n, int layer, int x, int z, int act, bool barrier, int xtail = -1, int tail_from = 0x7fff) {
+        Step &s = add(ST_FWD, barrier);
+        s.w = theta + (layer == 1 ? n.oW1() : layer == 2 ? n.oW2() : n.oW3());
+        s.b = theta + (layer == 1 ? n.ob1() : layer == 2 ? n.ob2() : n.ob3());
+        s.in = (int16_t)(layer == 1 ? n.in : layer == 2 ? n.h1 + n.extra : n.h2);
+        s.out = (int16_t)(layer == 1 ? n.h1 : layer == 2 ? n.h2 : n.out);
+        s.x = x; s.z = z; s.act = (int16_t)act;
+        s.xtail = xtail >= 0 ? xtail : x; s.tail_from = (int16_t)tail_from;
+    }
+    // a_rows / act: activation rows whose derivative multiplies the result (act == ACT_NONE: none)
+    void bwd(int theta_w, int out, int i0, int i1, int dz, int dx, int a_rows, int act, bool barrier) {
+        Step &s = add(ST_BWD, barrier);
+        s.w = theta_w; s.out = (int16_t)out; s.i0 = (int16_t)i0; s.i1 = (int16_t)i1; s.x = dz; s.z = dx;
+        s.xtail = a_rows; s.act = (int16_t)act;
+    }
+    void deriv(int a, int dlt, int rows, int act, bool barrier) {
+        Step &s = add(ST_DERIV, barrier);
+        s.x = a; s.z = dlt; s.out = (int16_t)rows; s.act = (int16_t)act;
+    }
+    void wgrad(int net, int offW, int offb, int in, int out, int x, int dz, bool barrier, int xtail = -1, int tail_from = 0x7fff) {
+        Step &s = add(ST_WGRAD, barrier);
+        s.net = (int16_t)net; s.w = offW; s.b = offb; s.in = (int16_t)in; s.out = (int16_t)out; s.x = x; s.z = dz;
+        s.xtail = xtail >= 0 ? xtail : x; s.tail_from = (int16_t)tail_from;
+    }
+};
 
 }  // namespace ssc
 
@@ -312,25 +425,93 @@ extern "C" int ssc_ddpg_train(const ssc_ddpg_desc *d, const ssc_replay_view *rp,
                 "ssc_ddpg_train: obs_dim/act_dim out of range");
     SSC_REQUIRE(d->actor_h1 >= 1 && d->actor_h2 >= 1 && d->critic_h1 >= 1 && d->critic_h2 >= 1,
                 "ssc_ddpg_train: bad hidden sizes");
+    if (d->actor_h1 > 64 || d->actor_h2 > 64 || d->critic_h1 > 64 || d->critic_h2 > 64)
+        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: hidden layers wider than 64 units (the batch's activations "
+                                           "and the parameters must fit the 160 KB of LDS)");
     if (n_iters == 0) return SSC_OK;
     SSC_REQUIRE(d->actor && d->critic && d->target_actor && d->target_critic && d->adam_m_actor && d->adam_v_actor &&
                     d->adam_m_critic && d->adam_v_critic && d->adam_t,
                 "ssc_ddpg_train: NULL parameter / optimiser pointer");
     SSC_REQUIRE(rp->s && rp->a && rp->r && rp->t && rp->s2 && rp->capacity > 0 && d_batch_idx,
                 "ssc_ddpg_train: NULL replay pointer");
-    const int rows = 2 * d->obs_dim + 3 + (d->critic_h1 + d->act_dim) + d->critic_h2 + 1 + d->critic_h2 + d->critic_h1 +
-                     d->actor_h1 + d->actor_h2 + d->act_dim + d->act_dim + d->actor_h2 + d->actor_h1 +
-                     (d->critic_h1 + d->act_dim) + 2 * d->critic_h2;
-    const size_t lds = (size_t)rows * kP * sizeof(float);
-    if (lds > 150 * 1024)
-        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: hidden sizes need %zu B of LDS (> 150 KB)", lds);
+
+    const NetDims A{d->obs_dim, d->actor_h1, d->actor_h2, d->act_dim, 0};
+    const NetDims C{d->obs_dim, d->critic_h1, d->critic_h2, 1, d->act_dim};
+    const int act2 = d->last_layer_tanh ? ACT_TANH : ACT_RELU;
+    TrainArgs g{};
+    g.d = *d; g.rp = *rp; g.batch_idx = d_batch_idx; g.n_iters = n_iters; g.losses = d_losses;
+    // ---- LDS carve (rows of kP floats), then the parameters --------------------------------------------------
+    int p = 0;
+    auto take = [&](int rows) { const int q = p; p += rows * kP; return q; };
+    const int S = take(d->obs_dim), RT = take(3);                             // RT: r, terminal, y (target Q)
+    const int X2 = take(C.h1 + d->act_dim);                                   // critic: relu(layer 1) rows, then the action rows
+    const int CA2 = take(C.h2 > d->obs_dim ? C.h2 : d->obs_dim);              // critic layer 2; before that the next-state rows
+    const int S2 = CA2;                                                       // (read by the target pass's first two steps only)
+    const int DQ = take(1), DZ2 = take(C.h2);
+    const int DZ1 = take(C.h1 + d->act_dim);                                  // critic layer-1 deltas; before that the target pass's X2B
+    const int U1 = take(A.h1), U2 = take(A.h2), PI = take(d->act_dim);
+    const int DZ3A = take(d->act_dim), DZ2A = take(A.h2), DZ1A = take(A.h1);
+    const int CB2 = take(C.h2), DZB2 = take(C.h2);                            // also target-pass scratch
+    const int X2B = DZ1;
+    g.off_S = S; g.off_S2 = S2; g.off_RT = RT; g.off_X2act = X2 + C.h1 * kP;
+    g.n_actor = A.total(); g.n_critic = C.total();
+    // every parameter vector starts on a 16-byte boundary: the dense passes read weights as float4 (a
+    // misaligned ds_read_b128 was measured 6x slower)
+    auto al4 = [](int x) { return (x + 3) & ~3; };
+    const int TA = al4(p), TC = al4(TA + A.total()), TTA = al4(TC + C.total()), TTC = al4(TTA + A.total());
+    g.off_theta[0] = TA; g.off_theta[1] = TC; g.off_theta[2] = TTA; g.off_theta[3] = TTC;
+    p = TTC + C.total();
+    const size_t lds = (size_t)p * sizeof(float);
+    if (lds > 160 * 1024 - 128)   // 64 B of static LDS (loss partials, Adam step sizes)
+        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: these layer sizes need %zu B of LDS", lds);
+    // ---- the steps of one iteration ----------------------------------------------------------------------------
+    StepList L(g);
+    L.add(ST_GATHER, true);
+    // target_Q = r + (1 - terminal) * gamma * Q'(s2, pi'(s2))      (ddpg_editted.py:132-133)
+    L.fwd(TTA, A, 1, S2, DZ1A, ACT_RELU, false);
+    L.fwd(TTC, C, 1, S2, X2B, ACT_RELU, true);
+    L.fwd(TTA, A, 2, DZ1A, DZ2A, act2, true);
+    L.fwd(TTA, A, 3, DZ2A, X2B + C.h1 * kP, ACT_TANH, true);
+    L.fwd(TTC, C, 2, X2B, CB2, act2, true);
+    L.fwd(TTC, C, 3, CB2, DZB2, ACT_NONE, true);
+    { Step &s = L.add(ST_YTARGET, false); s.x = DZB2; }
+    // critic on (s, a) and actor on s                                (:181, :127)
+    L.fwd(TC, C, 1, S, X2, ACT_RELU, false);
+    L.fwd(TA, A, 1, S, U1, ACT_RELU, true);
+    L.fwd(TC, C, 2, X2, CA2, act2, false);
+    L.fwd(TA, A, 2, U1, U2, act2, true);
+    L.fwd(TC, C, 3, CA2, DQ, ACT_NONE, false);
+    L.fwd(TA, A, 3, U2, PI, ACT_TANH, true);
+    { Step &s = L.add(ST_CLOSS, true); s.x = DQ; s.z = DQ; }
+    // critic backward: dz2 = (W3 dq) * act'(z2)
+    L.bwd(TC + C.oW3(), 1, 0, C.h2, DQ, DZ2, CA2, act2, false);
+    // critic forward on (s, pi(s)) for the actor loss: the same relu(layer 1) rows, the action rows are pi(s)
+    L.fwd(TC, C, 2, X2, CB2, act2, true, PI, C.h1);
+    L.bwd(TC + C.oW2(), C.h2, 0, C.h1, DZ2, DZ1, X2, ACT_RELU, false);   // ... * relu'(layer 1)
+    L.fwd(TC, C, 3, CB2, DZ3A, ACT_NONE, true);             // q(s, pi) -> DZ3A row 0 (temporarily)
+    { Step &s = L.add(ST_ALOSS, false); s.x = DZ3A; }
+    { Step &s = L.add(ST_FILL, true); s.z = DZ3A; s.out = 1; s.c = -1.0f / (float)kB; }   // dq of -mean Q
+    L.bwd(TC + C.oW3(), 1, 0, C.h2, DZ3A, DZB2, CB2, act2, true);
+    // d(-mean Q)/d(action) = rows h1.. of W2 dzb2 (through the output tanh), then back through the actor
+    L.bwd(TC + C.oW2(), C.h2, C.h1, C.h1 + d->act_dim, DZB2, DZ3A, PI, ACT_TANH, true);
+    L.bwd(TA + A.oW3(), A.out, 0, A.h2, DZ3A, DZ2A, U2, act2, true);
+    L.bwd(TA + A.oW2(), A.h2, 0, A.h1, DZ2A, DZ1A, U1, ACT_RELU, false);
+    L.add(ST_LOSSES, true);                                  // every read of the old parameters is done after this barrier
+    L.wgrad(1, C.oW1(), C.ob1(), C.in, C.h1, S, DZ1, false);
+    L.wgrad(1, C.oW2(), C.ob2(), C.h1 + d->act_dim, C.h2, X2, DZ2, false);
+    L.wgrad(1, C.oW3(), C.ob3(), C.h2, 1, CA2, DQ, false);
+    L.wgrad(0, A.oW1(), A.ob1(), A.in, A.h1, S, DZ1A, false);
+    L.wgrad(0, A.oW2(), A.ob2(), A.h1, A.h2, U1, DZ2A, false);
+    L.wgrad(0, A.oW3(), A.ob3(), A.h2, A.out, U2, DZ3A, true);
+    L.add(ST_TUPDATE, true);
+    if (L.overflow) return set_error(SSC_EINVAL, "ssc_ddpg_train: step list overflow");
+
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(ddpg_train_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "hipFuncSetAttribute(ddpg_train_kernel)");
         if (rc) return rc;
     }
-    TrainArgs g{*d, *rp, d_batch_idx, n_iters, d_losses};
     hipLaunchKernelGGL(ddpg_train_kernel, dim3(1), dim3(kTrainThreads), lds, as_stream(stream), g);
     return check_launch("ssc_ddpg_train");
 }
