@@ -24,7 +24,11 @@ namespace ssc {
 constexpr int kB = 64;       // batch size = lanes of a wave
 constexpr int kP = kB + 4;   // padded LDS row: 16-B aligned rows (float4 access over 4 samples); a stride of
                              // 68 dwords keeps both ds_read_b128 column gathers and ds_write_b128 conflict-free
-constexpr int kTrainThreads = 256;
+#ifndef SSC_DDPG_THREADS
+#define SSC_DDPG_THREADS 512
+#endif
+constexpr int kTrainThreads = SSC_DDPG_THREADS;
+constexpr int kNW = kTrainThreads / 64;   // waves: the dense passes deal unit groups / input rows round-robin to them
 constexpr int kMaxSteps = 44;
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
@@ -82,7 +86,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-// Z[j][b] = act(bias[j] + sum_i W[i][j] X[i][b]) for the NQ unit groups {4 (wave + 4 q)} of this wave.
+// Z[j][b] = act(bias[j] + sum_i W[i][j] X[i][b]) for the NQ unit groups {4 (wave + kNW q)} of this wave.
 // Input rows i >= tail_from come from Xtail (the critic's action rows live apart from relu(layer 1)).
 template <int NQ, bool AL4>
 __device__ __forceinline__ void dense_fwd_groups(const float *W, const float *bias, int in, int out, const float *X,
@@ -90,24 +94,24 @@ __device__ __forceinline__ void dense_fwd_groups(const float *W, const float *bi
     const int wave = threadIdx.x >> 6, b = threadIdx.x & 63;
     f4 acc[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = weights4<AL4>(bias, 4 * (wave + 4 * q), out);
+    for (int q = 0; q < NQ; ++q) acc[q] = weights4<AL4>(bias, 4 * (wave + kNW * q), out);
     const int n_head = in < tail_from ? in : tail_from;
 #pragma unroll 8
     for (int i = 0; i < n_head; ++i) {
         const float x = X[i * kP + b];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] += weights4<AL4>(W + i * out, 4 * (wave + 4 * q), out) * x;
+        for (int q = 0; q < NQ; ++q) acc[q] += weights4<AL4>(W + i * out, 4 * (wave + kNW * q), out) * x;
     }
     for (int i = n_head; i < in; ++i) {
         const float x = Xtail[(i - tail_from) * kP + b];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] += weights4<AL4>(W + i * out, 4 * (wave + 4 * q), out) * x;
+        for (int q = 0; q < NQ; ++q) acc[q] += weights4<AL4>(W + i * out, 4 * (wave + kNW * q), out) * x;
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int j = 4 * (wave + 4 * q) + e;
+            const int j = 4 * (wave + kNW * q) + e;
             if (AL4 || j < out) Z[j * kP + b] = apply_act(acc[q][e], act);
         }
 }
@@ -134,14 +138,14 @@ __device__ __forceinline__ void dense_fwd(const float *W, const float *bias, int
                                           int act, const float *Xtail, int tail_from) {
     const int wave = threadIdx.x >> 6;
     const int groups = (out + 3) >> 2;
-    const int nq = (groups - wave + 3) >> 2;   // groups wave, wave + 4, ... < groups  (out <= 64: nq <= 4)
+    const int nq = (groups - wave + kNW - 1) / kNW;   // groups wave, wave + kNW, ... < groups  (out <= 64: nq <= 4)
     if (nq >= 4) dense_fwd_groups<4, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
     else if (nq == 3) dense_fwd_groups<3, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
     else if (nq == 2) dense_fwd_groups<2, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
     else if (nq == 1) dense_fwd_groups<1, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
 }
 
-// dX[i - i0][b] = sum_j W[i][j] dZ[j][b] for the NR input rows {i0 + wave + 4 (qbase + r)} of this wave.
+// dX[i - i0][b] = sum_j W[i][j] dZ[j][b] for the NR input rows {i0 + wave + kNW (qbase + r)} of this wave.
 // act != ACT_NONE: the result is multiplied by act'(A[i - i0]) (tanh: 1 - a^2, relu: a > 0) on the way out.
 __device__ __forceinline__ float act_deriv(float a, int act) {
     return act == ACT_TANH ? 1.0f - a * a : (act == ACT_RELU ? (a > 0.0f ? 1.0f : 0.0f) : 1.0f);
@@ -161,14 +165,14 @@ __device__ __forceinline__ void dense_bwd_rows(const float *W, int out, int i0, 
         for (int e = 0; e < 4; ++e) dz[e] = (AL4 || j + e < out) ? dZ[(j + e) * kP + b] : 0.0f;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int i = i0 + wave + 4 * (qbase + r);
+            const int i = i0 + wave + kNW * (qbase + r);
             const f4 w = weights4<AL4>(W + i * out, j, out);
             acc[r] += (w[0] * dz[0] + w[1] * dz[1]) + (w[2] * dz[2] + w[3] * dz[3]);
         }
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const int o = (wave + 4 * (qbase + r)) * kP + b;
+        const int o = (wave + kNW * (qbase + r)) * kP + b;
         dX[o] = acc[r] * act_deriv(A[o], act);
     }
 }
@@ -177,7 +181,7 @@ template <bool AL4>
 __device__ __forceinline__ void dense_bwd_in(const float *W, int out, int i0, int i1, const float *dZ, float *dX,
                                              const float *A, int act) {
     const int wave = threadIdx.x >> 6;
-    const int nr = (i1 - i0 - wave + 3) >> 2;   // rows i0 + wave, i0 + wave + 4, ... of this wave
+    const int nr = (i1 - i0 - wave + kNW - 1) / kNW;   // rows i0 + wave, i0 + wave + kNW, ... of this wave
     int q = 0;
     for (; q + 4 <= nr; q += 4) dense_bwd_rows<4, AL4>(W, out, i0, q, dZ, dX, A, act);
     if (nr - q == 3) dense_bwd_rows<3, AL4>(W, out, i0, q, dZ, dX, A, act);
@@ -236,7 +240,7 @@ __device__ __forceinline__ void weight_grad_adam(const float *X, const float *dZ
 // the cycles thread 0 spent in each step instead of the losses.
 __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float red[2][kTrainThreads / 64];
+    __shared__ float red[2][kNW];
     __shared__ AdamCfg cfg_s[2];
     const ssc_ddpg_desc &d = g.d;
     const int tid = threadIdx.x, b = tid & 63;
@@ -336,8 +340,10 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
                 for (int e = tid; e < g.n_critic; e += kTrainThreads) th_tc[e] = (1.0f - d.tau) * th_tc[e] + d.tau * th_c[e];
 #ifndef SSC_DDPG_DIAG
                 if (tid == 0 && g.losses != nullptr) {
-                    g.losses[2 * it + 0] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)kB;
-                    g.losses[2 * it + 1] = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)kB;
+                    float l0 = 0.0f, l1 = 0.0f;
+                    for (int w = 0; w < kNW; ++w) { l0 += red[0][w]; l1 += red[1][w]; }
+                    g.losses[2 * it + 0] = l0 / (float)kB;
+                    g.losses[2 * it + 1] = l1 / (float)kB;
                 }
 #endif
                 break;
