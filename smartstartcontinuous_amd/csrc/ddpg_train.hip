@@ -456,8 +456,10 @@ extern "C" int ssc_ddpg_train(const ssc_ddpg_desc *d, const ssc_replay_view *rp,
     const int DQ = take(1), DZ2 = take(C.h2);
     const int DZ1 = take(C.h1 + d->act_dim);                                  // critic layer-1 deltas; before that the target pass's X2B
     const int U1 = take(A.h1), U2 = take(A.h2), PI = take(d->act_dim);
-    const int DZ3A = take(d->act_dim), DZ2A = take(A.h2), DZ1A = take(A.h1);
-    const int CB2 = take(C.h2), DZB2 = take(C.h2);                            // also target-pass scratch
+    const int DZ3A = take(d->act_dim), DZ1A = take(A.h1);
+    const int CB2 = take(C.h2 > A.h2 ? C.h2 : A.h2), DZB2 = take(C.h2);       // also target-pass scratch
+    const int DZ2A = CB2;   // actor layer-2 deltas: written (bwd a3) after the last read of CB2, and in the target pass
+                            // (target actor layer 2) read for the last time before CB2 is written
     const int X2B = DZ1;
     g.off_S = S; g.off_S2 = S2; g.off_RT = RT; g.off_X2act = X2 + C.h1 * kP;
     g.n_actor = A.total(); g.n_critic = C.total();

@@ -198,14 +198,25 @@ def test_rltrain_with_smartstart_agent(ssc, golden_dir):
     assert len(path) >= 2 and np.asarray(path).shape[1] == 2
 
 
-def test_ddpg_train_kernel_vs_oracle(ssc):
+class _BoxEnv:
+    """Just the spaces a DDPG agent reads: obs_dim-dimensional observations, one action in [-1, 1]."""
+
+    def __init__(self, obs_dim):
+        from smartstartcontinuous_amd import spaces
+        self.observation_space = spaces.Box(low=-np.ones(obs_dim, np.float32), high=np.ones(obs_dim, np.float32))
+        self.action_space = spaces.Box(low=np.array([-1.0], np.float32), high=np.array([1.0], np.float32))
+
+
+@pytest.mark.parametrize("obs_dim,h1,h2", [(2, 64, 32), (3, 64, 32), (8, 64, 32), (2, 24, 20)])
+def test_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2):
     """ssc_ddpg_train (train + update_target_net, n iterations in one launch) against the fp64 restatement
-    of ddpg_editted.py:287-339 (itself cross-checked against torch autograd on the CPU)."""
+    of ddpg_editted.py:287-339 (itself cross-checked against torch autograd on the CPU).  obs_dim 3 is the
+    Pendulum layout, 8 the widest the ABI admits (the LDS carve must hold), 24-20 exercises ragged unit groups."""
     from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
     rng = np.random.default_rng(11)
-    env = ssc.make("MountainCarContinuous-v0")
+    env = ssc.make("MountainCarContinuous-v0") if obs_dim == 2 else _BoxEnv(obs_dim)
     for llt in (True, False):
-        agent = DDPG_Baselines_agent(env, None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32, lastLayerTanh=llt,
+        agent = DDPG_Baselines_agent(env, None, actor_h1=h1, actor_h2=h2, critic_h1=h1, critic_h2=h2, lastLayerTanh=llt,
                                      actor_lr=1e-3, critic_lr=1e-3, gamma=0.99, tau=0.001, batch_size=64, seed=5,
                                      training=False)
         # non-trivial starting point: perturb every parameter (biases and the 3e-3 output layers included)
@@ -216,11 +227,11 @@ def test_ddpg_train_kernel_vs_oracle(ssc):
         agent.target_actor_flat += 0.01
         agent.target_critic_flat -= 0.01
         cap, n_iters, B = 1000, 6, 64
-        s = rng.uniform(-1.2, 0.6, (cap, 2)).astype(np.float32)
+        s = rng.uniform(-1.2, 0.6, (cap, obs_dim)).astype(np.float32)
         a = rng.uniform(-1, 1, (cap, 1)).astype(np.float32)
         r = (rng.normal(size=cap) * 0.5).astype(np.float32)
         t = (rng.random(cap) < 0.1)
-        s2 = (s + rng.normal(size=(cap, 2)) * 0.01).astype(np.float32)
+        s2 = (s + rng.normal(size=(cap, obs_dim)) * 0.01).astype(np.float32)
         idx = np.stack([rng.permutation(cap)[:B] for _ in range(n_iters)]).astype(np.int32)
         # oracle state (fp64 copies of what the device holds)
         o_a = {k: v.astype(np.float64) for k, v in aw.items()}
