@@ -47,6 +47,7 @@ class Summary:
 
     def __init__(self, name=None, last_x=5):
         self.name = name
+        self._pending = []      # (lengths, returns) numpy chunks from the fused rollouts, not yet turned into tuples
         self.episodes = []
         self.best_path = None
         self.best_reward = -sys.maxsize                      # :163
@@ -88,6 +89,30 @@ class Summary:
         if total_reward > self.best_reward:
             self.best_reward = float(total_reward)
 
+    def extend_records(self, lengths, total_rewards):
+        """Many finished episodes at once (numpy arrays from the episode ring).  A 65 536-env chunk can finish
+        65 536 of them; building that many Python tuples per chunk would dominate the loop, so the arrays are
+        kept and turned into the reference's list of ``(steps, total_reward)`` tuples when ``episodes`` is read."""
+        if len(lengths) == 0:
+            return
+        self._pending.append((np.asarray(lengths).copy(), np.asarray(total_rewards).copy()))
+        best = float(total_rewards.max())
+        if best > self.best_reward:
+            self.best_reward = best
+
+    @property
+    def episodes(self):
+        if self._pending:
+            pend, self._pending = self._pending, []
+            for lengths, rets in pend:
+                self._episodes.extend(zip(lengths.tolist(), rets.tolist()))
+        return self._episodes
+
+    @episodes.setter
+    def episodes(self, value):
+        self._pending = []
+        self._episodes = value
+
     # ---- accessors (:205-255) ---------------------------------------------------------------------
     def total_episode_reward(self):
         return [reward for _, reward in self.episodes]
@@ -114,19 +139,23 @@ class Summary:
         return self.last_rewards[-(x + 1)]
 
     def __len__(self):
-        return len(self.episodes)
+        return len(self._episodes) + sum(len(l) for l, _ in self._pending)
 
     # ---- persistence (:257-374) ---------------------------------------------------------------------
     def to_json(self):
         def plain(o):
             return o.tolist() if isinstance(o, np.ndarray) else float(o) if isinstance(o, np.floating) else \
                 int(o) if isinstance(o, np.integer) else str(o)
-        return json.dumps(self.__dict__, default=plain)
+        d = {k: v for k, v in self.__dict__.items() if k not in ("_episodes", "_pending")}
+        d["episodes"] = self.episodes
+        return json.dumps(d, default=plain)
 
     @classmethod
     def from_json(cls, data):
         summary = cls()
-        summary.__dict__.update(json.loads(data))
+        fields = json.loads(data)
+        summary.episodes = fields.pop("episodes", [])
+        summary.__dict__.update(fields)
         return summary
 
     def save(self, directory=".", post_fix=0, extra_name_append="", last_name_section=False):
@@ -201,8 +230,7 @@ def rl_train_vec(env, policy, num_chunks, chunk_steps=1024, ring_capacity=1 << 2
             on_chunk(out, env)
         (ids, lens, rets), d = ring.drain()
         dropped += d
-        for length, ret in zip(lens.tolist(), rets.tolist()):
-            summary.append_record(length, ret)
+        summary.extend_records(lens, rets)
     summary.dropped_episode_records = dropped
     return summary
 
@@ -230,8 +258,7 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
         if l is not None:
             losses.append(l)
         (ids, lens, rets), _d = ring.drain()
-        for length, ret in zip(lens.tolist(), rets.tolist()):
-            summary.append_record(length, ret)
+        summary.extend_records(lens, rets)
         generations += len(lens) / float(env.n)
         while generations >= 1.0:
             agent.decaying_ou_action_noise.reduce_epsilon()
