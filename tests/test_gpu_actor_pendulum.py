@@ -196,3 +196,43 @@ def test_rollout_pendulum_teacher_forced(ssc, policy):
     log = _log(chunk)
     assert (log["done"][19] == 1).all() and log["done"].sum() == n           # 180 + 20 = 200
     assert abs(env.stats.cpu().numpy()[0] - log["rew"].astype(np.float64).sum()) < 0.5
+
+
+def test_rollout_actor_full_size_properties(ssc):
+    """BASELINE config 3 at full size (65 536 envs x 256 steps, actor 64-32 on the bf16 MFMA + OU noise):
+    size-independent properties on the device, the logged action equal to the standalone actor kernel plus a
+    noise term bounded by the OU process, bit-for-bit repeatability, and a 128-env slice replayed by the oracle."""
+    n, K, seed = 65536, 256, 1234
+    w = actor_weights(2, 64, 32, seed=1234, w3_scale=0.5)
+    wt = {k: torch.as_tensor(v) for k, v in w.items()}
+
+    def run():
+        env = ssc.VecEnv("MountainCarContinuous-v0", n, seed=seed)
+        obs0 = env.reset().cpu().numpy()
+        chunk = env.rollout(K, ssc.ActorPolicy(wt, precision="bf16_mfma"))
+        torch.cuda.synchronize()
+        return env, obs0, chunk
+    env, obs0, chunk = run()
+    done = chunk.done.bool()
+    cont = (chunk.obs[:, 1:] == chunk.obs2[:, :-1]).all(dim=0) | done[:-1]
+    assert bool(cont.all())
+    assert float(chunk.act.abs().max()) <= 1.0                                   # clip of DDPG_editted.pi (:271)
+    assert float(chunk.obs2[0].min()) >= -1.2000001 and float(chunk.obs2[0].max()) <= 0.6000001
+    assert float(chunk.obs2[1].abs().max()) <= 0.0700001
+    goal = chunk.obs2[0] >= 0.45
+    r = goal.float() * 100.0 - 0.1 * chunk.act * chunk.act
+    assert float((r - chunk.rew).abs().max()) <= 1e-4
+    assert bool((done == goal).all())                                             # 256 < 999: no time-limit resets yet
+    stats = env.stats.cpu().numpy()
+    assert stats[2] == n * K and stats[3] == int(done.sum().item())
+    # same seed, same ids -> the same bits
+    _, _, chunk2 = run()
+    assert torch.equal(chunk.act, chunk2.act) and torch.equal(chunk.obs2, chunk2.obs2) and torch.equal(chunk.rew, chunk2.rew)
+    # a slice of envs, every step re-derived by the oracle from the logged state (teacher forced)
+    sl = slice(4000, 4128)
+    log = {k: v[..., sl] for k, v in _log(chunk).items()}
+    pol = O.OracleDDPGPolicy(w, seed, 4000, 128, bf16=False)
+    res = O.replay_rollout("mc", log, seed, 4000, 0, 999, obs0[sl], np.zeros(128, np.int64), pol)
+    assert res["start_max_err"] == 0 and res["continuity_mismatch"] == 0 and res["done_mismatch"] == 0, res
+    assert res["max_dact"] <= TOL_ACT_BF16 and res["max_drew_rel"] <= 1e-6, res
+    assert res["max_dobs2"][0] <= 2.4e-7 and res["max_dobs2"][1] <= 1e-8, res

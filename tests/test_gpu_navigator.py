@@ -456,3 +456,44 @@ def test_default_mfma_precision_falls_back_to_fp32_kernels_for_uncovered_network
     S = model.do_forward_sim(s0, A).cpu().numpy()
     ref = O.dyn_forward_sim(s0, A, norm32(nm), Ws, bs)
     assert np.max(np.abs(S - ref)) <= 3e-2 * max(1.0, np.abs(ref).max())
+
+
+def test_forward_sim_and_scoring_full_size_properties(nav):
+    """BASELINE config 4 at full size (65 536 rows, in 4 / 2x500 / out 3, H = 4; 16 problems x 4096 samples):
+    S[0] is the start state, a row's trajectory depends on its own (s0, actions) only (a row permutation permutes
+    the output bit for bit), 512 rows spread over the batch match the fp64 oracle, the scorer's argmax is the max
+    of its scores and identical problems get identical results."""
+    rng = np.random.default_rng(44)
+    P, N, H, d, a = 16, 4096, 4, 3, 1
+    M = P * N
+    Ws, bs = make_mlp(rng, (4, 500, 500, 3))
+    norm = make_norm(rng, d, a)
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=a, precision="bf16_mfma")
+    A = torch.as_tensor(rng.uniform(-2, 2, size=(M, H, a)).astype(np.float32), device="cuda")
+    s0 = torch.as_tensor((rng.normal(size=(M, d)) * 0.3).astype(np.float32), device="cuda")
+    S = model.do_forward_sim(s0, A)
+    assert S.shape == (H + 1, M, d) and torch.equal(S[0], s0) and bool(torch.isfinite(S).all())
+    perm = torch.as_tensor(rng.permutation(M), device="cuda")
+    Sp = model.do_forward_sim(s0[perm], A[perm])
+    assert torch.equal(Sp, S[:, perm])
+    rows = np.sort(rng.choice(M, 512, replace=False))
+    ref = O.dyn_forward_sim(s0[rows].cpu().numpy(), A[rows].cpu().numpy(), norm32(norm), Ws, bs)
+    got = S[:, rows].cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 3e-2 * max(1.0, np.abs(ref).max())       # SURVEY 8d: 3e-2 rel (bf16)
+    # scoring: every problem follows the same 60-waypoint path; problems 0 and 1 get identical samples
+    wp = np.cumsum(rng.normal(scale=[0.02, 0.004, 0.01], size=(60, d)), axis=0)
+    stds, means = O.path_deltas_stds_and_means_per_dim(wp)
+    r = O.radii_calc(means, stds, 1, 1, 1) + 1e-4
+    left = O.distances_left(wp, O.distance_func(r))
+    ps = nav.MpcProblemSet([wp] * P, [left] * P, [r] * P, [0] * P, theta=1.0, gamma=0.75, horizontal_penalty_factor=0.5)
+    S4 = (torch.as_tensor(wp[0], dtype=torch.float32, device="cuda") + 0.02 * S).contiguous()
+    S4[:, N:2 * N] = S4[:, :N]
+    scores, best, best_score = nav.mpc_score(ps, S4)
+    scores = scores.view(P, N)
+    assert bool(torch.isfinite(scores).all())
+    assert torch.equal(best_score, scores.max(dim=1).values) and torch.equal(best.long(), scores.argmax(dim=1))
+    assert torch.equal(scores[0], scores[1]) and int(best[0]) == int(best[1])
+    p0 = S4[:, :N].cpu().numpy().astype(np.float64)
+    ref_scores, _, _, _ = O.mpc_scores_add_delta(p0, wp.astype(np.float32), np.asarray(left, np.float32),
+                                                 np.asarray(r, np.float32), 0, theta=1.0, gamma=0.75, hpf=0.5)
+    assert np.max(np.abs(scores[0].cpu().numpy() - ref_scores)) <= 1e-3 * max(1.0, np.abs(ref_scores).max())
