@@ -217,8 +217,9 @@ int ssc_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float 
 /* Dyn_Model.do_forward_sim, batched branch (NN_Dynamics_Model/dynamics_model.py:204-240):
  *   S[0] = s0;  for t < H:  x = nan_to_num((S[t]-mean_x)/std_x) || nan_to_num((A[:,t]-mean_y)/std_y)
  *                           S[t+1] = S[t] + net(x) * std_z + mean_z
- * d_s0 is [s0_rows][state_dim] with s0_rows == m, or s0_rows == 1 (one start state tiled to all
- * rows, :215-217).  d_A is [m][H][act_dim]; d_S is [H+1][m][state_dim]. */
+ * d_s0 is [s0_rows][state_dim]: s0_rows == 1 (one start state tiled to all rows, :215-217), s0_rows == m,
+ * or any divisor P of m (P problems with m/P candidate sequences each: row r starts from state r / (m/P)).
+ * d_A is [m][H][act_dim]; d_S is [H+1][m][state_dim]. */
 size_t ssc_dyn_workspace_bytes(const ssc_mlp_desc *mlp, int64_t m, int precision);
 /* The MFMA path works from a packed bf16 image of the weights (and of the statistics) in the workspace.
  * ssc_dyn_forward_sim / ssc_mlp_forward with SSC_PREC_BF16_MFMA write that image on every call; a caller
@@ -251,10 +252,11 @@ typedef struct ssc_mpc_problems {
 } ssc_mpc_problems;
 
 /* all_samples = npr.uniform(low, high, (N, H, act)) (NND_MB_agent.py:500-501) for P problems:
- * d_A [P*N][H][act_dim], Philox(seed; (problem_id0+p) << 32 | n, t, TAG_MPC). */
+ * d_A [P*N][H][act_dim], Philox(seed; (problem_id0+p) << 32 | n, t, TAG_MPC).  d_t_base (may be NULL) is a
+ * device-resident step counter added to t, so that a captured HIP graph can be replayed step after step. */
 int ssc_mpc_sample_actions(int32_t n_problems, int32_t n_samples, int32_t horizon, int32_t act_dim,
                            const float *low, const float *high, uint64_t seed, uint64_t problem_id0,
-                           uint64_t t, float *d_A, ssc_stream_t stream);
+                           uint64_t t, const uint64_t *d_t_base, float *d_A, ssc_stream_t stream);
 
 /* generate_scores_add_delta (NND_MB_agent.py:566-628) + argmax (:625-626) per problem.
  * d_S [H+1][P*N][state_dim] (output of ssc_dyn_forward_sim); d_scores [P*N]; d_best_idx [P]
@@ -280,6 +282,30 @@ int ssc_mpc_select_action(int32_t n_problems, int32_t n_samples, int32_t horizon
                           int32_t act_dim, const float *d_A, const float *d_S, const int32_t *d_best_idx,
                           float noise_amount, uint64_t seed, uint64_t problem_id0, uint64_t t,
                           float *d_action, float *d_best_path, ssc_stream_t stream);
+
+/* One MPC-policy step of rollout(K, policy = 'mpc') for P envs (one navigation problem each), everything
+ * after the scoring in ONE launch: executed action = best_sequence[0] + noise_amount * N(0,1) (NND_MB_agent.py:
+ * 353-356, same draws as ssc_mpc_select_action), env.step (+ TimeLimit), transition-log row, chunk statistics,
+ * episode record, NND_MB_agent.observe on the new observation (waypoint advance, :360-373), auto-reset of finished
+ * envs (state, episode counters, navigator plan position back to d_start_idx) and the planning state of the
+ * next step, d_plan_state [P][obs_dim] (the observation after a possible reset).
+ * The global step t and the log row k are DEVICE counters (*d_t, *d_k), advanced by the launch itself, so a
+ * HIP graph {ssc_mpc_sample_actions(.., 0, d_t, ..), ssc_dyn_forward_sim(d_plan_state, s0_rows = P),
+ * ssc_mpc_score, ssc_mpc_rollout_step} is replayed K times per chunk without touching the host.
+ * d_ticket: one zero-initialised int32 (election of the block that advances the counters). */
+typedef struct ssc_mpc_nav_state {
+    int32_t *cur_idx;            /* [P] current waypoint (== ssc_mpc_problems.cur_idx) */
+    const int32_t *start_idx;    /* [P] waypoint a fresh episode starts from */
+    int32_t *actions_done;       /* [P] actions spent on the current waypoint */
+    uint8_t *at_goal;            /* [P] close_enough_to_goal (:425-432); may be NULL */
+    int32_t give_up_after, final_steps;
+} ssc_mpc_nav_state;
+
+int ssc_mpc_rollout_step(const ssc_env_params *p, const ssc_mpc_problems *problems, const ssc_mpc_nav_state *nav,
+                         const float *d_A, const int32_t *d_best_idx, float noise_amount, uint64_t noise_seed,
+                         uint64_t problem_id0, const ssc_rollout_state *state, const ssc_transition_log *log,
+                         const ssc_episode_ring *ring, double *d_stats, uint64_t env_seed, uint64_t env_id0,
+                         uint64_t *d_t, int32_t *d_k, int32_t *d_ticket, float *d_plan_state, ssc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * SmartStart selection (smartstart/smartexploration/smartexplorationcontinuous.py:223-305)

@@ -77,6 +77,11 @@ class Norm(Structure):
                 ("mean_z", c_float * SSC_MAX_STATE), ("std_z", c_float * SSC_MAX_STATE)]
 
 
+class MpcNavState(Structure):
+    _fields_ = [("cur_idx", c_void_p), ("start_idx", c_void_p), ("actions_done", c_void_p), ("at_goal", c_void_p),
+                ("give_up_after", c_int32), ("final_steps", c_int32)]
+
+
 class MpcProblems(Structure):
     _fields_ = [("n_problems", c_int32), ("n_samples", c_int32), ("horizon", c_int32), ("state_dim", c_int32),
                 ("wp", c_void_p), ("left", c_void_p), ("wp_off", c_void_p), ("cur_idx", c_void_p),
@@ -157,7 +162,11 @@ _SIGNATURES = {
     "ssc_dyn_forward_sim": (c_int, [POINTER(MlpDesc), POINTER(Norm), c_int64, c_int32, c_int32, c_int32, c_void_p,
                                     c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "ssc_mpc_sample_actions": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float),
-                                       c_uint64, c_uint64, c_uint64, c_void_p, c_void_p]),
+                                       c_uint64, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "ssc_mpc_rollout_step": (c_int, [POINTER(EnvParams), POINTER(MpcProblems), POINTER(MpcNavState), c_void_p, c_void_p,
+                                     c_float, c_uint64, c_uint64, POINTER(RolloutState), POINTER(TransitionLog),
+                                     POINTER(EpisodeRing), c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
     "ssc_mpc_score_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "ssc_mpc_score": (c_int, [POINTER(MpcProblems), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                               c_void_p]),

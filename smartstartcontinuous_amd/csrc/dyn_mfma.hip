@@ -191,7 +191,7 @@ struct DynSimArgs {
     int32_t in, out;        // network input / output width
     int32_t fwd_mode;       // 1: plain y = net(x) (ssc_mlp_forward); 0: forward simulation
     const float *s0;
-    int64_t s0_rows;
+    int64_t s0_rows;        // consecutive rows sharing one start state (m / number of start states)
     const float *A;         // sim: [m][H][a]; fwd: x [m][in]
     float *S;               // sim: [H+1][m][d]; fwd: y [m][out]
     const unsigned char *a1, *a2, *a3;  // packed weight image (workspace)
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         if (!g.fwd_mode) {
 #pragma unroll
             for (int k = 0; k < DS; ++k)
-                st[nt][k] = (k < g.d) ? g.s0[(g.s0_rows == 1 ? 0 : rowc[nt]) * g.d + k] : 0.0f;
+                st[nt][k] = (k < g.d) ? g.s0[(rowc[nt] / g.s0_rows) * g.d + k] : 0.0f;   // s0_rows: rows per start state
         }
     }
 
@@ -669,7 +669,7 @@ int dyn_mfma_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t 
         if (int rc = dyn_mfma_prepare(mlp, norm, ws, s)) return rc;
     DynSimArgs g{};
     g.m = m; g.H = H; g.d = state_dim; g.a = act_dim; g.fwd_mode = 0;
-    g.s0 = d_s0; g.s0_rows = s0_rows; g.A = d_A; g.S = d_S;
+    g.s0 = d_s0; g.s0_rows = m / s0_rows; g.A = d_A; g.S = d_S;
     return run_mfma(mlp, g, ws, s);
 }
 

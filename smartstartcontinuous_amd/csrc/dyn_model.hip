@@ -83,14 +83,14 @@ struct DynDims {
     int32_t state_dim, act_dim, H;
 };
 
-// S[0] = s0 (tiled when s0_rows == 1, dynamics_model.py:215-217)
+// S[0] = s0: one state per m / s0_rows consecutive rows (s0_rows == 1: np.tile, dynamics_model.py:215-217)
 __global__ __launch_bounds__(256) void dyn_init_kernel(int64_t m, int d, const float *__restrict__ s0,
-                                                       int64_t s0_rows, float *__restrict__ S0) {
+                                                       int64_t rows_per_state, float *__restrict__ S0) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= m * d) return;
     const int64_t row = e / d;
     const int k = (int)(e - row * d);
-    S0[e] = s0[(s0_rows == 1 ? 0 : row) * d + k];
+    S0[e] = s0[(row / rows_per_state) * d + k];   // rows_per_state = m / s0_rows
 }
 
 // x[m][d+a] = normalised (S_t, A[:, t])   (dynamics_model.py:228-230)
@@ -242,7 +242,7 @@ int ssc_dyn_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m
     SSC_REQUIRE(mlp->dims[0] == state_dim + act_dim && mlp->dims[mlp->n_layers] == state_dim,
                 "ssc_dyn_forward_sim: network is %d -> %d, expected %d -> %d", mlp->dims[0],
                 mlp->dims[mlp->n_layers], state_dim + act_dim, state_dim);
-    SSC_REQUIRE(s0_rows == 1 || s0_rows == m, "ssc_dyn_forward_sim: s0_rows must be 1 or m");
+    SSC_REQUIRE(s0_rows >= 1 && (m == 0 || m % s0_rows == 0), "ssc_dyn_forward_sim: s0_rows must divide m");
     if (m == 0) return SSC_OK;
     SSC_REQUIRE(d_s0 && d_S && (H == 0 || d_A), "ssc_dyn_forward_sim: NULL device pointer");
     const size_t need = ssc_dyn_workspace_bytes(mlp, m, precision);
@@ -268,7 +268,7 @@ int ssc_dyn_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m
     const DynDims dd{state_dim, act_dim, H};
     const int in = state_dim + act_dim;
     hipLaunchKernelGGL(dyn_init_kernel, dim3(blocks_for(m * state_dim)), dim3(256), 0, s, m, state_dim, d_s0,
-                       s0_rows, d_S);
+                       m / s0_rows, d_S);
     for (int t = 0; t < H; ++t) {
         const float *St = d_S + (size_t)t * m * state_dim;
         float *Sn = d_S + (size_t)(t + 1) * m * state_dim;

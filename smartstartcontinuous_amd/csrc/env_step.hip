@@ -54,11 +54,7 @@ __global__ __launch_bounds__(kBlock) void pend_step_kernel(PendConst c, int64_t 
     thdot[i] = td;
     rew[i] = r;
     done[i] = d ? 1 : 0;
-    if (obs != nullptr) {
-        obs[i] = cosf(t);
-        obs[n + i] = sinf(t);
-        obs[2 * n + i] = td;
-    }
+    if (obs != nullptr) pend_observe_one(t, td, obs[i], obs[n + i], obs[2 * n + i]);
 }
 
 __global__ __launch_bounds__(kBlock) void env_reset_kernel(int kind, McConst mc, int64_t n,
@@ -92,10 +88,7 @@ __global__ __launch_bounds__(kBlock) void env_observe_kernel(int kind, int64_t n
         obs[i] = s0[i];
         obs[n + i] = s1[i];
     } else {
-        const float t = s0[i];
-        obs[i] = cosf(t);
-        obs[n + i] = sinf(t);
-        obs[2 * n + i] = s1[i];
+        pend_observe_one(s0[i], s1[i], obs[i], obs[n + i], obs[2 * n + i]);
     }
 }
 

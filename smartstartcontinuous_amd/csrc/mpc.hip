@@ -15,33 +15,13 @@
 //           the block of a problem that finishes last (atomic ticket) reduces the per-block winners.
 // HBM traffic is the [H+1][P*N][d] trajectory read twice (8 B/sample-step for d=2) -- negligible
 // next to the forward simulation that produced it.
-#include "ssc_device.h"
+#include "mpc_device.h"
 #include "ssc_host.h"
 
 namespace ssc {
 
 constexpr int kMpcBlock = 256;
 constexpr int kMaxH1 = 33;  // horizon + 1 <= 33
-
-struct MpcArgs {
-    int32_t P, N, H, d;
-    const float *wp, *left, *radii;
-    const int32_t *wp_off, *cur_idx;
-    float theta, gamma, hpf;
-    int32_t per_row;
-    int32_t nblk;  // blocks per problem
-};
-
-__device__ __forceinline__ float ell_dist(const float *x, const float *y, const float *inv_r, int d) {
-    float s = 0.0f;
-#pragma unroll
-    for (int k = 0; k < SSC_MAX_STATE; ++k)
-        if (k < d) {
-            const float v = (x[k] - y[k]) * inv_r[k];
-            s = fmaf(v, v, s);
-        }
-    return sqrtf(s);
-}
 
 // State of one sample's walk over the horizon
 struct WalkState {
@@ -273,9 +253,11 @@ struct ActBounds {
 
 // npr.uniform(low, high, (N, H, act)) (NND_MB_agent.py:500-501); oracle: mpc_action_samples
 __global__ __launch_bounds__(256) void mpc_sample_kernel(int P, int N, int H, int act, ActBounds bd, uint64_t seed,
-                                                         uint64_t problem_id0, uint64_t t, float *__restrict__ A) {
+                                                         uint64_t problem_id0, uint64_t t, const uint64_t *__restrict__ t_base,
+                                                         float *__restrict__ A) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= (int64_t)P * N) return;
+    if (t_base != nullptr) t += *t_base;   // device-resident step counter (HIP-graph replay)
     const uint64_t p = (uint64_t)(row / N), n = (uint64_t)(row % N);
     const uint64_t id = ((problem_id0 + p) << 32) + n;
     const int per = (H * act + 3) / 4;
@@ -324,29 +306,15 @@ __global__ __launch_bounds__(64) void mpc_observe_kernel(MpcArgs a, const float 
                                                          uint8_t *at_goal) {
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= a.P) return;
-    const int off = a.wp_off[p], W = a.wp_off[p + 1] - off, d = a.d;
-    float inv_r[SSC_MAX_STATE], x[SSC_MAX_STATE];
+    float x[SSC_MAX_STATE];
 #pragma unroll
-    for (int k = 0; k < SSC_MAX_STATE; ++k) {
-        inv_r[k] = (k < d) ? 1.0f / a.radii[p * d + k] : 0.0f;
-        x[k] = (k < d) ? ns[p * d + k] : 0.0f;
-    }
+    for (int k = 0; k < SSC_MAX_STATE; ++k) x[k] = (k < a.d) ? ns[p * a.d + k] : 0.0f;
     int idx = cur_idx[p];
     int done_act = actions_done[p];
-    const float *wp = a.wp + (int64_t)off * d;
-    const float dc = ell_dist(x, wp + idx * d, inv_r, d);                        // :364
-    const float dn = ell_dist(x, wp + min(idx + 1, W - 1) * d, inv_r, d);        // :365
-    const bool move = (dc <= a.theta || dn <= dc) && idx != W - 1;               // :491-496
-    if (move || (done_act > give_up && idx != W - 1)) {                          // :368-373
-        idx += 1;
-        done_act = 0;
-    }
+    const bool goal = nav_observe_one(a, p, x, idx, done_act, give_up, final_steps);
     cur_idx[p] = idx;
     actions_done[p] = done_act;
-    if (at_goal != nullptr) {
-        const bool near = ell_dist(x, wp + (W - 1) * d, inv_r, d) <= a.theta;   // :426
-        at_goal[p] = (near || (idx == W - 1 && final_steps <= done_act)) ? 1 : 0; // :429-431
-    }
+    if (at_goal != nullptr) at_goal[p] = goal ? 1 : 0;
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -358,7 +326,8 @@ using namespace ssc;
 extern "C" {
 
 int ssc_mpc_sample_actions(int32_t P, int32_t N, int32_t H, int32_t act, const float *low, const float *high,
-                           uint64_t seed, uint64_t problem_id0, uint64_t t, float *d_A, ssc_stream_t stream) {
+                           uint64_t seed, uint64_t problem_id0, uint64_t t, const uint64_t *d_t_base, float *d_A,
+                           ssc_stream_t stream) {
     SSC_REQUIRE(P >= 0 && N >= 0 && H >= 0, "ssc_mpc_sample_actions: negative size");
     SSC_REQUIRE(act >= 1 && act <= SSC_MAX_ACT, "ssc_mpc_sample_actions: act_dim %d out of range", act);
     SSC_REQUIRE(low && high, "ssc_mpc_sample_actions: NULL bounds");
@@ -370,7 +339,7 @@ int ssc_mpc_sample_actions(int32_t P, int32_t N, int32_t H, int32_t act, const f
         bd.span[a] = high[a] - low[a];
     }
     hipLaunchKernelGGL(mpc_sample_kernel, dim3(blocks_for((int64_t)P * N)), dim3(256), 0, as_stream(stream), P, N,
-                       H, act, bd, seed, problem_id0, t, d_A);
+                       H, act, bd, seed, problem_id0, t, d_t_base, d_A);
     return check_launch("ssc_mpc_sample_actions");
 }
 

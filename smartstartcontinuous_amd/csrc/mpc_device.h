@@ -1,0 +1,49 @@
+// mpc_device.h -- pieces of the navigator shared by the scorer (mpc.hip) and the fused MPC rollout step
+// (rollout.hip): the problem-set arguments, the radii-scaled distance and the waypoint bookkeeping of one env.
+#pragma once
+#include "ssc_device.h"
+
+namespace ssc {
+
+struct MpcArgs {
+    int32_t P, N, H, d;
+    const float *wp, *left, *radii;
+    const int32_t *wp_off, *cur_idx;
+    float theta, gamma, hpf;
+    int32_t per_row;
+    int32_t nblk;  // blocks per problem
+};
+
+// distance_func of numerical.py:116-124: || (x - y) / radii ||
+__device__ __forceinline__ float ell_dist(const float *x, const float *y, const float *inv_r, int d) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SSC_MAX_STATE; ++k)
+        if (k < d) {
+            const float v = (x[k] - y[k]) * inv_r[k];
+            s = fmaf(v, v, s);
+        }
+    return sqrtf(s);
+}
+
+// NND_MB_agent.observe (:360-373) and close_enough_to_goal (:425-432) for problem p at the new state x:
+// advances idx / done_act in place, returns the at-goal flag.
+__device__ __forceinline__ bool nav_observe_one(const MpcArgs &a, int p, const float *x, int &idx, int &done_act,
+                                                int give_up, int final_steps) {
+    const int off = a.wp_off[p], W = a.wp_off[p + 1] - off, d = a.d;
+    float inv_r[SSC_MAX_STATE];
+#pragma unroll
+    for (int k = 0; k < SSC_MAX_STATE; ++k) inv_r[k] = (k < d) ? 1.0f / a.radii[p * d + k] : 0.0f;
+    const float *wp = a.wp + (int64_t)off * d;
+    const float dc = ell_dist(x, wp + idx * d, inv_r, d);                        // :364
+    const float dn = ell_dist(x, wp + min(idx + 1, W - 1) * d, inv_r, d);        // :365
+    const bool move = (dc <= a.theta || dn <= dc) && idx != W - 1;               // :491-496
+    if (move || (done_act > give_up && idx != W - 1)) {                          // :368-373
+        idx += 1;
+        done_act = 0;
+    }
+    const bool near = ell_dist(x, wp + (W - 1) * d, inv_r, d) <= a.theta;        // :426
+    return near || (idx == W - 1 && final_steps <= done_act);                     // :429-431
+}
+
+}  // namespace ssc

@@ -14,6 +14,7 @@
 // wave-aggregated atomic cursor; chunk statistics are reduced wave -> block -> one f64
 // atomic per block.
 #include "actor_device.h"
+#include "mpc_device.h"
 #include "ssc_device.h"
 #include "ssc_host.h"
 
@@ -54,11 +55,7 @@ struct PendEnv {
     static constexpr int OBS = 3;
     float th, thdot;
     __device__ void load(float a, float b) { th = a; thdot = b; }
-    __device__ void observe(float (&o)[OBS]) const {
-        float s, c;
-        sincosf(th, &s, &c);
-        o[0] = c; o[1] = s; o[2] = thdot;
-    }
+    __device__ void observe(float (&o)[OBS]) const { pend_observe_one(th, thdot, o[0], o[1], o[2]); }
     __device__ void step(const Const &c, float a, float &rew, bool &goal) {
         pend_step_one(c, th, thdot, a, rew);
         goal = false;
@@ -366,6 +363,132 @@ static int dispatch_policy(const typename EnvT::Const &ec, const ssc_policy_desc
     return set_error(SSC_EINVAL, "ssc_rollout: unknown precision %d", a.precision);
 }
 
+
+// ---------------------------------------------------------------- MPC-policy rollout step --
+// Everything of one rollout(K, 'mpc') step that follows the scoring, for P envs (one navigation problem each)
+// in one launch: executed action, env.step, log row, statistics, episode record, navigator bookkeeping,
+// auto-reset, planning state of the next step.  The step index t and the log row k come from device counters
+// that the launch advances itself (the block that finishes last), so the whole step is HIP-graph replayable.
+struct MpcStepArgs {
+    MpcArgs nav;
+    int32_t *cur_idx;
+    const int32_t *start_idx;
+    int32_t *actions_done;
+    uint8_t *at_goal;
+    int32_t give_up, final_steps;
+    const float *A;
+    const int32_t *best_idx;
+    float noise;
+    uint64_t noise_seed, problem_id0;
+    uint64_t *d_t;
+    int32_t *d_k, *ticket;
+    float *plan_state;
+};
+
+template <class EnvT>
+__global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT::Const ec, RolloutArgs ra, MpcStepArgs ma) {
+    constexpr int OBS = EnvT::OBS;
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = gi < ra.n;
+    const int64_t i = active ? gi : ra.n - 1;
+    const uint64_t t = *ma.d_t;
+    const int32_t k = *ma.d_k;
+    float rew = 0.0f;
+    bool goal = false, done = false;
+    if (active) {
+        EnvT env;
+        env.load(ra.st.s0[i], ra.st.s1[i]);
+        int32_t el = ra.st.steps[i];
+        float ep_ret = ra.st.ep_ret[i];
+        float obs[OBS], obs2[OBS];
+        env.observe(obs);
+        // action = best_sequence[0] + noise * N(0,1), no clip (NND_MB_agent.py:353-356; ssc_mpc_select_action's draw)
+        const int64_t row = i * ma.nav.N + ma.best_idx[i];
+        float a = ma.A[row * ma.nav.H];   // act_dim == 1 (the envs of this engine)
+        if (ma.noise != 0.0f) {
+            const u32x4 w = rng_words(ma.noise_seed, ma.problem_id0 + (uint64_t)i, t, TAG_MPC_NOISE);
+            a += ma.noise * gaussian_f32(w.x, w.y);
+        }
+        env.step(ec, a, rew, goal);
+        env.observe(obs2);
+        el += 1;
+        done = goal || (ec.max_episode_steps > 0 && el >= ec.max_episode_steps);
+        ep_ret += rew;
+        if (ra.has_log) {
+            const int64_t lr = (int64_t)k * ra.log.row_stride + i, ld = (int64_t)k * ra.log.done_row_stride + i;
+#pragma unroll
+            for (int c = 0; c < OBS; ++c) {
+                ra.log.obs[c][lr] = obs[c];
+                ra.log.obs2[c][lr] = obs2[c];
+            }
+            ra.log.act[lr] = a;
+            ra.log.rew[lr] = rew;
+            ra.log.done[ld] = done ? 1 : 0;
+        }
+        // NND_MB_agent.get_action counts the action (:340), observe advances the waypoint (:360-373)
+        float x[SSC_MAX_STATE];
+#pragma unroll
+        for (int c = 0; c < SSC_MAX_STATE; ++c) x[c] = (c < OBS) ? obs2[c < OBS ? c : 0] : 0.0f;
+        int idx = ma.cur_idx[i];
+        int done_act = ma.actions_done[i] + 1;
+        const bool at_goal = nav_observe_one(ma.nav, (int)i, x, idx, done_act, ma.give_up, ma.final_steps);
+        if (ma.at_goal != nullptr) ma.at_goal[i] = at_goal ? 1 : 0;
+        if (done) {
+            if (ra.has_ring) {
+                const uint32_t slot = atomicAdd(ra.ring.cursor, 1u);
+                if (slot < (uint32_t)ra.ring.capacity) {
+                    ra.ring.env_id[slot] = (int64_t)(ra.env_id0 + (uint64_t)i);
+                    ra.ring.length[slot] = el;
+                    ra.ring.ret[slot] = ep_ret;
+                }
+            }
+            env.reset(ec, rng_words(ra.seed, ra.env_id0 + (uint64_t)i, t, TAG_RESET));
+            el = 0;
+            ep_ret = 0.0f;
+            idx = ma.start_idx[i];    // start_new_episode_plan (:383-384)
+            done_act = 0;
+            if (ra.st.ou_x != nullptr) ra.st.ou_x[i] = 0.0f;
+        }
+        ra.st.s0[i] = env.s0();
+        ra.st.s1[i] = env.s1();
+        ra.st.steps[i] = el;
+        ra.st.ep_ret[i] = ep_ret;
+        ma.cur_idx[i] = idx;
+        ma.actions_done[i] = done_act;
+        env.observe(obs);
+#pragma unroll
+        for (int c = 0; c < OBS; ++c) ma.plan_state[i * OBS + c] = obs[c];
+    }
+    __shared__ double red[kBlock / 64][4];
+    if (ra.stats != nullptr) {
+        double v[4] = {active ? (double)rew : 0.0, (active && goal) ? 1.0 : 0.0, active ? 1.0 : 0.0, (active && done) ? 1.0 : 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v[q] += __shfl_xor(v[q], m);
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[wave][q] = v[q];
+    }
+    __syncthreads();
+    if (ra.stats != nullptr && threadIdx.x < 4) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) s += red[w][threadIdx.x];
+        atomicAdd(ra.stats + threadIdx.x, s);
+    }
+    // every block has read *d_t / *d_k before it gets here; the last one to arrive advances them
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ma.ticket, 1) == (int)gridDim.x - 1) {
+            *ma.ticket = 0;
+            *ma.d_t = t + 1;
+            *ma.d_k = k + 1;
+        }
+    }
+}
+
 }  // namespace ssc
 
 using namespace ssc;
@@ -436,4 +559,69 @@ extern "C" int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *polic
     if (p->kind == SSC_ENV_PENDULUM)
         return dispatch_policy<PendEnv>(make_pend_const(*p), policy, pa, ra, as_stream(stream));
     return set_error(SSC_EINVAL, "ssc_rollout: unknown env kind %d", p->kind);
+}
+
+extern "C" int ssc_mpc_rollout_step(const ssc_env_params *p, const ssc_mpc_problems *pr, const ssc_mpc_nav_state *nav,
+                                    const float *d_A, const int32_t *d_best_idx, float noise_amount, uint64_t noise_seed,
+                                    uint64_t problem_id0, const ssc_rollout_state *state, const ssc_transition_log *log,
+                                    const ssc_episode_ring *ring, double *d_stats, uint64_t env_seed, uint64_t env_id0,
+                                    uint64_t *d_t, int32_t *d_k, int32_t *d_ticket, float *d_plan_state,
+                                    ssc_stream_t stream) {
+    SSC_REQUIRE(p && pr && nav && state, "ssc_mpc_rollout_step: NULL descriptor");
+    const int64_t n = pr->n_problems;
+    SSC_REQUIRE(n >= 0 && pr->n_samples >= 1 && pr->horizon >= 1, "ssc_mpc_rollout_step: bad problem sizes");
+    if (n == 0) return SSC_OK;
+    const int obs_dim = (p->kind == SSC_ENV_MOUNTAINCAR) ? 2 : 3;
+    SSC_REQUIRE(pr->state_dim == obs_dim, "ssc_mpc_rollout_step: the navigator plans in observation space (%d dims), "
+                                          "problems have %d", obs_dim, pr->state_dim);
+    SSC_REQUIRE(pr->wp && pr->wp_off && pr->radii && nav->cur_idx && nav->start_idx && nav->actions_done,
+                "ssc_mpc_rollout_step: NULL navigator pointer");
+    SSC_REQUIRE(state->s0 && state->s1 && state->steps && state->ep_ret, "ssc_mpc_rollout_step: NULL state column");
+    SSC_REQUIRE(d_A && d_best_idx && d_t && d_k && d_ticket && d_plan_state, "ssc_mpc_rollout_step: NULL device pointer");
+    RolloutArgs ra;
+    ra.n = n;
+    ra.K = 1;
+    ra.st = *state;
+    ra.has_log = log != nullptr;
+    ra.has_ring = ring != nullptr;
+    if (log) {
+        ra.log = *log;
+        for (int c = 0; c < obs_dim; ++c)
+            SSC_REQUIRE(log->obs[c] && log->obs2[c], "ssc_mpc_rollout_step: NULL log obs column %d", c);
+        SSC_REQUIRE(log->act && log->rew && log->done, "ssc_mpc_rollout_step: NULL log column");
+        if (ra.log.row_stride == 0) ra.log.row_stride = n;
+        if (ra.log.done_row_stride == 0) ra.log.done_row_stride = n;
+        SSC_REQUIRE(ra.log.row_stride >= n && ra.log.done_row_stride >= n, "ssc_mpc_rollout_step: row stride < n");
+    } else {
+        ra.log = ssc_transition_log{};
+    }
+    if (ring) {
+        ra.ring = *ring;
+        SSC_REQUIRE(ring->env_id && ring->length && ring->ret && ring->cursor && ring->capacity >= 0,
+                    "ssc_mpc_rollout_step: bad episode ring");
+    } else {
+        ra.ring = ssc_episode_ring{};
+    }
+    ra.stats = d_stats;
+    ra.seed = env_seed;
+    ra.env_id0 = env_id0;
+    ra.step0 = 0;
+    MpcStepArgs ma{};
+    ma.nav.P = pr->n_problems; ma.nav.N = pr->n_samples; ma.nav.H = pr->horizon; ma.nav.d = pr->state_dim;
+    ma.nav.wp = pr->wp; ma.nav.left = pr->left; ma.nav.radii = pr->radii; ma.nav.wp_off = pr->wp_off;
+    ma.nav.cur_idx = pr->cur_idx; ma.nav.theta = pr->theta;
+    ma.cur_idx = nav->cur_idx; ma.start_idx = nav->start_idx; ma.actions_done = nav->actions_done; ma.at_goal = nav->at_goal;
+    ma.give_up = nav->give_up_after; ma.final_steps = nav->final_steps;
+    ma.A = d_A; ma.best_idx = d_best_idx; ma.noise = noise_amount; ma.noise_seed = noise_seed; ma.problem_id0 = problem_id0;
+    ma.d_t = d_t; ma.d_k = d_k; ma.ticket = d_ticket; ma.plan_state = d_plan_state;
+    hipStream_t s = as_stream(stream);
+    if (p->kind == SSC_ENV_MOUNTAINCAR) {
+        if (int rc = validate_mc_params(p, "ssc_mpc_rollout_step")) return rc;
+        hipLaunchKernelGGL(mpc_rollout_step_kernel<McEnv>, dim3(blocks_for(n)), dim3(kBlock), 0, s, make_mc_const(*p), ra, ma);
+    } else if (p->kind == SSC_ENV_PENDULUM) {
+        hipLaunchKernelGGL(mpc_rollout_step_kernel<PendEnv>, dim3(blocks_for(n)), dim3(kBlock), 0, s, make_pend_const(*p), ra, ma);
+    } else {
+        return set_error(SSC_EINVAL, "ssc_mpc_rollout_step: unknown env kind %d", p->kind);
+    }
+    return check_launch("ssc_mpc_rollout_step");
 }

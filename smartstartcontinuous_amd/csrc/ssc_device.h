@@ -152,11 +152,15 @@ SSC_HD PendConst make_pend_const(const ssc_env_params &p) {
     return c;
 }
 
+// The Pendulum arithmetic spells out every fused multiply-add and forbids implicit contraction: hipcc otherwise
+// decides per call site which a*b+c become v_fma, and two kernels that inline the same source (single-step API,
+// fused rollout, MPC rollout step) would round differently.
 // ((x + pi) mod 2pi) - pi with python-modulo semantics (result of mod in [0, 2pi)).
 SSC_HD float angle_normalize(float x) {
+#pragma clang fp contract(off)
     const float TWO_PI = 6.28318530717958647692f;
     const float y = x + 3.14159265358979323846f;
-    float r = y - TWO_PI * floorf(y * (1.0f / TWO_PI));
+    float r = fmaf(-TWO_PI, floorf(y * (1.0f / TWO_PI)), y);
     // floorf rounding can leave r marginally outside [0, 2pi)
     if (r < 0.0f) r += TWO_PI;
     if (r >= TWO_PI) r -= TWO_PI;
@@ -164,22 +168,36 @@ SSC_HD float angle_normalize(float x) {
 }
 
 SSC_HD void pend_step_one(const PendConst &c, float &th, float &thdot, float a, float &rew) {
+#pragma clang fp contract(off)
     const float u = fminf(fmaxf(a, -c.max_torque), c.max_torque);
     const float an = angle_normalize(th);
-    const float cost = an * an + 0.1f * thdot * thdot + 0.001f * (u * u);
+    const float cost = fmaf(an, an, fmaf(0.1f * thdot, thdot, 0.001f * (u * u)));
     // sin(th + pi) = -sin(th)
-    float nd = thdot + (3.0f * c.g / (2.0f * c.l) * sinf(th) + 3.0f / (c.m * c.l * c.l) * u) * c.dt;
+    const float k1 = 3.0f * c.g / (2.0f * c.l), k2 = 3.0f / (c.m * c.l * c.l);
+    float nd = fmaf(fmaf(k1, sinf(th), k2 * u), c.dt, thdot);
     float nt;
     if (c.v1_order) {
         nd = fminf(fmaxf(nd, -c.max_speed), c.max_speed);
-        nt = th + nd * c.dt;
+        nt = fmaf(nd, c.dt, th);
     } else {
-        nt = th + nd * c.dt;
+        nt = fmaf(nd, c.dt, th);
         nd = fminf(fmaxf(nd, -c.max_speed), c.max_speed);
     }
     th = nt;
     thdot = nd;
     rew = -cost;
+}
+
+// PendulumEnv._get_obs [third-party gym 0.10.5]: (cos th, sin th, thdot).  One definition for every kernel, so
+// the single-step API, the fused rollouts and the MPC rollout step report the same bits.
+SSC_HD void pend_observe_one(float th, float thdot, float &c, float &s, float &td) {
+#ifdef __HIP_DEVICE_COMPILE__
+    sincosf(th, &s, &c);
+#else
+    s = sinf(th);
+    c = cosf(th);
+#endif
+    td = thdot;
 }
 
 SSC_HD void pend_reset_one(const u32x4 &w, float &th, float &thdot) {

@@ -255,17 +255,18 @@ class MpcProblemSet:
         return s
 
 
-def mpc_sample_actions(P, N, H, low, high, seed, problem_id0=0, t=0, device="cuda"):
-    """``npr.uniform(low, high, (N, H, act))`` per problem (NND_MB_agent.py:500-501) -> [P*N, H, act]."""
+def mpc_sample_actions(P, N, H, low, high, seed, problem_id0=0, t=0, device="cuda", out=None, t_base=None):
+    """``npr.uniform(low, high, (N, H, act))`` per problem (NND_MB_agent.py:500-501) -> [P*N, H, act].
+    ``t_base``: a one-element int64 device tensor added to ``t`` on the device (HIP-graph replay)."""
     low = np.asarray(low, np.float32).reshape(-1)
     high = np.asarray(high, np.float32).reshape(-1)
     act = low.size
-    A = torch.empty((P * N, H, act), dtype=torch.float32, device=device)
+    A = out if out is not None else torch.empty((P * N, H, act), dtype=torch.float32, device=device)
     lo = (ctypes.c_float * act)(*low.tolist())
     hi = (ctypes.c_float * act)(*high.tolist())
     with torch.cuda.device(A.device):
         _ffi.check(_ffi.lib().ssc_mpc_sample_actions(P, N, H, act, lo, hi, int(seed), int(problem_id0), int(t),
-                                                     _ffi.ptr(A), _stream()))
+                                                     _ffi.ptr(t_base), _ffi.ptr(A), _stream()))
     return A
 
 
@@ -353,3 +354,50 @@ class NavigatorBatch:
         m = mask.bool()
         self.problems.cur_idx[m] = self.start_idx[m]
         self.actions_done[m] = 0
+
+    # ---- fused, HIP-graph replayable step (VecEnv.rollout(K, MpcPolicy)) ------------------------------------
+    def _fused_buffers(self, device):
+        if getattr(self, "_fb", None) is None:
+            M, d = self.P * self.N, self.problems.d
+            lib = _ffi.lib()
+            nbytes = lib.ssc_mpc_score_workspace_bytes(self.P, self.N, self.H)
+            self._fb = dict(
+                A=torch.empty((M, self.H, len(self.low)), dtype=torch.float32, device=device),
+                scores=torch.empty(M, dtype=torch.float32, device=device),
+                best=torch.zeros(self.P, dtype=torch.int32, device=device),
+                best_score=torch.empty(self.P, dtype=torch.float32, device=device),
+                ws=torch.empty(nbytes, dtype=torch.uint8, device=device),
+                plan=torch.empty((self.P, d), dtype=torch.float32, device=device),
+                t=torch.zeros(1, dtype=torch.int64, device=device),      # global step counter (uint64 on the device)
+                k=torch.zeros(1, dtype=torch.int32, device=device),      # log row inside the chunk
+                ticket=torch.zeros(1, dtype=torch.int32, device=device))
+        return self._fb
+
+    def fused_step(self, env, chunk, ring):
+        """Enqueue ONE MPC-policy step for every env of ``env`` (a VecEnv with one env per problem): sample ->
+        forward sim from the planning states -> score -> ``ssc_mpc_rollout_step``.  Step index and log row come
+        from device counters, so the sequence is captured once as a HIP graph and replayed."""
+        fb = self._fused_buffers(env.device)
+        lib = _ffi.lib()
+        if len(self.low) != 1:
+            raise ValueError("the envs of this engine take one action component")
+        mpc_sample_actions(self.P, self.N, self.H, self.low, self.high, self.seed, self.problem_id0, 0,
+                           out=fb["A"], t_base=fb["t"])
+        S = self.model.do_forward_sim(fb["plan"], fb["A"], out=self._S)
+        st = self.problems.as_struct(self.N, self.H)
+        nav = _ffi.MpcNavState(self.problems.cur_idx.data_ptr(), self.start_idx.data_ptr(), self.actions_done.data_ptr(),
+                               self.at_goal.data_ptr(), self.give_up, self.final_steps)
+        rs = _ffi.RolloutState(env.s0.data_ptr(), env.s1.data_ptr(), env.steps.data_ptr(), env.ep_ret.data_ptr(),
+                               env.ou_x.data_ptr())
+        log_s = chunk.as_struct() if chunk is not None else None
+        ring_s = ring.as_struct() if ring is not None else None
+        with torch.cuda.device(env.device):
+            _ffi.check(lib.ssc_mpc_score(ctypes.byref(st), _ffi.ptr(S), _ffi.ptr(fb["scores"]), _ffi.ptr(fb["best"]),
+                                         _ffi.ptr(fb["best_score"]), _ffi.ptr(fb["ws"]), fb["ws"].numel(), _stream()))
+            _ffi.check(lib.ssc_mpc_rollout_step(
+                ctypes.byref(env.params), ctypes.byref(st), ctypes.byref(nav), _ffi.ptr(fb["A"]), _ffi.ptr(fb["best"]),
+                float(self.noise_amount), self.seed, self.problem_id0, ctypes.byref(rs),
+                ctypes.byref(log_s) if log_s is not None else None,
+                ctypes.byref(ring_s) if ring_s is not None else None,
+                _ffi.ptr(env.stats), env._seed, env.env_id0, _ffi.ptr(fb["t"]), _ffi.ptr(fb["k"]), _ffi.ptr(fb["ticket"]),
+                _ffi.ptr(fb["plan"]), _stream()))

@@ -75,10 +75,12 @@ class ActorPolicy:
 class MpcPolicy:
     """The SmartStart navigator as a rollout policy (NND_MB_agent.get_action, NND_MB_agent.py:339-358):
     ``navigators`` is a :class:`smartstartcontinuous_amd.navigator.NavigatorBatch` with one problem per env.
-    Unlike RANDOM / ACTOR this policy is a chain of kernels per step (sample, forward-sim, score, select,
-    env step, waypoint advance), not one fused launch: the forward simulation dominates by orders of
-    magnitude."""
+    Unlike RANDOM / ACTOR this policy is a chain of launches per step -- sample, forward sim, score (2), and one
+    fused launch for action / env step / log / statistics / waypoint advance / auto-reset -- whose step index and
+    log row are device counters: the chain is captured once as a HIP graph and replayed K times per chunk
+    (``graph=False``: the step-by-step reference path through the single-purpose entry points)."""
     navigators: object
+    graph: bool = True
 
 
 class TransitionChunk:
@@ -295,6 +297,8 @@ class VecEnv:
         if self._needs_reset:
             self.reset()
         if isinstance(policy, MpcPolicy):
+            if policy.graph:
+                return self._rollout_mpc_graph(K, policy.navigators, out, log, ring)
             return self._rollout_mpc(K, policy.navigators, out, log)
         if policy_desc is None:
             policy_desc = self.policy_desc(policy)
@@ -320,9 +324,63 @@ class VecEnv:
         return chunk
 
 
+    def _rollout_mpc_graph(self, K, nav, out, log, ring):
+        """K steps with the MPC navigator choosing every action, each step ONE replay of a captured HIP graph
+        (NavigatorBatch.fused_step): nothing but the graph launch runs on the host, there is no device -> host
+        read inside the chunk."""
+        if nav.P != self.n:
+            raise ValueError("MpcPolicy needs one navigation problem per env")
+        if nav.problems.d != self.obs_dim:
+            raise ValueError("the navigator plans in observation space")
+        chunk = None
+        cache = self.__dict__.setdefault("_mpc_graphs", {})
+        if log:
+            # the graph bakes the log pointers in: without `out` the steps are logged into a chunk kept with the
+            # graph and the caller gets a copy (a fresh chunk per call would mean a fresh capture per call)
+            chunk = out if out is not None else cache.setdefault(("chunk", K), TransitionChunk(self.obs_dim, K, self.n, self.device))
+            if (chunk.K, chunk.N, chunk.obs_dim) != (K, self.n, self.obs_dim):
+                raise ValueError("out chunk has the wrong shape")
+            chunk.step0, chunk.env_id0 = self.t, self.env_id0
+        fb = nav._fused_buffers(self.device)
+        fb["t"].fill_(self.t)
+        fb["k"].zero_()
+        fb["plan"].copy_(self.observe())
+        key = (id(nav), self.n, None if chunk is None else chunk.act.data_ptr(), None if ring is None else ring.cursor.data_ptr())
+        if key not in cache:
+            # warm-up outside the capture (lazy allocations, the weight image, LDS opt-ins) on a side stream, then
+            # restore the state it advanced
+            snap = [x.clone() for x in (self.s0, self.s1, self.steps, self.ep_ret, self.stats, nav.problems.cur_idx,
+                                        nav.actions_done, nav.at_goal, fb["plan"], fb["t"], fb["k"])]
+            ring_snap = None if ring is None else ring.cursor.clone()
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                nav.fused_step(self, chunk, ring)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            for dst, src in zip((self.s0, self.s1, self.steps, self.ep_ret, self.stats, nav.problems.cur_idx,
+                                 nav.actions_done, nav.at_goal, fb["plan"], fb["t"], fb["k"]), snap):
+                dst.copy_(src)
+            if ring is not None:
+                ring.cursor.copy_(ring_snap)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                nav.fused_step(self, chunk, ring)
+            cache[key] = g
+        g = cache[key]
+        for _ in range(K):
+            g.replay()
+        self.t += K
+        if chunk is not None and out is None:
+            copy = TransitionChunk(self.obs_dim, K, self.n, self.device, packed=chunk.packed)
+            for dst, src in zip(copy.columns(), chunk.columns()):
+                dst.copy_(src)
+            copy.step0, copy.env_id0 = chunk.step0, chunk.env_id0
+            return copy
+        return chunk
+
     def _rollout_mpc(self, K, nav, out, log):
         """K steps with the MPC navigator choosing every action (one problem per env); same transition log
-        and statistics as the fused kernels, auto-reset on done."""
+        and statistics as the fused kernels, auto-reset on done.  Step-by-step reference path."""
         if nav.P != self.n:
             raise ValueError("MpcPolicy needs one navigation problem per env")
         chunk = None
@@ -341,7 +399,9 @@ class VecEnv:
                 chunk.obs2[:, k, :] = obs2.t()
             nav.observe(obs2)
             self.ep_ret += rew
-            self.stats += torch.stack([rew.double().sum(), torch.zeros((), dtype=torch.float64, device=self.device),
+            goals = (done & (obs2[:, 0] >= self.params.goal_position)) if self.kind == _ffi.SSC_ENV_MOUNTAINCAR \
+                else torch.zeros_like(done)
+            self.stats += torch.stack([rew.double().sum(), goals.double().sum(),
                                        torch.tensor(float(self.n), dtype=torch.float64, device=self.device),
                                        done.double().sum()])
             if bool(done.any()):

@@ -497,3 +497,56 @@ def test_forward_sim_and_scoring_full_size_properties(nav):
     ref_scores, _, _, _ = O.mpc_scores_add_delta(p0, wp.astype(np.float32), np.asarray(left, np.float32),
                                                  np.asarray(r, np.float32), 0, theta=1.0, gamma=0.75, hpf=0.5)
     assert np.max(np.abs(scores[0].cpu().numpy() - ref_scores)) <= 1e-3 * max(1.0, np.abs(ref_scores).max())
+
+
+@pytest.mark.parametrize("env_name,max_steps,prec", [("MountainCarContinuous-v0", 9, "f32"), ("Pendulum-v0", 6, "bf16_mfma")])
+def test_mpc_rollout_graph_replay_equals_step_by_step_path(nav, env_name, max_steps, prec):
+    """rollout(K, MpcPolicy): the HIP-graph path (fused ssc_mpc_rollout_step, device step counters) produces the
+    same bits as the step-by-step path through the single-purpose entry points -- log, env state, navigator
+    state, statistics, episode records -- across auto-resets (short time limit) and over two consecutive chunks."""
+    import smartstartcontinuous_amd as ssc
+    rng = np.random.default_rng(8)
+    P, N, H, K = 70, 128, 3, 8
+    d = 2 if env_name.startswith("Mountain") else 3
+    Ws, bs = make_mlp(rng, (d + 1, 32, d))
+    norm = make_norm(rng, d, 1)
+    paths = [np.cumsum(rng.normal(scale=0.02, size=(12, d)), axis=0) for _ in range(P)]
+
+    def setup(graph):
+        env = ssc.VecEnv(env_name, P, seed=21, max_episode_steps=max_steps)
+        env.reset()
+        model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=1, precision=prec)
+        wps, lefts, radii = [], [], []
+        for pth in paths:
+            stds, means = O.path_deltas_stds_and_means_per_dim(pth)
+            r = O.radii_calc(means, stds, 1, 1, 1) + 1e-3
+            wps.append(pth); radii.append(r); lefts.append(O.distances_left(pth, O.distance_func(r)))
+        ps = nav.MpcProblemSet(wps, lefts, radii, [1] * P)
+        lo, hi = ([-1.0], [1.0]) if d == 2 else ([-2.0], [2.0])
+        batch = nav.NavigatorBatch(model, ps, num_control_samples=N, horizon=H, action_low=lo, action_high=hi, seed=4,
+                                   steps_before_giving_up_on_waypoint=2)
+        return env, ps, batch, ssc.MpcPolicy(batch, graph=graph)
+
+    out = []
+    for graph in (True, False):
+        env, ps, batch, pol = setup(graph)
+        ring = ssc.EpisodeRing(4096, "cuda") if graph else None
+        chunks = []
+        for c in range(2):
+            ch = env.rollout(K, pol, ring=ring) if graph else env.rollout(K, pol)
+            torch.cuda.synchronize()
+            chunks.append({k: getattr(ch, k).clone() for k in ("obs", "act", "rew", "done", "obs2")})
+        out.append((env, ps, batch, chunks, ring))
+    (eg, pg, bg, cg, ring), (ee, pe, be, ce, _) = out
+    for c in range(2):
+        for key in ("obs", "act", "rew", "done", "obs2"):
+            assert torch.equal(cg[c][key], ce[c][key]), (c, key)
+    assert torch.equal(eg.s0, ee.s0) and torch.equal(eg.s1, ee.s1) and torch.equal(eg.steps, ee.steps)
+    assert torch.equal(eg.ep_ret, ee.ep_ret) and eg.t == ee.t == 2 * K
+    assert torch.equal(pg.cur_idx, pe.cur_idx) and torch.equal(bg.actions_done, be.actions_done)
+    sg, se = eg.stats.cpu().numpy(), ee.stats.cpu().numpy()
+    assert sg[2] == se[2] == 2 * K * P and sg[3] == se[3] and sg[1] == se[1] and abs(sg[0] - se[0]) <= 1e-6 * max(1.0, abs(se[0]))
+    n_done = int(sum(int(ch["done"].sum()) for ch in cg))
+    assert n_done >= P and sg[3] == n_done                                     # the short time limit forces resets
+    (ids, lens, rets), dropped = ring.drain()
+    assert dropped == 0 and len(lens) == n_done and lens.max() <= max_steps
