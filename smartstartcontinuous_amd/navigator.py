@@ -333,8 +333,8 @@ class NavigatorBatch:
         self.actions_done += 1                                                            # :340
         A = mpc_sample_actions(self.P, self.N, self.H, self.low, self.high, self.seed, self.problem_id0, t,
                                device=states.device)
-        s0 = states.float().repeat_interleave(self.N, dim=0)                              # np.tile, :215-217
-        S = self.model.do_forward_sim(s0, A, out=self._S)
+        # every problem's state is the start of its N candidate rows (np.tile, :215-217): s0_rows = P
+        S = self.model.do_forward_sim(states.float().contiguous(), A, out=self._S)
         _, best, _ = mpc_score(self.problems, S)
         action, _ = mpc_select_action(A, S, best, self.P, self.noise_amount, self.seed, self.problem_id0, t,
                                       want_path=False)
