@@ -140,7 +140,7 @@ __device__ __forceinline__ void load_problem(const MpcArgs &a, int p, float *wps
     idx0 = a.cur_idx[p];
     for (int e = threadIdx.x; e < W * a.d; e += blockDim.x) wps[e] = a.wp[(int64_t)off * a.d + e];
     for (int e = threadIdx.x; e < W; e += blockDim.x) lefts[e] = a.left[off + e];
-    if (threadIdx.x < a.d) inv_r[threadIdx.x] = 1.0f / a.radii[p * a.d + threadIdx.x];
+    if ((int)threadIdx.x < a.d) inv_r[threadIdx.x] = 1.0f / a.radii[p * a.d + threadIdx.x];
     __syncthreads();
 }
 
