@@ -165,6 +165,12 @@ class DynamicsModel:
             self._image_stale = False
         return self._image
 
+    def refresh_prepared_image(self):
+        """Re-pack the MFMA weight image if the weights changed since it was written (same buffer, so launches
+        captured in a HIP graph keep reading the right bytes)."""
+        if self._image is not None and self._image_stale and self._mfma_ok:
+            self._mfma_image()
+
     def _resolve(self, precision):
         """SSC_PREC_* for a call.  A network the MFMA kernel does not cover (more than 2 hidden layers, depth >
         512, ...) runs on the fp32 GPU kernels instead when the model's DEFAULT precision asked for MFMA; an

@@ -345,7 +345,13 @@ class VecEnv:
         fb["t"].fill_(self.t)
         fb["k"].zero_()
         fb["plan"].copy_(self.observe())
-        key = (id(nav), self.n, None if chunk is None else chunk.act.data_ptr(), None if ring is None else ring.cursor.data_ptr())
+        # the captured launches bake pointers in: the graph is per (navigator, weight tensors, log chunk, ring);
+        # weights trained IN PLACE keep their graph -- only the packed image of the MFMA path is refreshed
+        model = nav.model
+        key = (id(nav), self.n, None if chunk is None else chunk.act.data_ptr(), None if ring is None else ring.cursor.data_ptr(),
+               model.precision, tuple(w.data_ptr() for w in model.W), tuple(b.data_ptr() for b in model.b),
+               bytes(model.norm))   # the fp32 path takes the statistics by value: baked into the capture
+        model.refresh_prepared_image()
         if key not in cache:
             # warm-up outside the capture (lazy allocations, the weight image, LDS opt-ins) on a side stream, then
             # restore the state it advanced

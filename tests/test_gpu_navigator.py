@@ -550,3 +550,41 @@ def test_mpc_rollout_graph_replay_equals_step_by_step_path(nav, env_name, max_st
     assert n_done >= P and sg[3] == n_done                                     # the short time limit forces resets
     (ids, lens, rets), dropped = ring.drain()
     assert dropped == 0 and len(lens) == n_done and lens.max() <= max_steps
+
+
+def test_mpc_rollout_graph_follows_weight_updates(nav):
+    """The replayed graph reads the CURRENT dynamics model: after train_step (in place) and after set_weights (new
+    tensors) the graph path still equals the step-by-step path."""
+    import smartstartcontinuous_amd as ssc
+    rng = np.random.default_rng(12)
+    P, N, H, K, d = 40, 128, 3, 5, 2
+    Ws, bs = make_mlp(rng, (3, 500, 500, 2))
+    norm = make_norm(rng, d, 1)
+    paths = [np.cumsum(rng.normal(scale=[0.02, 0.004], size=(12, d)), axis=0) + [-0.5, 0.0] for _ in range(P)]
+    X = torch.as_tensor(rng.normal(size=(64, 3)).astype(np.float32), device="cuda")
+    Z = torch.as_tensor(rng.normal(size=(64, 2)).astype(np.float32), device="cuda")
+    Ws2, bs2 = make_mlp(rng, (3, 500, 500, 2))
+
+    def run(graph):
+        env = ssc.VecEnv("MountainCarContinuous-v0", P, seed=2)
+        env.reset()
+        model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=1, precision="bf16_mfma")
+        wps, lefts, radii = [], [], []
+        for pth in paths:
+            stds, means = O.path_deltas_stds_and_means_per_dim(pth)
+            r = O.radii_calc(means, stds, 1, 1, 1) + 1e-3
+            wps.append(pth); radii.append(r); lefts.append(O.distances_left(pth, O.distance_func(r)))
+        batch = nav.NavigatorBatch(model, nav.MpcProblemSet(wps, lefts, radii, [0] * P), num_control_samples=N, horizon=H, seed=6)
+        pol = ssc.MpcPolicy(batch, graph=graph)
+        acts = [env.rollout(K, pol).act.clone()]
+        for _ in range(3):
+            model.train_step(X, Z, torch.arange(64, dtype=torch.int32, device="cuda"), lr=0.05)   # in place
+        acts.append(env.rollout(K, pol).act.clone())
+        model.set_weights(Ws2, bs2)                                                                # new tensors
+        acts.append(env.rollout(K, pol).act.clone())
+        torch.cuda.synchronize()
+        return acts
+    g, e = run(True), run(False)
+    for i in range(3):
+        assert torch.equal(g[i], e[i]), i
+    assert not torch.equal(g[0], g[1]) and not torch.equal(g[1], g[2])
