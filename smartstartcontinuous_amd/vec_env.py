@@ -350,7 +350,8 @@ class VecEnv:
         model = nav.model
         key = (id(nav), self.n, None if chunk is None else chunk.act.data_ptr(), None if ring is None else ring.cursor.data_ptr(),
                model.precision, tuple(w.data_ptr() for w in model.W), tuple(b.data_ptr() for b in model.b),
-               bytes(model.norm))   # the fp32 path takes the statistics by value: baked into the capture
+               bytes(model.norm),   # the fp32 path takes the statistics by value: baked into the capture
+               nav.problems.wp.data_ptr(), nav.problems.cur_idx.data_ptr())
         model.refresh_prepared_image()
         if key not in cache:
             # warm-up outside the capture (lazy allocations, the weight image, LDS opt-ins) on a side stream, then
@@ -371,6 +372,9 @@ class VecEnv:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 nav.fused_step(self, chunk, ring)
+            stale = [k for k in cache if k[0] != "chunk"]
+            for k in stale[:max(0, len(stale) - 7)]:     # plans come and go (one per episode): keep the newest graphs
+                del cache[k]
             cache[key] = g
         g = cache[key]
         for _ in range(K):
