@@ -427,6 +427,49 @@ size_t ssc_mlp_train_workspace_bytes(const ssc_mlp_train_desc *net, int32_t batc
 int ssc_mlp_train_step(const ssc_mlp_train_desc *net, const float *d_X, const float *d_Z, const int32_t *d_idx,
                        int32_t batch, float *d_loss, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Random-rollout data collection -> dynamics-model training set (SURVEY.md section 8a row A17 and the
+ * data format either side of it): CollectSamples.collect_samples / do_rollout
+ * (NN_Dynamics_Model/collect_samples_threaded.py:25-111), generate_training_data_inputs / _outputs
+ * (NN_Dynamics_Model/data_manipulation.py:58-88), the z-score statistics of NND_MB_agent.py:302-319 and
+ * helper_funcs.add_noise (NN_Dynamics_Model/helper_funcs.py:10-17).
+ * ------------------------------------------------------------------------------------- */
+
+/* A "rollout" is one env's FIRST episode segment of the chunk `log` ([K][n] SoA columns written by
+ * ssc_rollout from freshly reset envs): it stops after its first terminal step like do_rollout (:89-93).
+ * d_len [n]  = number of steps of rollout i (first done inclusive, else K);
+ * d_off [n+1] = exclusive prefix sum of max(d_len - 1, 0): the first data-set row of rollout i, d_off[n] the
+ * total -- every rollout loses its last entry (data_manipulation.py:66-74). */
+size_t ssc_dataset_scan_workspace_bytes(int64_t n);
+int ssc_dataset_scan(const ssc_transition_log *log, int32_t K, int64_t n, int32_t *d_len, int64_t *d_off,
+                     void *d_workspace, size_t workspace_bytes, ssc_stream_t stream);
+
+/* Row-major data set, rollout after rollout like np.concatenate over the list of rollouts (:77-78, :87):
+ * d_X [rows][obs_dim] = s_i, d_Y [rows][1] = a_i, d_Z [rows][obs_dim] = s_{i+1} - s_i (fp32 subtraction).
+ * Rows >= capacity_rows are not written; n * (K - 1) rows always suffice. */
+int ssc_dataset_build(const ssc_transition_log *log, int32_t obs_dim, int32_t K, int64_t n, const int32_t *d_len,
+                      const int64_t *d_off, int64_t capacity_rows, float *d_X, float *d_Y, float *d_Z,
+                      ssc_stream_t stream);
+
+/* mean_c = mean(x[:, c]); std_c = sqrt(mean((x[:, c] - mean_c)^2)) (NND_MB_agent.py:302-304: np.mean, then
+ * np.std of the centred column), accumulated in f64 in a fixed order (bit-reproducible).  rows >= 1,
+ * cols <= 64. */
+size_t ssc_column_stats_workspace_bytes(int32_t cols);
+int ssc_column_stats(const float *d_x, int64_t rows, int32_t cols, double *d_mean, double *d_std, void *d_workspace,
+                     size_t workspace_bytes, ssc_stream_t stream);
+
+/* d_out[r][out_col0 + c] = np.nan_to_num((x[r][c] - mean_c) / std_c) (NND_MB_agent.py:305,310,315), evaluated
+ * in f64 and rounded to fp32; d_out has out_stride columns -- so dataX and dataY land side by side in the
+ * network-input matrix of :318 (np.concatenate((dataX, dataY), axis=1)). */
+int ssc_zscore(const float *d_x, int64_t rows, int32_t cols, const double *d_mean, const double *d_std, float *d_out,
+               int32_t out_stride, int32_t out_col0, ssc_stream_t stream);
+
+/* helper_funcs.add_noise: x[r][c] += N(0, |mean_c * noise_to_signal|) in the columns where
+ * mean_c * noise_to_signal > 0 (only those, :14).  Gaussian = Box-Muller of
+ * Philox(seed; r, stream_id << 8 | c, TAG_DATA_NOISE = 6) words (x, y); oracle: add_noise_keyed. */
+int ssc_add_noise(float *d_x, int64_t rows, int32_t cols, const double *d_mean, double noise_to_signal, uint64_t seed,
+                  uint64_t stream_id, ssc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

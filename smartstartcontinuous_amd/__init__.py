@@ -13,3 +13,5 @@ from .vec_env import (ActorPolicy, Continuous_MountainCarEnv_Editted, EpisodeRin
 from .rl_train import Episode, Summary, rlTrain, rl_train_vec, rl_train_vec_ddpg  # noqa: F401,E402
 from .replay_buffer import DeviceReplayBuffer, ReplayBuffer  # noqa: F401,E402
 from .smartstart import SmartStartContinuous  # noqa: F401,E402
+from .collect_samples import (CollectSamples, Policy_Random, TrainingSet, dataset_from_chunk,  # noqa: F401,E402
+                              generate_training_data_inputs, generate_training_data_outputs, perform_rollouts)

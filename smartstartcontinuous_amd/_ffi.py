@@ -152,6 +152,15 @@ _SIGNATURES = {
                                   c_void_p]),
     "ssc_replay_sample": (c_int, [c_uint64, c_uint64, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ssc_ddpg_train": (c_int, [POINTER(DdpgDesc), POINTER(ReplayView), c_void_p, c_int32, c_void_p, c_void_p]),
+    "ssc_dataset_scan_workspace_bytes": (c_size_t, [c_int64]),
+    "ssc_dataset_scan": (c_int, [POINTER(TransitionLog), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
+                                 c_void_p]),
+    "ssc_dataset_build": (c_int, [POINTER(TransitionLog), c_int32, c_int32, c_int64, c_void_p, c_void_p, c_int64,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ssc_column_stats_workspace_bytes": (c_size_t, [c_int32]),
+    "ssc_column_stats": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ssc_zscore": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "ssc_add_noise": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_double, c_uint64, c_uint64, c_void_p]),
     "ssc_mlp_train_workspace_bytes": (c_size_t, [POINTER(MlpTrainDesc), c_int32]),
     "ssc_mlp_train_step": (c_int, [POINTER(MlpTrainDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                    c_size_t, c_void_p]),

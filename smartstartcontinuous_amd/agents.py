@@ -389,6 +389,8 @@ class NND_MB_agent(NavigationRLAgent):
                  num_fc_layers=1, depth_fc_layers=500,
                  training_data=None, weights=None, biases=None, norm=None,
                  make_aggregated_dataset_noisy=True, nEpochs=30, fraction_use_new=0.9,
+                 make_training_dataset_noisy=True, num_rollouts_train=25, num_rollouts_val=20,
+                 steps_per_rollout_train=333, steps_per_rollout_val=333,
                  device="cuda", precision="bf16_mfma", seed=1234, per_row_projection=False, **unused):
         self.env = env
         self.device = torch.device(device)
@@ -409,9 +411,11 @@ class NND_MB_agent(NavigationRLAgent):
         state_dim = env.observation_space.shape[0]
         act_dim = env.action_space.shape[0]
         self._train_inputs = self._train_outputs = None
-        if norm is None:
-            if training_data is None:
-                raise ValueError("NND_MB_agent needs `training_data` (dataX, dataY, dataZ) or `norm` statistics")
+        self.states_val = self.controls_val = None
+        if norm is None and training_data is None:
+            norm = self._collect_training_data(num_rollouts_train, steps_per_rollout_train, num_rollouts_val,
+                                               steps_per_rollout_val, make_training_dataset_noisy)
+        elif norm is None:
             norm = self.normalisation_from_data(training_data["dataX"], training_data["dataY"], training_data["dataZ"])
         if training_data is not None:
             # z-scored (x, y) -> z training set (NND_MB_agent.py:302-319)
@@ -429,6 +433,33 @@ class NND_MB_agent(NavigationRLAgent):
         self.desired_states = None
         self.radii = None                   # NND_MB_agent.py:168
         self.param_dict = None
+
+    def _collect_training_data(self, num_rollouts_train, steps_per_rollout_train, num_rollouts_val,
+                               steps_per_rollout_val, make_training_dataset_noisy):
+        """The constructor's data-collection branch (NND_MB_agent.py:215-319) with everything resident in HBM:
+        random-policy rollouts (one fused launch), (s, a, s' - s) formatting, optional ``add_noise`` on states and
+        deltas (:263-266), column statistics and z-scoring.  Leaves ``dataX / dataY / dataZ`` (raw, device),
+        the z-scored training matrices, ``states_val / controls_val`` (host lists like the reference keeps) and
+        returns the ``norm`` dict."""
+        from . import collect_samples as cs
+        collector = cs.CollectSamples(self.env, cs.Policy_Random(self.env), seed=self.seed)
+        train = collector.collect_dataset(num_rollouts_train, steps_per_rollout_train)
+        if len(train) == 0:
+            raise ValueError("the random rollouts produced no training rows")
+        self.states_val, self.controls_val, _, _ = collector.collect_samples(num_rollouts_val, steps_per_rollout_val)
+        if make_training_dataset_noisy:
+            cs.add_noise_device(train.dataX, self.noiseToSignal, self.seed, stream_id=0)
+            cs.add_noise_device(train.dataZ, self.noiseToSignal, self.seed, stream_id=1)
+        self.dataX, self.dataY, self.dataZ = train.dataX, train.dataY, train.dataZ
+        (mx, sx), (my, sy), (mz, sz) = (cs.column_stats(v) for v in (train.dataX, train.dataY, train.dataZ))
+        d, a = train.dataX.shape[1], train.dataY.shape[1]
+        inputs = torch.empty((len(train), d + a), dtype=torch.float32, device=train.dataX.device)
+        cs.zscore_into(train.dataX, mx, sx, inputs, 0)                   # :318 np.concatenate((dataX, dataY), axis=1)
+        cs.zscore_into(train.dataY, my, sy, inputs, d)
+        self._train_inputs = inputs
+        self._train_outputs = cs.zscore_into(train.dataZ, mz, sz, torch.empty_like(train.dataZ), 0)
+        host = lambda t: t.cpu().numpy()
+        return dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz))
 
     @staticmethod
     def normalisation_from_data(dataX, dataY, dataZ):

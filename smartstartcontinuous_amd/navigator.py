@@ -120,7 +120,10 @@ class DynamicsModel:
         uploaded once; only index vectors travel per iteration.  Returns the mean training loss of the
         last epoch, like the reference's first return value."""
         rng = rng if rng is not None else np.random
-        f = lambda a, cols: torch.as_tensor(np.asarray(a, np.float32).reshape(-1, cols), device=self.device)
+        def f(a, cols):       # device tensors (collect_samples.TrainingSet) stay where they are
+            if torch.is_tensor(a):
+                return a.to(device=self.device, dtype=torch.float32).reshape(-1, cols)
+            return torch.as_tensor(np.asarray(a, np.float32).reshape(-1, cols), device=self.device)
         n_old, n_new = len(dataX), len(dataX_new)
         X = torch.cat([f(dataX, self.in_dim), f(dataX_new, self.in_dim)])
         Z = torch.cat([f(dataZ, self.out_dim), f(dataZ_new, self.out_dim)])

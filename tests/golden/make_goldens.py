@@ -17,6 +17,12 @@ What is extracted:
      its functions on seeded inputs, including the batched-projection quirk and an MPC
      scoring loop assembled from the reference's own helper functions.
 
+  4. replay_buffer_kats.npz / reference_summary.json -- traces of the reference's ReplayBuffer and one of its
+     Summary dumps.
+  5. data_manipulation_kats.npz -- ragged rollout lists pushed through the reference's
+     generate_training_data_inputs / generate_training_data_outputs
+     (smartstart/RLContinuousAlgorithms/NN_Dynamics_Model/data_manipulation.py:58-88, imported by path).
+
 No reference source text is copied; only numeric inputs/outputs are stored.
 """
 import glob
@@ -233,11 +239,41 @@ def summary_json_fixture():
     print("summary fixture:", os.path.relpath(f, REF), sorted(d.keys()))
 
 
+def data_manipulation_kats():
+    """Rollout lists -> (dataX, dataY, dataZ) through the reference's own functions.  Case 0: seeded ragged
+    rollouts (lengths 1 and 2 included: they contribute 0 and 1 rows); case 1: the reference's recorded
+    validation rollouts, truncated to ragged lengths."""
+    dm = load_by_path("ref_data_manipulation",
+                      "smartstart/RLContinuousAlgorithms/NN_Dynamics_Model/data_manipulation.py")
+    rng = np.random.default_rng(4242)
+    out = {}
+    lens0 = [5, 1, 2, 64, 65, 129, 333, 3]
+    states0 = [rng.normal(size=(L, 3)) for L in lens0]
+    controls0 = [rng.uniform(-2, 2, size=(L, 1)) for L in lens0]
+    d = os.path.join(REF, "models/NND_MB_agent/default/training_data")
+    sv, cv = np.load(os.path.join(d, "states_val.npy")), np.load(os.path.join(d, "controls_val.npy"))
+    lens1 = [int(x) for x in rng.integers(2, sv.shape[1] + 1, size=sv.shape[0])]
+    states1 = [sv[i, :L] for i, L in enumerate(lens1)]
+    controls1 = [cv[i, :L] for i, L in enumerate(lens1)]
+    for tag, lens, st, ct in ((0, lens0, states0, controls0), (1, lens1, states1, controls1)):
+        # the reference np.copy()s the ragged list, which numpy 1.15 (its pin) turns into an object array and
+        # numpy 2 refuses -- hand it that object array directly
+        ragged = lambda lst: np.array(lst + [None], dtype=object)[:-1]
+        X, Y = dm.generate_training_data_inputs(ragged(st), ragged(ct))
+        Z = dm.generate_training_data_outputs(st)
+        out[f"c{tag}_lens"] = np.asarray(lens, np.int64)
+        out[f"c{tag}_states"] = np.concatenate(st, axis=0)
+        out[f"c{tag}_controls"] = np.concatenate(ct, axis=0)
+        out[f"c{tag}_dataX"], out[f"c{tag}_dataY"], out[f"c{tag}_dataZ"] = X, Y, Z
+    np.savez_compressed(os.path.join(OUT, "data_manipulation_kats.npz"), **out)
+    print("data_manipulation kats:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not found at %s" % REF)
-    rollouts()
-    summaries()
-    numerical_kats()
-    replay_buffer_kats()
-    summary_json_fixture()
+    jobs = dict(rollouts=rollouts, summaries=summaries, numerical_kats=numerical_kats,
+                replay_buffer_kats=replay_buffer_kats, summary_json_fixture=summary_json_fixture,
+                data_manipulation_kats=data_manipulation_kats)
+    for name in (sys.argv[1:] or list(jobs)):       # `make_goldens.py data_manipulation_kats` regenerates one file
+        jobs[name]()

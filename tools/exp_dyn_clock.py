@@ -38,3 +38,6 @@ t0 = entry.min()
 print("realtime (us): kernel span first entry -> last exit %.1f; block entry stagger median %.1f max %.1f; entry -> step loop median %.1f max %.1f; step loop median %.1f max %.1f; last exit - median exit %.1f"
       % ((exit_.max() - t0) / 100.0, np.median(entry - t0) / 100.0, (entry - t0).max() / 100.0, np.median(loop0 - entry) / 100.0, (loop0 - entry).max() / 100.0,
          np.median(exit_ - loop0) / 100.0, (exit_ - loop0).max() / 100.0, (exit_.max() - np.median(exit_)) / 100.0))
+bad = np.where(~ok)[0]
+if len(bad):
+    print("blocks with implausible stamps:", bad[:16].tolist(), "raw:", [hex(int(x)) for x in v[bad[0], 0]])
