@@ -423,7 +423,14 @@ typedef struct ssc_mlp_train_desc {
 } ssc_mlp_train_desc;
 
 size_t ssc_mlp_train_workspace_bytes(const ssc_mlp_train_desc *net, int32_t batch);
-/* d_loss [1] receives the batch MSE (before the update); may be NULL. */
+/* n_steps consecutive iterations enqueued by one call: step k trains on rows d_idx[k*batch .. (k+1)*batch) and
+ * writes its batch MSE (before the update) to d_loss[k] (d_loss may be NULL).  One hidden layer of <= 512 units
+ * (in <= 12, out <= 8 -- the shapes the reference ships) runs ONE fused launch per step; other shapes run the
+ * generic chain of per-layer launches. */
+int ssc_mlp_train_steps(const ssc_mlp_train_desc *net, const float *d_X, const float *d_Z, const int32_t *d_idx,
+                        int32_t batch, int32_t n_steps, float *d_loss, void *d_workspace, size_t workspace_bytes,
+                        ssc_stream_t stream);
+/* = ssc_mlp_train_steps with n_steps = 1. */
 int ssc_mlp_train_step(const ssc_mlp_train_desc *net, const float *d_X, const float *d_Z, const int32_t *d_idx,
                        int32_t batch, float *d_loss, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream);
 

@@ -1,11 +1,19 @@
 // dyn_train.hip -- one Adam step of the NND_MB dynamics model on a mini-batch
 // (NN_Dynamics_Model/dynamics_model.py:41-50, 98-113) for ANY feedforward_network shape.
 //
-// fp32 throughout (the reference trains in fp64 on the CPU; parity tolerance in the tests).  The step is
-// a chain of small launches over the batch (512 rows in the shipped runs): gather -> forward layers
-// (reusing the fp32 layer kernel of dyn_model.hip) -> output delta -> per layer {dW, db, dX, ReLU mask,
-// Adam}.  The bias-corrected step size is computed on the device from a device-side step counter, so
-// consecutive steps can be enqueued without a host round trip.
+// fp32 throughout (the reference trains in fp64 on the CPU; parity tolerance in the tests).
+//
+// Two paths behind ssc_mlp_train_steps:
+//   * mlp_train_fused_kernel -- ONE launch per step for the shapes the reference ships (one hidden layer of
+//     <= 512 units: 1x32 in the examples, 1x500 the class default).  Block b owns 32 batch rows: gather, forward,
+//     output delta, back-propagation and its share of every gradient, all in LDS/registers; the block that
+//     finishes last (atomic ticket) sums the per-block gradients in block order and applies Adam.
+//   * the generic chain of small launches for any other feedforward_network shape: gather -> forward layers
+//     (the fp32 layer kernel of dyn_model.hip) -> output delta -> per layer {dW, db, dX, ReLU mask, Adam}.
+// The bias-corrected step size comes from a device-side step counter, so any number of consecutive steps is
+// enqueued by one call without a host round trip.
+#include <stdlib.h>
+
 #include "ssc_device.h"
 #include "ssc_host.h"
 
@@ -95,6 +103,283 @@ __global__ __launch_bounds__(256) void train_back_kernel(int B, int K, int N, co
 
 __global__ void train_loss_out_kernel(const float *scal, float *loss) { loss[0] = scal[1]; }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused step for one hidden layer:  y = relu(x W1 + b1) W2 + b2.
+constexpr int kFT = 512;      // threads per block
+constexpr int kFRows = 32;    // batch rows per block
+
+// tf.train.AdamOptimizer's bias-corrected step size lr * sqrt(1 - beta2^t) / (1 - beta1^t): the powers are
+// computed once per call (pow) and advanced by one multiplication per step
+struct FusedStepState {
+    double pw1, pw2;     // beta1^t, beta2^t for the COMING step t
+    float lr_t;
+};
+
+struct FusedTrainArgs {
+    const float *X, *Z;
+    const int32_t *idx;
+    int B, in, hd, out, hd_pad, hd_shift, S, G;
+    float *W1, *b1, *W2, *b2;
+    float *mW1, *vW1, *mb1, *vb1, *mW2, *vW2, *mb2, *vb2;
+    int32_t *adam_t;
+    float lr, beta1, beta2, eps;
+    float *partial;      // [G][P + 1]: per-block gradients in flat parameter order (W1 | b1 | W2 | b2), then sum (y-z)^2
+    uint32_t *ticket;    // [1], zero before the first launch; the last block leaves it zero again
+    FusedStepState *state;   // beta powers and the step size of the coming step (fused_begin_kernel)
+    float *loss;         // [1] or NULL
+};
+
+static inline size_t fused_lds_floats(int hd_pad, int S, int IN, int OUT) {
+    return (size_t)kFRows * (hd_pad + 1) + (size_t)hd_pad * OUT + (size_t)kFRows * IN + 2 * (size_t)kFRows * OUT +
+           (S > 1 ? (size_t)kFT * (IN + 1 + OUT) : 0) + kFRows + 8;
+}
+
+template <int IN, int OUT>
+__global__ __launch_bounds__(kFT) void mlp_train_fused_kernel(FusedTrainArgs g) {
+    extern __shared__ float lds[];
+    float *h_s = lds;                                   // [32][hd_pad + 1] hidden activations of the block's rows
+    float *w2_s = h_s + kFRows * (g.hd_pad + 1);        // [hd_pad][OUT]
+    float *x_s = w2_s + g.hd_pad * OUT;                 // [32][IN]
+    float *z_s = x_s + kFRows * IN;                     // [32][OUT]
+    float *dy_s = z_s + kFRows * OUT;                   // [32][OUT]
+    float *sc_s = dy_s + kFRows * OUT;                  // [IN + 1 + OUT][kFT] per-thread gradient partials (S > 1)
+    float *loss_s = sc_s + (g.S > 1 ? kFT * (IN + 1 + OUT) : 0);   // [32]
+    float *misc_s = loss_s + kFRows;                    // [0] last-block flag, [1] lr_t
+    const int t = threadIdx.x;
+    const int u = t & (g.hd_pad - 1), s = t >> g.hd_shift;          // hidden unit, row sub-slice
+    const bool unit_ok = u < g.hd;
+    const int row0 = blockIdx.x * kFRows;
+    const int nrows = g.B - row0 < kFRows ? g.B - row0 : kFRows;
+    const int hp = g.hd_pad + 1;
+
+    // this thread's unit: column u of W1, b1[u], row u of W2 (registers)
+    float w1[IN], w2[OUT], bb1 = unit_ok ? g.b1[u] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < IN; ++i) w1[i] = (unit_ok && i < g.in) ? g.W1[i * g.hd + u] : 0.0f;
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) w2[o] = (unit_ok && o < g.out) ? g.W2[u * g.out + o] : 0.0f;
+    if (s == 0) {
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) w2_s[u * OUT + o] = w2[o];
+    }
+    // batch rows of this block (train_gather_kernel's job)
+    if (t < kFRows) {
+        const bool live = t < nrows;
+        const int64_t src = live ? g.idx[row0 + t] : 0;
+#pragma unroll
+        for (int i = 0; i < IN; ++i) x_s[t * IN + i] = (live && i < g.in) ? g.X[src * g.in + i] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) z_s[t * OUT + o] = (live && o < g.out) ? g.Z[src * g.out + o] : 0.0f;
+    }
+    __syncthreads();
+
+    // pass 1: h[r][u] = relu(x[r] . W1[:, u] + b1[u])        (feedforward_network.py:14-19)
+#pragma unroll 4
+    for (int r = s; r < kFRows; r += g.S) {
+        float h = bb1;
+#pragma unroll
+        for (int i = 0; i < IN; ++i) h = fmaf(x_s[r * IN + i], w1[i], h);
+        h_s[r * hp + u] = (unit_ok && r < nrows) ? fmaxf(h, 0.0f) : 0.0f;
+    }
+    __syncthreads();
+
+    // pass 2: y[r][o] = h[r] . W2[:, o] + b2[o]; 16 lanes share a row, lane c takes units c, c + 16, ...
+    {
+        const int r2 = t >> 4, c = t & 15;
+        float acc[OUT];
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) acc[o] = 0.0f;
+        for (int uu = c; uu < g.hd_pad; uu += 16) {
+            const float hv = h_s[r2 * hp + uu];
+#pragma unroll
+            for (int o = 0; o < OUT; ++o) acc[o] = fmaf(hv, w2_s[uu * OUT + o], acc[o]);
+        }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1)
+#pragma unroll
+            for (int o = 0; o < OUT; ++o) acc[o] += __shfl_xor(acc[o], m);
+        if (c == 0) {
+            float lp = 0.0f;
+            const float scale = 2.0f / (float)(g.B * g.out);       // d mean((z - y)^2) / dy   (dynamics_model.py:41)
+#pragma unroll
+            for (int o = 0; o < OUT; ++o) {
+                const bool valid = r2 < nrows && o < g.out;
+                const float d = valid ? acc[o] + g.b2[o] - z_s[r2 * OUT + o] : 0.0f;
+                dy_s[r2 * OUT + o] = d * scale;
+                lp = fmaf(d, d, lp);
+            }
+            loss_s[r2] = lp;
+        }
+    }
+    __syncthreads();
+
+    // pass 3: gradients of this thread's unit over its rows
+    float g1[IN], g2[OUT], gb1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < IN; ++i) g1[i] = 0.0f;
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) g2[o] = 0.0f;
+#pragma unroll 4
+    for (int r = s; r < kFRows; r += g.S) {
+        const float hv = h_s[r * hp + u];
+        float dh = 0.0f;
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) {
+            const float dyo = dy_s[r * OUT + o];
+            g2[o] = fmaf(hv, dyo, g2[o]);
+            dh = fmaf(dyo, w2[o], dh);
+        }
+        dh = hv > 0.0f ? dh : 0.0f;                                // ReLU mask
+#pragma unroll
+        for (int i = 0; i < IN; ++i) g1[i] = fmaf(x_s[r * IN + i], dh, g1[i]);
+        gb1 += dh;
+    }
+    if (g.S > 1) {       // sum the S row sub-slices of a unit in a fixed order
+#pragma unroll
+        for (int i = 0; i < IN; ++i) sc_s[i * kFT + t] = g1[i];
+        sc_s[IN * kFT + t] = gb1;
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) sc_s[(IN + 1 + o) * kFT + t] = g2[o];
+        __syncthreads();
+        if (s == 0) {
+            for (int ss = 1; ss < g.S; ++ss) {
+                const int tt = u + (ss << g.hd_shift);
+#pragma unroll
+                for (int i = 0; i < IN; ++i) g1[i] += sc_s[i * kFT + tt];
+                gb1 += sc_s[IN * kFT + tt];
+#pragma unroll
+                for (int o = 0; o < OUT; ++o) g2[o] += sc_s[(IN + 1 + o) * kFT + tt];
+            }
+        }
+    }
+    // block partials -> global, flat parameter order
+    const int oB1 = g.in * g.hd, oW2 = oB1 + g.hd, oB2 = oW2 + g.hd * g.out, P = oB2 + g.out;
+    float *mine = g.partial + (size_t)blockIdx.x * (P + 1);
+    // Agent-scope (write-through) stores, waited for before the ticket, and agent-scope loads in the last block: the
+    // partials cross XCDs without an L2 write-back / invalidate (a full __threadfence costs more than the step).
+    auto put = [&](int p, float v) { __hip_atomic_store(mine + p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (s == 0 && unit_ok) {
+#pragma unroll
+        for (int i = 0; i < IN; ++i)
+            if (i < g.in) put(i * g.hd + u, g1[i]);
+        put(oB1 + u, gb1);
+#pragma unroll
+        for (int o = 0; o < OUT; ++o)
+            if (o < g.out) put(oW2 + u * g.out + o, g2[o]);
+    }
+    if (t < g.out) {     // b2 gradient: sum of dy over the block's rows
+        float a = 0.0f;
+        for (int r = 0; r < kFRows; ++r) a += dy_s[r * OUT + t];
+        put(oB2 + t, a);
+    }
+    if (t == 0) {
+        float a = 0.0f;
+        for (int r = 0; r < kFRows; ++r) a += loss_s[r];
+        put(P, a);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's partial stores have been acknowledged
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t tk = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = tk == (uint32_t)g.G - 1;
+        misc_s[0] = last ? 1.0f : 0.0f;
+        if (last) {
+            __hip_atomic_store(g.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            misc_s[1] = g.state->lr_t;
+        }
+    }
+    __syncthreads();
+    if (misc_s[0] == 0.0f) return;
+    const float lr_t = misc_s[1];
+    if (t == 0) {        // state of the next step (only this block, only this thread touches it)
+        const double p1 = g.state->pw1 * (double)g.beta1, p2 = g.state->pw2 * (double)g.beta2;
+        g.state->pw1 = p1; g.state->pw2 = p2;
+        g.state->lr_t = (float)((double)g.lr * sqrt(1.0 - p2) / (1.0 - p1));
+        g.adam_t[0] = g.adam_t[0] + 1;
+    }
+    auto get = [&](int b, int p) {
+        return __hip_atomic_load(g.partial + (size_t)b * (P + 1) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // Adam on the summed gradients: 4 parameters per thread and round trip (their 4 x 16 block partials and their
+    // theta / m / v are requested together), blocks summed in block order
+    constexpr int kU = 4;
+    for (int p0 = t; p0 < P; p0 += kU * kFT) {
+        float *th[kU], *m[kU], *v[kU];
+        float th0[kU], m0[kU], v0[kU], gr[kU];
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
+            const int p = p0 + k * kFT;
+            const bool ok = p < P;
+            int q;
+            if (p < oB1) { th[k] = g.W1; m[k] = g.mW1; v[k] = g.vW1; q = p; }
+            else if (p < oW2) { th[k] = g.b1; m[k] = g.mb1; v[k] = g.vb1; q = p - oB1; }
+            else if (p < oB2) { th[k] = g.W2; m[k] = g.mW2; v[k] = g.vW2; q = p - oW2; }
+            else { th[k] = g.b2; m[k] = g.mb2; v[k] = g.vb2; q = ok ? p - oB2 : 0; }
+            th[k] += q; m[k] += q; v[k] += q;
+            th0[k] = ok ? *th[k] : 0.0f; m0[k] = ok ? *m[k] : 0.0f; v0[k] = ok ? *v[k] : 0.0f;
+            gr[k] = 0.0f;
+        }
+        for (int b0 = 0; b0 < g.G; b0 += 16) {
+            float pv[kU][16];
+#pragma unroll
+            for (int k = 0; k < kU; ++k)
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    pv[k][j] = (b0 + j < g.G && p0 + k * kFT < P) ? get(b0 + j, p0 + k * kFT) : 0.0f;
+#pragma unroll
+            for (int k = 0; k < kU; ++k)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gr[k] += pv[k][j];
+        }
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
+            if (p0 + k * kFT >= P) break;
+            const float mm = g.beta1 * m0[k] + (1.0f - g.beta1) * gr[k];
+            const float vv = g.beta2 * v0[k] + (1.0f - g.beta2) * gr[k] * gr[k];
+            *m[k] = mm; *v[k] = vv;
+            *th[k] = th0[k] - lr_t * mm / (sqrtf(vv) + g.eps);
+        }
+    }
+    if (t == kFT - 1 && g.loss != nullptr) {
+        float a = 0.0f;
+        for (int b = 0; b < g.G; ++b) a += get(b, P);
+        g.loss[0] = a / (float)(g.B * g.out);
+    }
+}
+
+// once per ssc_mlp_train_steps call: ticket = 0, beta powers and step size of the first step of the call
+__global__ void fused_begin_kernel(const int32_t *adam_t, float lr, float b1, float b2, uint32_t *ticket, FusedStepState *st) {
+    const int tt = adam_t[0] + 1;
+    const double p1 = pow((double)b1, (double)tt), p2 = pow((double)b2, (double)tt);
+    st->pw1 = p1; st->pw2 = p2;
+    st->lr_t = (float)((double)lr * sqrt(1.0 - p2) / (1.0 - p1));
+    ticket[0] = 0u;
+}
+
+static bool fused_eligible(const ssc_mlp_train_desc *net) {
+    static const bool off = getenv("SSC_DYN_TRAIN_GENERIC") != nullptr;    // A/B switch for the tests and tools
+    return !off && net->n_layers == 2 && net->dims[0] <= 12 && net->dims[1] <= 512 && net->dims[2] <= 8;
+}
+
+static int fused_param_count(const ssc_mlp_train_desc *net) {
+    return net->dims[0] * net->dims[1] + net->dims[1] + net->dims[1] * net->dims[2] + net->dims[2];
+}
+
+template <int IN, int OUT>
+static int launch_fused(const FusedTrainArgs &g, hipStream_t s) {
+    const size_t lds_bytes = fused_lds_floats(g.hd_pad, g.S, IN, OUT) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_train_fused_kernel<IN, OUT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                               "hipFuncSetAttribute(mlp_train_fused_kernel)"))
+            return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_train_fused_kernel<IN, OUT>), dim3(g.G), dim3(kFT), lds_bytes, s, g);
+    return SSC_OK;
+}
+
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace ssc
@@ -111,23 +396,16 @@ size_t ssc_mlp_train_workspace_bytes(const ssc_mlp_train_desc *net, int32_t B) {
     for (int l = 0; l <= net->n_layers; ++l) maxw = net->dims[l] > maxw ? net->dims[l] : maxw;
     total += al256((size_t)B * net->dims[net->n_layers] * 4);  // z batch
     total += 2 * al256((size_t)B * maxw * 4);                  // delta ping-pong
+    if (net->n_layers == 2) {                                  // fused path: ticket + per-block gradients
+        const size_t G = ((size_t)B + kFRows - 1) / kFRows;
+        const size_t fused = 256 + al256(G * ((size_t)fused_param_count(net) + 1) * 4);
+        total = fused > total ? fused : total;
+    }
     return total;
 }
 
-int ssc_mlp_train_step(const ssc_mlp_train_desc *net, const float *d_X, const float *d_Z, const int32_t *d_idx,
-                       int32_t B, float *d_loss, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream) {
-    SSC_REQUIRE(net != nullptr, "ssc_mlp_train_step: net NULL");
-    SSC_REQUIRE(net->n_layers >= 1 && net->n_layers <= SSC_MAX_LAYERS, "ssc_mlp_train_step: bad n_layers");
-    SSC_REQUIRE(B >= 1 && B <= 65536, "ssc_mlp_train_step: batch %d out of range", B);
-    for (int l = 0; l <= net->n_layers; ++l)
-        SSC_REQUIRE(net->dims[l] >= 1 && net->dims[l] <= 8192, "ssc_mlp_train_step: bad dims[%d]", l);
-    for (int l = 0; l < net->n_layers; ++l)
-        SSC_REQUIRE(net->W[l] && net->b[l] && net->mW[l] && net->vW[l] && net->mb[l] && net->vb[l],
-                    "ssc_mlp_train_step: NULL parameter / moment pointer (layer %d)", l);
-    SSC_REQUIRE(net->adam_t && d_X && d_Z && d_idx, "ssc_mlp_train_step: NULL pointer");
-    const size_t need = ssc_mlp_train_workspace_bytes(net, B);
-    SSC_REQUIRE(d_workspace && workspace_bytes >= need, "ssc_mlp_train_step: workspace %zu < %zu", workspace_bytes, need);
-    hipStream_t s = as_stream(stream);
+static int generic_step(const ssc_mlp_train_desc *net, const float *d_X, const float *d_Z, const int32_t *d_idx, int32_t B,
+                        float *d_loss, void *d_workspace, hipStream_t s) {
     const int L = net->n_layers;
     char *w = static_cast<char *>(d_workspace);
     float *scal = reinterpret_cast<float *>(w); w += 256;
@@ -158,7 +436,63 @@ int ssc_mlp_train_step(const ssc_mlp_train_desc *net, const float *d_X, const fl
         float *t = dz; dz = dprev; dprev = t;
     }
     if (d_loss != nullptr) hipLaunchKernelGGL(train_loss_out_kernel, dim3(1), dim3(1), 0, s, scal, d_loss);
-    return check_launch("ssc_mlp_train_step");
+    return SSC_OK;
+}
+
+int ssc_mlp_train_steps(const ssc_mlp_train_desc *net, const float *d_X, const float *d_Z, const int32_t *d_idx,
+                        int32_t B, int32_t n_steps, float *d_loss, void *d_workspace, size_t workspace_bytes,
+                        ssc_stream_t stream) {
+    SSC_REQUIRE(net != nullptr, "ssc_mlp_train_steps: net NULL");
+    SSC_REQUIRE(net->n_layers >= 1 && net->n_layers <= SSC_MAX_LAYERS, "ssc_mlp_train_steps: bad n_layers");
+    SSC_REQUIRE(B >= 1 && B <= 65536, "ssc_mlp_train_steps: batch %d out of range", B);
+    SSC_REQUIRE(n_steps >= 0, "ssc_mlp_train_steps: n_steps %d < 0", n_steps);
+    for (int l = 0; l <= net->n_layers; ++l)
+        SSC_REQUIRE(net->dims[l] >= 1 && net->dims[l] <= 8192, "ssc_mlp_train_steps: bad dims[%d]", l);
+    for (int l = 0; l < net->n_layers; ++l)
+        SSC_REQUIRE(net->W[l] && net->b[l] && net->mW[l] && net->vW[l] && net->mb[l] && net->vb[l],
+                    "ssc_mlp_train_steps: NULL parameter / moment pointer (layer %d)", l);
+    if (n_steps == 0) return SSC_OK;
+    SSC_REQUIRE(net->adam_t && d_X && d_Z && d_idx, "ssc_mlp_train_steps: NULL pointer");
+    const size_t need = ssc_mlp_train_workspace_bytes(net, B);
+    SSC_REQUIRE(d_workspace && workspace_bytes >= need, "ssc_mlp_train_steps: workspace %zu < %zu", workspace_bytes, need);
+    hipStream_t s = as_stream(stream);
+    if (!fused_eligible(net)) {
+        for (int k = 0; k < n_steps; ++k)
+            if (int rc = generic_step(net, d_X, d_Z, d_idx + (size_t)k * B, B, d_loss ? d_loss + k : nullptr, d_workspace, s))
+                return rc;
+        return check_launch("ssc_mlp_train_steps");
+    }
+    FusedTrainArgs g;
+    g.X = d_X; g.Z = d_Z; g.B = B;
+    g.in = net->dims[0]; g.hd = net->dims[1]; g.out = net->dims[2];
+    g.hd_pad = 16; g.hd_shift = 4;
+    while (g.hd_pad < g.hd) { g.hd_pad <<= 1; ++g.hd_shift; }
+    g.S = kFT / g.hd_pad;
+    g.G = (B + kFRows - 1) / kFRows;
+    g.W1 = net->W[0]; g.b1 = net->b[0]; g.W2 = net->W[1]; g.b2 = net->b[1];
+    g.mW1 = net->mW[0]; g.vW1 = net->vW[0]; g.mb1 = net->mb[0]; g.vb1 = net->vb[0];
+    g.mW2 = net->mW[1]; g.vW2 = net->vW[1]; g.mb2 = net->mb[1]; g.vb2 = net->vb[1];
+    g.adam_t = net->adam_t; g.lr = net->lr; g.beta1 = net->beta1; g.beta2 = net->beta2; g.eps = net->epsilon;
+    g.ticket = static_cast<uint32_t *>(d_workspace);
+    g.state = reinterpret_cast<FusedStepState *>(static_cast<char *>(d_workspace) + 64);
+    g.partial = reinterpret_cast<float *>(static_cast<char *>(d_workspace) + 256);
+    hipLaunchKernelGGL(fused_begin_kernel, dim3(1), dim3(1), 0, s, net->adam_t, net->lr, net->beta1, net->beta2, g.ticket,
+                       g.state);
+    for (int k = 0; k < n_steps; ++k) {
+        g.idx = d_idx + (size_t)k * B;
+        g.loss = d_loss ? d_loss + k : nullptr;
+        int rc;
+        if (g.in <= 3 && g.out <= 2) rc = launch_fused<3, 2>(g, s);
+        else if (g.in <= 4 && g.out <= 3) rc = launch_fused<4, 3>(g, s);
+        else rc = launch_fused<12, 8>(g, s);
+        if (rc) return rc;
+    }
+    return check_launch("ssc_mlp_train_steps");
+}
+
+int ssc_mlp_train_step(const ssc_mlp_train_desc *net, const float *d_X, const float *d_Z, const int32_t *d_idx,
+                       int32_t B, float *d_loss, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream) {
+    return ssc_mlp_train_steps(net, d_X, d_Z, d_idx, B, 1, d_loss, d_workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

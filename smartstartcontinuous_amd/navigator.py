@@ -113,6 +113,20 @@ class DynamicsModel:
                                                    _ffi.ptr(loss), _ffi.ptr(ws), ws.numel(), _stream()))
         self.invalidate()
 
+    def train_steps(self, X, Z, idx, lr=0.001):
+        """``idx.shape[0]`` consecutive Adam steps, step k on rows ``idx[k]`` (int32 [n_steps, B] on the device);
+        returns the per-step batch MSEs as a device tensor.  One C call, no host synchronisation."""
+        d = self._train_desc(lr)
+        n_steps, B = idx.shape
+        idx = idx.contiguous()
+        losses = torch.empty(n_steps, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.ssc_mlp_train_workspace_bytes(ctypes.byref(d), B))
+            _ffi.check(self.lib.ssc_mlp_train_steps(ctypes.byref(d), _ffi.ptr(X), _ffi.ptr(Z), _ffi.ptr(idx), B, n_steps,
+                                                    _ffi.ptr(losses), _ffi.ptr(ws), ws.numel(), _stream()))
+        self.invalidate()
+        return losses
+
     def train(self, dataX, dataZ, dataX_new, dataZ_new, nEpoch, fraction_use_new, batchsize=512, lr=0.001,
               rng=None):
         """``Dyn_Model.train`` (dynamics_model.py:52-171): every batch mixes ``batchsize*fraction_use_new``
@@ -130,10 +144,8 @@ class DynamicsModel:
         b_new = n_new if n_new < batchsize * fraction_use_new else int(batchsize * fraction_use_new)   # :60-67
         b_old = int(batchsize - b_new)
         perm_new = np.arange(n_new)
-        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-        last = 0.0
+        epoch_losses = []
         for _ in range(nEpoch):
-            losses = []
             old = rng.choice(np.arange(n_old), size=(n_old,), replace=False)                          # :78
             if b_old > 0:
                 batches = []
@@ -143,12 +155,11 @@ class DynamicsModel:
             else:
                 batches = [n_old + perm_new[b * b_new:(b + 1) * b_new] for b in range(int(np.floor(n_new / b_new)))]
                 perm_new = perm_new[rng.permutation(n_new)]                                           # :120-122
-            for bi in batches:
-                idx = torch.as_tensor(bi.astype(np.int32), device=self.device)
-                self.train_step(X, Z, idx, lr=lr, loss=loss)
-                losses.append(loss.clone())
-            last = float(torch.stack(losses).mean().item()) if losses else 0.0
-        return last
+            if batches:       # the epoch's index vectors travel in one copy, its steps are enqueued by one call
+                idx = torch.as_tensor(np.stack(batches).astype(np.int32), device=self.device)
+                epoch_losses.append(self.train_steps(X, Z, idx, lr=lr))
+        # the only device -> host read of the whole training: the mean loss of the last epoch
+        return float(epoch_losses[-1].mean().item()) if epoch_losses else 0.0
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:

@@ -250,9 +250,13 @@ def test_forward_sim_mfma(nav, dims, H):
     assert np.max(np.abs(Sf - S)) <= 3e-2 * np.maximum(1.0, np.abs(Sf).max())
 
 
-@pytest.mark.parametrize("dims,B", [((3, 32, 2), 512), ((4, 500, 500, 3), 512), ((3, 40, 24, 16, 2), 77)])
+@pytest.mark.parametrize("dims,B", [((3, 32, 2), 512), ((4, 500, 500, 3), 512), ((3, 40, 24, 16, 2), 77),
+                                    ((4, 500, 3), 512), ((4, 20, 3), 77), ((9, 100, 5), 100), ((3, 512, 2), 33),
+                                    ((12, 7, 8), 1)])
 def test_mlp_train_step_kernel_vs_oracle(nav, dims, B):
-    """ssc_mlp_train_step (forward, MSE, backprop, tf-style Adam) for several steps against the fp64 oracle."""
+    """ssc_mlp_train_step (forward, MSE, backprop, tf-style Adam) for several steps against the fp64 oracle.
+    One hidden layer runs the fused one-launch kernel (all three instantiations, unit counts on and off the
+    power-of-two padding, batches that do not fill the last 32-row block); the others the generic chain."""
     rng = np.random.default_rng(sum(dims))
     Ws, bs = make_mlp(rng, dims)
     d, a = dims[-1], dims[0] - dims[-1]
@@ -275,6 +279,32 @@ def test_mlp_train_step_kernel_vs_oracle(nav, dims, B):
         assert np.max(np.abs(model.W[l].cpu().numpy() - oW[l])) <= 2e-5, l
         assert np.max(np.abs(model.b[l].cpu().numpy() - ob[l])) <= 2e-5, l
     assert int(model._adam["t"].item()) == 4
+
+
+@pytest.mark.parametrize("dims", [(3, 32, 2), (4, 500, 3), (4, 24, 24, 3)])
+def test_mlp_train_steps_equals_single_steps(nav, dims):
+    """ssc_mlp_train_steps: n consecutive steps enqueued by one call == the same steps one call at a time -- bit for
+    bit on the fused path (fixed summation order), to rounding on the generic chain (its loss is a float atomic)."""
+    rng = np.random.default_rng(7)
+    n, B, steps = 3000, 512, 6
+    X = torch.as_tensor(rng.normal(size=(n, dims[0])).astype(np.float32), device="cuda")
+    Z = torch.as_tensor((rng.normal(size=(n, dims[-1])) * 0.5).astype(np.float32), device="cuda")
+    idx = torch.as_tensor(np.stack([rng.permutation(n)[:B] for _ in range(steps)]).astype(np.int32), device="cuda")
+    d, a = dims[-1], dims[0] - dims[-1]
+    Ws, bs = make_mlp(rng, dims)
+    m1 = nav.DynamicsModel(Ws, bs, make_norm(rng, d, a), state_dim=d, act_dim=a)
+    m2 = nav.DynamicsModel(Ws, bs, make_norm(rng, d, a), state_dim=d, act_dim=a)
+    losses = m1.train_steps(X, Z, idx, lr=1e-3)
+    one = torch.zeros(1, device="cuda")
+    for k in range(steps):
+        m2.train_step(X, Z, idx[k], lr=1e-3, loss=one)
+        if len(dims) == 3:
+            assert one.item() == losses[k].item()
+        else:
+            assert abs(one.item() - losses[k].item()) <= 1e-6 * abs(one.item())
+    for l in range(len(Ws)):
+        assert torch.equal(m1.W[l], m2.W[l]) and torch.equal(m1.b[l], m2.b[l])
+    assert losses[-1].item() < losses[0].item()
 
 
 def test_dynamics_model_training_learns_mountaincar(nav, golden_dir):

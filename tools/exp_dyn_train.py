@@ -20,3 +20,18 @@ for layers, depth in [(1, 32), (1, 500), (2, 500)]:
     dt = time.perf_counter() - t0
     steps = 30 * (n // 512)
     print(json.dumps(dict(layers=layers, depth=depth, seconds=dt, steps=steps, ms_per_step=dt / steps * 1e3, last_loss=loss)), flush=True)
+
+# GPU time per step without the host-side epoch bookkeeping: 2000 steps enqueued by ONE ssc_mlp_train_steps call
+for layers, depth, B in [(1, 32, 512), (1, 500, 512), (1, 500, 64), (2, 500, 512)]:
+    Ws, bs = init_dynamics_weights(3, 2, layers, depth, torch.Generator().manual_seed(1))
+    model = nav.DynamicsModel(Ws, bs, norm, 2, 1, precision="f32")
+    Xd = torch.as_tensor(X, dtype=torch.float32, device="cuda"); Zd = torch.as_tensor(Z, dtype=torch.float32, device="cuda")
+    steps = 2000 if layers == 1 else 200
+    idx = torch.randint(0, n, (steps, B), dtype=torch.int32, device="cuda")
+    model.train_steps(Xd, Zd, idx[:10])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record(); model.train_steps(Xd, Zd, idx); e1.record(); t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print(json.dumps(dict(layers=layers, depth=depth, batch=B, steps=steps, gpu_us_per_step=e0.elapsed_time(e1) / steps * 1e3,
+                          host_enqueue_us_per_step=(t1 - t0) / steps * 1e6)), flush=True)
