@@ -389,6 +389,7 @@ class NND_MB_agent(NavigationRLAgent):
                  num_fc_layers=1, depth_fc_layers=500,
                  training_data=None, weights=None, biases=None, norm=None,
                  make_aggregated_dataset_noisy=True, nEpochs=30, fraction_use_new=0.9,
+                 num_episodes_for_aggregation=3,
                  make_training_dataset_noisy=True, num_rollouts_train=25, num_rollouts_val=20,
                  steps_per_rollout_train=333, steps_per_rollout_val=333,
                  device="cuda", precision="bf16_mfma", seed=1234, per_row_projection=False, **unused):
@@ -404,6 +405,8 @@ class NND_MB_agent(NavigationRLAgent):
         self.steps_before_giving_up_on_waypoint = steps_before_giving_up_on_waypoint
         self.make_aggregated_dataset_noisy = make_aggregated_dataset_noisy   # NND_MB_agent.py:66
         self.nEpochs, self.fraction_use_new = nEpochs, fraction_use_new      # :64, :68
+        self.num_episodes_for_aggregation = num_episodes_for_aggregation     # :65
+        self.num_episodes_finished = 0
         self.theta = 1                      # NND_MB_agent.py:143
         self.noise_amount = 0.005           # :188-191
         self.per_row_projection = per_row_projection
@@ -470,7 +473,9 @@ class NND_MB_agent(NavigationRLAgent):
 
     # ---- planning (host, once per episode) -----------------------------------------------------
     def start_new_episode_plan(self, starting_state, path_to_follow):
-        """NND_MB_agent.py:375-423 (without the dynamics-model retraining trigger :421-423)."""
+        """NND_MB_agent.py:375-423, including the retraining of the dynamics model on the aggregated replay-buffer
+        transitions every ``num_episodes_for_aggregation`` planned episodes (:420-423; the very first plan trains
+        too).  An agent built from ``norm`` statistics alone has no initial data set and skips the training."""
         self.current_desired_state_index = 0
         self.actions_done_for_current_waypoint = 0
         stds, means = path_deltas_stds_and_means_per_dim(path_to_follow)
@@ -486,6 +491,9 @@ class NND_MB_agent(NavigationRLAgent):
                                                                                 self.steps_per_waypoint))
         self.distances_left = distances_left(self.desired_states, self.distance_function)
         self._problems = None
+        if self._train_inputs is not None and self.num_episodes_finished % self.num_episodes_for_aggregation == 0:
+            self.train_dynamics_model()                                       # :421-422
+        self.num_episodes_finished += 1
 
     @property
     def current_desired_state(self):

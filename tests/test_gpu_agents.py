@@ -94,6 +94,39 @@ def test_navigator_get_action_matches_oracle_pipeline(ssc, golden_dir):
     assert not agent.close_enough_to_goal(start) and agent.close_enough_to_goal(agent.desired_states[-1])
 
 
+def test_navigator_retrains_every_third_plan(ssc, golden_dir):
+    """NND_MB_agent.start_new_episode_plan :420-423: the dynamics model is retrained on initial + aggregated data at
+    plans 0, 3, 6, ... (num_episodes_for_aggregation = 3) and left alone in between."""
+    from smartstartcontinuous_amd.agents import NND_MB_agent
+    g = np.load(f"{golden_dir}/mc_reference_rollouts.npz")
+    env = ssc.make("MountainCarContinuous-v0", seed=2)
+    agent = NND_MB_agent(env, None, horizon=4, num_control_samples=64, num_fc_layers=1, depth_fc_layers=32,
+                         training_data=dict(dataX=g["dataX"], dataY=g["dataY"], dataZ=g["dataZ"]),
+                         precision="f32", seed=5, nEpochs=1)
+    path = g["states_val"][1, :60]
+    snap = lambda: [w.clone() for w in agent.dyn_model.W]
+    same = lambda a, b: all(torch.equal(x, y) for x, y in zip(a, b))
+    w0 = snap()
+    np.random.seed(0)
+    changed = []
+    for k in range(5):
+        if k == 2:       # transitions observed in between become the "new" rows of the next training
+            agent.replay_buffer.start_new_episode(agent)
+            for t in range(40):
+                agent.replay_buffer.add(agent, g["states_val"][2, t], g["controls_val"][2, t], 0.0, False, g["states_val"][2, t + 1])
+        agent.start_new_episode_plan(path[0], path)
+        w1 = snap()
+        changed.append(not same(w0, w1))
+        w0 = w1
+    assert changed == [True, False, False, True, False] and agent.num_episodes_finished == 5
+    assert int(agent.dyn_model._adam["t"].item()) > 0
+    # statistics-only agent: nothing to train on, plans still work
+    nm = NND_MB_agent.normalisation_from_data(g["dataX"], g["dataY"], g["dataZ"])
+    bare = NND_MB_agent(env, None, num_fc_layers=1, depth_fc_layers=32, norm=nm, precision="f32")
+    bare.start_new_episode_plan(path[0], path)
+    assert bare.num_episodes_finished == 1 and not hasattr(bare.dyn_model, "_adam")
+
+
 def test_rl_train_vec_summary(ssc):
     env = ssc.VecEnv("MountainCarContinuous-v0", 512, seed=9, max_episode_steps=50)
     seen = []
