@@ -8,8 +8,9 @@
 //     <= 512 units: 1x32 in the examples, 1x500 the class default).  Block b owns 32 batch rows: gather, forward,
 //     output delta, back-propagation and its share of every gradient, all in LDS/registers; the block that
 //     finishes last (atomic ticket) sums the per-block gradients in block order and applies Adam.
-//   * the generic chain of small launches for any other feedforward_network shape: gather -> forward layers
-//     (the fp32 layer kernel of dyn_model.hip) -> output delta -> per layer {dW, db, dX, ReLU mask, Adam}.
+//   * any other feedforward_network shape: gather -> per layer a forward GEMM -> output delta -> per layer
+//     {backward-data GEMM with the ReLU mask, weight-gradient GEMM with Adam in its epilogue}, all on the exact-fp32
+//     MFMA through one 32x32-tile kernel (gemm32_f32_kernel).
 // The bias-corrected step size comes from a device-side step counter, so any number of consecutive steps is
 // enqueued by one call without a host round trip.
 #include <stdlib.h>
@@ -19,13 +20,17 @@
 
 namespace ssc {
 
-// dyn_model.hip
-void launch_mlp_layer_f32(bool relu, int64_t m, int K, int N, const float *X, const float *W, const float *b, float *Y,
-                          hipStream_t s);
-
+// batch rows by index; block 0 also advances the Adam step counter: scal[0] = lr_t of this step
+// (tf.train.AdamOptimizer: lr * sqrt(1 - b2^t) / (1 - b1^t))
 __global__ __launch_bounds__(256) void train_gather_kernel(int B, int in, int out, const float *__restrict__ X,
                                                            const float *__restrict__ Z, const int32_t *__restrict__ idx,
-                                                           float *__restrict__ xb, float *__restrict__ zb) {
+                                                           float *__restrict__ xb, float *__restrict__ zb, int32_t *t,
+                                                           float lr, float b1, float b2, float *scal) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int tt = t[0] + 1;
+        t[0] = tt;
+        scal[0] = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)tt)) / (1.0 - pow((double)b1, (double)tt)));
+    }
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < B * in) {
         const int r = e / in, c = e - r * in;
@@ -37,71 +42,139 @@ __global__ __launch_bounds__(256) void train_gather_kernel(int B, int in, int ou
     }
 }
 
-// scal[0] = lr_t for this step, scal[1] = loss accumulator (zeroed); t += 1
-__global__ void train_begin_kernel(int32_t *t, float lr, float b1, float b2, float *scal) {
-    const int tt = t[0] + 1;
-    t[0] = tt;
-    scal[0] = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)tt)) / (1.0 - pow((double)b1, (double)tt)));
-    scal[1] = 0.0f;
-}
-
-// dY = 2 (y - z) / (B * out)   (d mean((z - y)^2) / dy, dynamics_model.py:41); loss accumulated
-__global__ __launch_bounds__(256) void train_out_delta_kernel(int n, const float *__restrict__ y,
-                                                              const float *__restrict__ z, float *__restrict__ dy,
-                                                              float *__restrict__ scal) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+// dY = 2 (y - z) / (B * out)   (d mean((z - y)^2) / dy, dynamics_model.py:41) and the batch MSE; ONE block, fixed
+// summation order
+constexpr int kDeltaThreads = 1024;
+__global__ __launch_bounds__(kDeltaThreads) void train_out_delta_kernel(int n, const float *__restrict__ y,
+                                                                        const float *__restrict__ z, float *__restrict__ dy,
+                                                                        float *__restrict__ loss) {
+    __shared__ float part[kDeltaThreads / 64];
     float l = 0.0f;
-    if (e < n) {
+    for (int e = threadIdx.x; e < n; e += kDeltaThreads) {
         const float d = y[e] - z[e];
         dy[e] = 2.0f * d / (float)n;
-        l = d * d / (float)n;
+        l = fmaf(d, d, l);
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m);
-    if ((threadIdx.x & 63) == 0) atomicAdd(scal + 1, l);
-}
-
-// one thread per weight: g = sum_b A[b][i] dZ[b][j], then Adam in place
-__global__ __launch_bounds__(256) void train_weight_kernel(int B, int K, int N, const float *__restrict__ A,
-                                                           const float *__restrict__ dZ, float *__restrict__ W,
-                                                           float *__restrict__ mW, float *__restrict__ vW,
-                                                           float *__restrict__ bias, float *__restrict__ mb,
-                                                           float *__restrict__ vb, const float *__restrict__ scal,
-                                                           float b1, float b2, float eps) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const float lr_t = scal[0];
-    if (e < K * N) {
-        const int i = e / N, j = e - i * N;
-        float g = 0.0f;
-        for (int b = 0; b < B; ++b) g = fmaf(A[(int64_t)b * K + i], dZ[(int64_t)b * N + j], g);
-        const float m = b1 * mW[e] + (1.0f - b1) * g;
-        const float v = b2 * vW[e] + (1.0f - b2) * g * g;
-        mW[e] = m; vW[e] = v;
-        W[e] -= lr_t * m / (sqrtf(v) + eps);
-    } else if (e < K * N + N) {
-        const int j = e - K * N;
-        float g = 0.0f;
-        for (int b = 0; b < B; ++b) g += dZ[(int64_t)b * N + j];
-        const float m = b1 * mb[j] + (1.0f - b1) * g;
-        const float v = b2 * vb[j] + (1.0f - b2) * g * g;
-        mb[j] = m; vb[j] = v;
-        bias[j] -= lr_t * m / (sqrtf(v) + eps);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss != nullptr) {
+        float a = 0.0f;
+        for (int w = 0; w < kDeltaThreads / 64; ++w) a += part[w];
+        loss[0] = a / (float)n;
     }
 }
 
-// dA[b][i] = (A[b][i] > 0) * sum_j dZ[b][j] W[i][j]    (ReLU of feedforward_network.py:19)
-__global__ __launch_bounds__(256) void train_back_kernel(int B, int K, int N, const float *__restrict__ dZ,
-                                                         const float *__restrict__ W, const float *__restrict__ A,
-                                                         float *__restrict__ dA) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= B * K) return;
-    const int b = e / K, i = e - b * K;
-    float g = 0.0f;
-    for (int j = 0; j < N; ++j) g = fmaf(dZ[(int64_t)b * N + j], W[(int64_t)i * N + j], g);
-    dA[e] = (A[e] > 0.0f) ? g : 0.0f;
+// ---------------------------------------------------------------------------------------------------------
+// The three GEMMs of a layer on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32):
+//   forward   Y  = act(X W + b)         A = X  [B x K] rows,      B = W  [K x N] rows
+//   backward  dX = (dY W^T) * (X > 0)   A = dY [B x N] rows,      B = W^T: B[k][n] = W[n][k]
+//   gradient  dW = X^T dY (+ ones row -> db), Adam in the epilogue:  A = X^T: A[m][k] = X[k][m],  B = dY rows
+// One block = one 32 x 32 output tile, its K range split over the 4 waves (one per SIMD) and summed through LDS in
+// wave order.  Operands go straight from global memory / L2 to the MFMA registers: a "row" operand is read as one
+// 16-byte vector per lane (lane = output row or column, 4 consecutive k), a "column" operand as 4 coalesced dwords.
+// Lanes 0-31 feed k = 8q + r, lanes 32-63 k = 8q + 4 + r into the r-th MFMA of group q -- any pairing of k values
+// is a valid contraction as long as A and B agree on it.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_ADAM = 3 };
+
+struct GemmArgs {
+    const float *A, *B;
+    int lda, ldb, M, N, K;
+    int a_vec, b_vec;              // 16-byte loads allowed for a row operand (alignment + K % 4 == 0)
+    int ones_row;                  // gradient GEMM: A row that reads as 1.0 (bias gradient), else -1
+    float *C; int ldc;             // EPI_BIAS / EPI_BIAS_RELU / EPI_MASK
+    const float *bias;             // EPI_BIAS*
+    const float *mask; int ldmask; // EPI_MASK
+    float *W, *mW, *vW, *bb, *mb, *vb;   // EPI_ADAM: W [M - 1 or M][N], bias [N]
+    const float *scal;             // scal[0] = lr_t
+    float beta1, beta2, eps;
+};
+
+// 4 k-values of operand element `idx` (row or column of the tile) for this lane's half
+template <bool ROWS>
+__device__ __forceinline__ void gemm_load4(const float *__restrict__ P, int ld, int idx, int lim, int k, int K, int vec,
+                                           int ones_idx, float (&out)[4]) {
+    if (ROWS) {      // P[idx * ld + k .. k + 3]
+        const float *src = P + (int64_t)idx * ld + k;
+        if (idx < lim && vec && k + 3 < K) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[r] = (idx < lim && k + r < K) ? src[r] : 0.0f;
+        }
+    } else {         // P[(k + r) * ld + idx]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.0f;
+            if (k + r < K) {
+                if (idx == ones_idx) v = 1.0f;
+                else if (idx < lim) v = P[(int64_t)(k + r) * ld + idx];
+            }
+            out[r] = v;
+        }
+    }
 }
 
-__global__ void train_loss_out_kernel(const float *scal, float *loss) { loss[0] = scal[1]; }
+template <bool A_ROWS, bool B_ROWS, int EPI>
+__global__ __launch_bounds__(256) void gemm32_f32_kernel(GemmArgs g) {
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int ksz = (((g.K + 3) >> 2) + 7) & ~7;          // k values per wave, a multiple of 8
+    const int kb = w * ksz, ke = kb + ksz < g.K ? kb + ksz : g.K;
+    const int a_lim = g.ones_row >= 0 ? g.ones_row : g.M;  // the ones row is not read from memory
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int k8 = kb; k8 < ke; k8 += 8) {
+        float a[4], b[4];
+        gemm_load4<A_ROWS>(g.A, g.lda, m0 + l32, a_lim, k8 + 4 * half, ke, g.a_vec, A_ROWS ? -1 : g.ones_row, a);
+        gemm_load4<B_ROWS>(g.B, g.ldb, n0 + l32, g.N, k8 + 4 * half, ke, g.b_vec, -1, b);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[i];
+    __syncthreads();
+    // wave w finishes accumulator registers 4w .. 4w + 3: rows m0 + 8w + 4 half + (i & 3), column n0 + l32
+    const int n = n0 + l32;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int i = 4 * w + ii;
+        const float v = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
+        const int m = m0 + 8 * w + 4 * half + ii;
+        if (m >= g.M || n >= g.N) continue;
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
+            const float y = v + g.bias[n];
+            g.C[(int64_t)m * g.ldc + n] = EPI == EPI_BIAS_RELU ? fmaxf(y, 0.0f) : y;
+        } else if (EPI == EPI_MASK) {
+            g.C[(int64_t)m * g.ldc + n] = g.mask[(int64_t)m * g.ldmask + n] > 0.0f ? v : 0.0f;
+        } else {
+            float *th, *mm, *vv;
+            if (m == g.ones_row) { th = g.bb + n; mm = g.mb + n; vv = g.vb + n; }
+            else { const int64_t e = (int64_t)m * g.N + n; th = g.W + e; mm = g.mW + e; vv = g.vW + e; }
+            const float m1 = g.beta1 * *mm + (1.0f - g.beta1) * v;
+            const float v1 = g.beta2 * *vv + (1.0f - g.beta2) * v * v;
+            *mm = m1; *vv = v1;
+            *th -= g.scal[0] * m1 / (sqrtf(v1) + g.eps);
+        }
+    }
+}
+
+static bool vec_ok(const float *p, int ld, int K) {
+    return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0) && (K % 4 == 0);
+}
+
+template <bool A_ROWS, bool B_ROWS, int EPI>
+static void launch_gemm(const GemmArgs &g, hipStream_t s) {
+    hipLaunchKernelGGL((gemm32_f32_kernel<A_ROWS, B_ROWS, EPI>), dim3((g.N + 31) / 32, (g.M + 31) / 32), dim3(256), 0, s, g);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Fused step for one hidden layer:  y = relu(x W1 + b1) W2 + b2.
@@ -417,25 +490,38 @@ static int generic_step(const ssc_mlp_train_desc *net, const float *d_X, const f
     float *d0 = reinterpret_cast<float *>(w); w += al256((size_t)B * maxw * 4);
     float *d1 = reinterpret_cast<float *>(w);
     const int in = net->dims[0], out = net->dims[L];
-    hipLaunchKernelGGL(train_begin_kernel, dim3(1), dim3(1), 0, s, net->adam_t, net->lr, net->beta1, net->beta2, scal);
     hipLaunchKernelGGL(train_gather_kernel, dim3(blocks_for((int64_t)B * (in > out ? in : out))), dim3(256), 0, s, B, in,
-                       out, d_X, d_Z, d_idx, act[0], zb);
-    for (int l = 0; l < L; ++l)
-        launch_mlp_layer_f32(l != L - 1, B, net->dims[l], net->dims[l + 1], act[l], net->W[l], net->b[l], act[l + 1], s);
-    hipLaunchKernelGGL(train_out_delta_kernel, dim3(blocks_for((int64_t)B * out)), dim3(256), 0, s, B * out, act[L], zb,
-                       d0, scal);
+                       out, d_X, d_Z, d_idx, act[0], zb, net->adam_t, net->lr, net->beta1, net->beta2, scal);
+    GemmArgs g;
+    for (int l = 0; l < L; ++l) {        // act[l + 1] = relu?(act[l] W_l + b_l)      (feedforward_network.py:14-23)
+        const int K = net->dims[l], N = net->dims[l + 1];
+        g = GemmArgs{};
+        g.A = act[l]; g.lda = K; g.B = net->W[l]; g.ldb = N; g.M = B; g.N = N; g.K = K;
+        g.a_vec = vec_ok(act[l], K, K); g.ones_row = -1;
+        g.C = act[l + 1]; g.ldc = N; g.bias = net->b[l];
+        if (l != L - 1) launch_gemm<true, false, EPI_BIAS_RELU>(g, s);
+        else launch_gemm<true, false, EPI_BIAS>(g, s);
+    }
+    hipLaunchKernelGGL(train_out_delta_kernel, dim3(1), dim3(kDeltaThreads), 0, s, B * out, act[L], zb, d0, d_loss);
     float *dz = d0, *dprev = d1;
     for (int l = L - 1; l >= 0; --l) {
         const int K = net->dims[l], N = net->dims[l + 1];
-        if (l > 0)  // delta of the previous layer from the OLD weights, before Adam touches them
-            hipLaunchKernelGGL(train_back_kernel, dim3(blocks_for((int64_t)B * K)), dim3(256), 0, s, B, K, N, dz,
-                               net->W[l], act[l], dprev);
-        hipLaunchKernelGGL(train_weight_kernel, dim3(blocks_for((int64_t)K * N + N)), dim3(256), 0, s, B, K, N, act[l],
-                           dz, net->W[l], net->mW[l], net->vW[l], net->b[l], net->mb[l], net->vb[l], scal, net->beta1,
-                           net->beta2, net->epsilon);
+        if (l > 0) {   // delta of the previous layer from the OLD weights, before Adam touches them
+            g = GemmArgs{};
+            g.A = dz; g.lda = N; g.B = net->W[l]; g.ldb = N; g.M = B; g.N = K; g.K = N;
+            g.a_vec = vec_ok(dz, N, N); g.b_vec = vec_ok(net->W[l], N, N); g.ones_row = -1;
+            g.C = dprev; g.ldc = K; g.mask = act[l]; g.ldmask = K;
+            launch_gemm<true, true, EPI_MASK>(g, s);
+        }
+        // dW = act[l]^T dz with a row of ones appended (-> db); Adam in the epilogue
+        g = GemmArgs{};
+        g.A = act[l]; g.lda = K; g.B = dz; g.ldb = N; g.M = K + 1; g.N = N; g.K = B;
+        g.ones_row = K;
+        g.W = net->W[l]; g.mW = net->mW[l]; g.vW = net->vW[l]; g.bb = net->b[l]; g.mb = net->mb[l]; g.vb = net->vb[l];
+        g.scal = scal; g.beta1 = net->beta1; g.beta2 = net->beta2; g.eps = net->epsilon;
+        launch_gemm<false, false, EPI_ADAM>(g, s);
         float *t = dz; dz = dprev; dprev = t;
     }
-    if (d_loss != nullptr) hipLaunchKernelGGL(train_loss_out_kernel, dim3(1), dim3(1), 0, s, scal, d_loss);
     return SSC_OK;
 }
 
