@@ -164,12 +164,13 @@ def bench_config4(args, torch):
     M = P * N
     # data set exactly as the reference builds it (NND_MB_agent.py:75-76,230-242): 25 random-policy
     # rollouts of 333 steps -- produced by the Pendulum rollout kernel; z-score statistics :302-315
+    from smartstartcontinuous_amd import collect_samples as cs
     denv = VecEnv("Pendulum-v0", 25, seed=1234)
     dchunk = denv.rollout(333, RandomPolicy())
-    X = dchunk.obs.permute(2, 1, 0).reshape(-1, d).double().cpu().numpy()
-    Y = dchunk.act.t().reshape(-1, a).double().cpu().numpy()
-    Z = dchunk.obs2.permute(2, 1, 0).reshape(-1, d).double().cpu().numpy() - X
-    norm = dict(mean_x=X.mean(0), std_x=X.std(0), mean_y=Y.mean(0), std_y=Y.std(0), mean_z=Z.mean(0), std_z=Z.std(0))
+    ts = cs.dataset_from_chunk(dchunk)                                   # data_manipulation.py:58-88 on the device
+    (mx, sx), (my, sy), (mz, sz) = (cs.column_stats(v) for v in (ts.dataX, ts.dataY, ts.dataZ))
+    host = lambda t: t.cpu().numpy()
+    norm = dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz))
     Ws, bs = init_dynamics_weights(d + a, d, 2, 500, torch.Generator().manual_seed(1234))
     model = nav.DynamicsModel(Ws, bs, norm, d, a, precision="bf16_mfma")
     # waypoints = a recorded 200-state path (env 0 of the data set), radii / distances_left as in
