@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _ffi
-from .vec_env import RandomPolicy, TransitionChunk, VecEnv
+from .vec_env import RandomPolicy, VecEnv
 
 
 def _stream():

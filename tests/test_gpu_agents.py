@@ -157,7 +157,7 @@ def test_replay_buffer_ingests_chunk(ssc):
 
 def test_critic_kde_ucb_kernels(ssc):
     from smartstartcontinuous_amd import smartstart as SS
-    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent, init_critic_weights
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
     rng = np.random.default_rng(4)
     env = ssc.make("MountainCarContinuous-v0")
     for (h1, h2, llt) in [(64, 32, True), (200, 100, False)]:

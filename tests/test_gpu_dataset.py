@@ -1,8 +1,6 @@
 """GPU parity of the data-collection path (csrc/dataset.hip through the C ABI): rollout chunk -> (dataX, dataY,
 dataZ) against the oracle and the reference-generated vectors, column statistics, z-scoring, keyed noise,
 CollectSamples end to end and the NND_MB_agent constructor that collects its own training data."""
-import ctypes
-
 import numpy as np
 import pytest
 

@@ -3,7 +3,6 @@ to the learner rank and all-reduce the chunk statistics; plus the shard arithmet
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
