@@ -8,6 +8,9 @@ Reference counterparts (SURVEY.md section 2 "Collective / IPC call sites"):
     the packed transition records to the learner rank over xGMI.
   * stats -- the epoch-stats ``allreduce`` of training_editted.py:173; here an
     ``all_reduce(SUM)`` of the 4 chunk statistics.
+  * parameter sync -- ``MpiAdam.sync`` / ``target_init_updates`` broadcasting the root's parameters
+    (ddpg_editted.py:331-336); here ONE ``broadcast`` of the learner's flat actor-parameter array per chunk
+    (``rl_train_sharded_ddpg``), the actors' weight views alias it so no copy follows.
 
 Envs are independent, so the rollout itself needs no collective; all RNG is keyed by the
 GLOBAL env id, so any world size reproduces the same per-env streams.
@@ -159,3 +162,58 @@ class TransitionGather:
     def finish(self):
         if self.cuda:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
+def broadcast_flat(flat, src=0, group=None):
+    """Everybody's ``flat`` becomes the ``src`` rank's (one collective for all of a network's parameters)."""
+    dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
+def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, learner=0, gather_steps=None,
+                          replay_capacity=1 << 20, train_iters=None, seed=0, group=None, ring_capacity=1 << 20):
+    """The actor-learner loop of ``rl_train_vec_ddpg`` over ``world`` GPUs (one process each, ``env`` = this rank's
+    shard of one global env-id space).  Per chunk:
+
+      every rank     rolls its envs out under the CURRENT actor (fused kernel, OU noise), packs the last
+                     ``gather_steps`` steps (default: 2^20 / N_total) and joins ONE gather to the learner;
+      learner rank   appends every rank's records to its device replay ring, runs ``train_iters`` DDPG iterations
+                     (``ssc_ddpg_train``), then
+      every rank     joins ONE broadcast of the learner's flat actor parameters -- the rollout policy reads views
+                     of that array, so the next chunk acts with the new weights.
+
+    Returns (Summary of THIS rank's finished episodes, losses per chunk [learner only], replay [learner only])."""
+    from .replay_buffer import DeviceReplayBuffer
+    from .rl_train import Summary
+    from .vec_env import EpisodeRing, TransitionChunk
+    n_total = env.n * world
+    g = int(gather_steps) if gather_steps is not None else max(1, min(chunk_steps, (1 << 20) // n_total))
+    gather = TransitionGather(env.obs_dim, g, env.n, world, rank, env.device, dst=learner, group=group)
+    summary = Summary("sharded_ddpg_" + env.spec.id)
+    ring = EpisodeRing(ring_capacity, env.device)
+    chunk = TransitionChunk(env.obs_dim, chunk_steps, env.n, env.device)
+    replay = DeviceReplayBuffer(replay_capacity, env.obs_dim, 1, env.device, seed=seed) if rank == learner else None
+    broadcast_flat(agent.actor_flat, src=learner, group=group)          # MpiAdam.sync: start from the root's parameters
+    losses = []
+    generations = 0.0
+    for i in range(num_chunks):
+        pd = env.policy_desc(agent.as_policy())
+        env.rollout(chunk_steps, out=chunk, ring=ring, policy_desc=pd)
+        gather.submit(chunk, i & 1, env.stats)
+        gather.finish()
+        if rank == learner:
+            for src in range(world):
+                replay.append_chunk(TransitionChunk.from_columns(*gather.unpack(src)),
+                                    reward_scale=agent.reward_scale)
+            l = agent.train_from(replay, train_iters)
+            if l is not None:
+                losses.append(l)
+        broadcast_flat(agent.actor_flat, src=learner, group=group)
+        (ids, lens, rets), _d = ring.drain()
+        summary.extend_records(lens, rets)
+        generations += len(lens) / float(env.n)      # epsilon decays once per episode per env (DDPG_Baselines_agent.py:255-258)
+        while generations >= 1.0:
+            agent.decaying_ou_action_noise.reduce_epsilon()
+            generations -= 1.0
+    return summary, losses, replay
+

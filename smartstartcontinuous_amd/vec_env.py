@@ -112,6 +112,17 @@ class TransitionChunk:
 
     BYTES_PER_STEP = {2: 25, 3: 33}
 
+    @classmethod
+    def from_columns(cls, obs, act, rew, obs2, done):
+        """A chunk over EXISTING column tensors (obs/obs2 [obs_dim, K, N], act/rew/done [K, N]; rows of one column
+        equally strided) -- e.g. the records a learner rank received from another rank (TransitionGather.unpack)."""
+        self = cls.__new__(cls)
+        self.packed = False
+        self.obs, self.act, self.rew, self.obs2, self.done = obs, act, rew, obs2, done
+        self.obs_dim, self.K, self.N = obs.shape[0], act.shape[0], act.shape[1]
+        self.step0 = self.env_id0 = 0
+        return self
+
     def nbytes(self):
         return self.K * self.N * (8 * self.obs_dim + 9)
 

@@ -127,6 +127,39 @@ def test_navigator_retrains_every_third_plan(ssc, golden_dir):
     assert bare.num_episodes_finished == 1 and not hasattr(bare.dyn_model, "_adam")
 
 
+def test_sharded_actor_learner_loop_world1_equals_vec_loop(ssc):
+    """rl_train_sharded_ddpg (rollout -> RCCL gather -> learner -> parameter broadcast) rehearsed with a 1-rank RCCL
+    group: with the same seeds it must reproduce rl_train_vec_ddpg fed the same last-g steps, bit for bit."""
+    import os
+    import torch.distributed as dist
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    from smartstartcontinuous_amd.sharding import rl_train_sharded_ddpg
+
+    def setup():
+        env = ssc.VecEnv("MountainCarContinuous-v0", 256, seed=11, max_episode_steps=60)
+        one = ssc.SingleEnvView(ssc.VecEnv("MountainCarContinuous-v0", 1, seed=11))
+        agent = DDPG_Baselines_agent(one, None, batch_size=64, num_train_iterations=5, actor_h1=64, actor_h2=32,
+                                     critic_h1=64, critic_h2=32, lastLayerTanh=True, seed=4)
+        return env, agent
+    env_a, agent_a = setup()
+    s_a, losses_a, replay_a = ssc.rl_train_vec_ddpg(env_a, agent_a, num_chunks=4, chunk_steps=48, replay_capacity=4096,
+                                                    replay_last_steps=8, seed=3)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        env_b, agent_b = setup()
+        s_b, losses_b, replay_b = rl_train_sharded_ddpg(env_b, agent_b, num_chunks=4, chunk_steps=48, rank=0, world=1,
+                                                        gather_steps=8, replay_capacity=4096, seed=3)
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(agent_a.actor_flat, agent_b.actor_flat) and torch.equal(agent_a.critic_flat, agent_b.critic_flat)
+    assert len(losses_a) == len(losses_b) == 4 and all(torch.equal(x, y) for x, y in zip(losses_a, losses_b))
+    assert sorted(s_a.episodes) == sorted(s_b.episodes) and len(s_a) > 0      # ring order is atomics order
+    assert replay_a.count == replay_b.count == 4 * 8 * 256 and torch.equal(replay_a.s, replay_b.s)
+    assert not torch.equal(agent_b.actor_flat, setup()[1].actor_flat)          # it did learn something
+
+
 def test_rl_train_vec_summary(ssc):
     env = ssc.VecEnv("MountainCarContinuous-v0", 512, seed=9, max_episode_steps=50)
     seen = []

@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from smartstartcontinuous_amd.sharding import TransitionGather, record_bytes, shard_range
+from smartstartcontinuous_amd.sharding import TransitionGather, broadcast_flat, record_bytes, shard_range
+from smartstartcontinuous_amd.vec_env import TransitionChunk
 
 
 def test_shard_ranges_cover_the_id_space():
@@ -61,6 +62,15 @@ def _worker(rank, world, port, obs_dim, g, tmp, allreduce=True):
     if allreduce or rank == 0:
         ok &= torch.equal(tg.global_stats, exp)
     ok &= tg.chunks_gathered == 3
+    if rank == 0:
+        # what the learner of rl_train_sharded_ddpg appends to its replay ring: a chunk over the received columns
+        got = TransitionChunk.from_columns(*tg.unpack(world - 1))
+        ok &= (got.K, got.N, got.obs_dim) == (g, N, obs_dim) and got.act.stride(0) == N
+    # parameter sync (MpiAdam.sync, ddpg_editted.py:331-336): the views every rank's policy reads alias the flat array
+    flat = torch.arange(10, dtype=torch.float32) + 100.0 * rank
+    view = flat[2:8].view(2, 3)
+    broadcast_flat(flat, src=0)
+    ok &= torch.equal(view, (torch.arange(10, dtype=torch.float32))[2:8].view(2, 3))
     open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()
