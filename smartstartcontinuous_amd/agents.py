@@ -455,14 +455,10 @@ class NND_MB_agent(NavigationRLAgent):
             cs.add_noise_device(train.dataZ, self.noiseToSignal, self.seed, stream_id=1)
         self.dataX, self.dataY, self.dataZ = train.dataX, train.dataY, train.dataZ
         (mx, sx), (my, sy), (mz, sz) = (cs.column_stats(v) for v in (train.dataX, train.dataY, train.dataZ))
-        d, a = train.dataX.shape[1], train.dataY.shape[1]
-        inputs = torch.empty((len(train), d + a), dtype=torch.float32, device=train.dataX.device)
-        cs.zscore_into(train.dataX, mx, sx, inputs, 0)                   # :318 np.concatenate((dataX, dataY), axis=1)
-        cs.zscore_into(train.dataY, my, sy, inputs, d)
-        self._train_inputs = inputs
-        self._train_outputs = cs.zscore_into(train.dataZ, mz, sz, torch.empty_like(train.dataZ), 0)
         host = lambda t: t.cpu().numpy()
-        return dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz))
+        norm = dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz))
+        self._train_inputs, self._train_outputs = train.normalised(norm)  # :302-319, np.concatenate((dataX, dataY), axis=1)
+        return norm
 
     @staticmethod
     def normalisation_from_data(dataX, dataY, dataZ):

@@ -53,6 +53,17 @@ class TrainingSet:
         return dict(dataX=self.dataX.double().cpu().numpy(), dataY=self.dataY.double().cpu().numpy(),
                     dataZ=self.dataZ.double().cpu().numpy())
 
+    def normalised(self, norm):
+        """(inputs [rows, d + a], outputs [rows, d]) z-scored with EXISTING statistics (``norm``: the dict of
+        NND_MB_agent / DynamicsModel) -- how aggregated rows enter a retraining (NND_MB_agent.py:455-461)."""
+        dev = self.dataX.device
+        st = lambda k: torch.as_tensor(np.asarray(norm[k], np.float64).reshape(-1), device=dev)
+        d, a = self.dataX.shape[1], self.dataY.shape[1]
+        inputs = torch.empty((len(self), d + a), dtype=torch.float32, device=dev)
+        zscore_into(self.dataX, st("mean_x"), st("std_x"), inputs, 0)
+        zscore_into(self.dataY, st("mean_y"), st("std_y"), inputs, d)
+        return inputs, zscore_into(self.dataZ, st("mean_z"), st("std_z"), torch.empty_like(self.dataZ), 0)
+
 
 def _scan(chunk):
     """(lens [n] i32, offsets [n+1] i64) of the first episode segment of every env of ``chunk``."""

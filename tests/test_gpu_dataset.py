@@ -197,6 +197,46 @@ def test_nnd_mb_agent_collects_and_trains_its_own_data(ssc):
     assert last_loss < 0.05 and (after < 0.35).all() and (after < 0.3 * before).all(), (before, after, last_loss)
 
 
+def test_mpc_rollout_chunks_aggregate_into_a_retraining(ssc):
+    """The vectorised counterpart of NND_MB_agent.train_dynamics_model (:437-480): transitions logged while the
+    navigator drives the envs become the "new" rows -- formatted and z-scored with the INITIAL statistics on the
+    device -- and are mixed into Dyn_Model.train's batches.  Nothing is copied to the host."""
+    from smartstartcontinuous_amd import collect_samples as cs, navigator as nav, numerical as num
+    from smartstartcontinuous_amd.agents import init_dynamics_weights
+    env1 = ssc.make("MountainCarContinuous-v0", device="cuda", seed=21)
+    col = cs.CollectSamples(env1, cs.Policy_Random(env1))
+    ts = col.collect_dataset(64, 200)
+    (mx, sx), (my, sy), (mz, sz) = (cs.column_stats(v) for v in (ts.dataX, ts.dataY, ts.dataZ))
+    host = lambda t: t.cpu().numpy()
+    norm = dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz))
+    old_in, old_out = ts.normalised(norm)
+    assert old_in.shape == (len(ts), 3) and abs(old_in.double().mean(0)).max().item() < 1e-5
+    Ws, bs = init_dynamics_weights(3, 2, 1, 32, torch.Generator().manual_seed(3))
+    model = nav.DynamicsModel(Ws, bs, norm, 2, 1, precision="f32")
+    model.train(old_in, old_out, np.zeros((0, 3)), np.zeros((0, 2)), 6, 0.0, rng=np.random.RandomState(0))
+    # P envs follow recorded paths under MPC; their logged transitions are the aggregated data
+    states, _, _, _ = col.collect_samples(8, 120)
+    wps, lefts, radii = [], [], []
+    for path in states:
+        stds, means = num.path_deltas_stds_and_means_per_dim(path)
+        rad = num.radii_calc(means, stds, 1, 1, 1)
+        dist = num.elliptical_euclidean_distance_function_generator(rad)
+        wps.append(path); radii.append(rad); lefts.append(num.distances_left(path, dist))
+    batch = nav.NavigatorBatch(model, nav.MpcProblemSet(wps, lefts, radii, [0] * 8), num_control_samples=512, horizon=4, seed=5)
+    venv = ssc.VecEnv("MountainCarContinuous-v0", 8, seed=23)
+    venv.reset()
+    chunk = venv.rollout(60, policy=ssc.MpcPolicy(batch))
+    new = cs.dataset_from_chunk(chunk)
+    assert len(new) == 8 * 59 and torch.equal(new.dataX[:59], chunk.obs[:, :59, 0].t())
+    new_in, new_out = new.normalised(norm)
+    ref_in = O.zscore(np.concatenate([host(new.dataX), host(new.dataY)], 1),
+                      np.concatenate([norm["mean_x"], norm["mean_y"]]), np.concatenate([norm["std_x"], norm["std_y"]]))
+    assert np.allclose(host(new_in), ref_in, rtol=2e-7, atol=0)
+    w_before = [w.clone() for w in model.W]
+    loss = model.train(old_in, old_out, new_in, new_out, 2, 0.5, rng=np.random.RandomState(1))
+    assert np.isfinite(loss) and loss < 0.1 and not torch.equal(w_before[0], model.W[0])
+
+
 def test_dataset_full_size_properties(ssc):
     """BASELINE-size collection (65 536 Pendulum rollouts x 200 steps = 13 M rows): sizes add up, rows inside a
     rollout chain (x + z of one row is the x of the next), spot rows equal the chunk."""
