@@ -3,7 +3,7 @@
 per-kernel PMC means, bench line, and for c2 the HBM traffic check."""
 import collections, csv, glob, json, os, shutil, sys
 src, dst = sys.argv[1], sys.argv[2]
-for cfg in ("c2", "c3", "c4"):
+for cfg in ("c2", "c3", "c4", "train", "dataset"):
     s, d = os.path.join(src, cfg), os.path.join(dst, cfg)
     if not os.path.isdir(s):
         continue
@@ -23,6 +23,10 @@ for cfg in ("c2", "c3", "c4"):
     bj = os.path.join(s, "bench.json")
     if os.path.exists(bj) and os.path.getsize(bj):
         shutil.copy(bj, os.path.join(d, "bench.json"))
+    ot = os.path.join(s, "out.txt")
+    if os.path.exists(ot):        # tool output measured under the profiler (kernels serialised): kept for the kernel list
+        open(os.path.join(d, "tool_output_under_profiler.txt"), "w").write(
+            "".join(l for l in open(ot) if "amdgpu.ids" not in l))
     if cfg == "c2":
         k = [v for name, v in pmc.items() if "rollout_kernel" in name]
         b = json.loads(open(bj).read().strip().splitlines()[-1])
