@@ -69,6 +69,24 @@ __global__ __launch_bounds__(256) void packed_writer(float *__restrict__ p, uint
     }
 }
 
+// wave-tiled records: [K][n/64][6 fp32 columns + 64 done bytes][64 envs] -- the 7 stores of a wave-step land in ONE
+// contiguous 1600-byte block, and a step of all waves is one contiguous sweep
+template <int NT>
+__global__ __launch_bounds__(256) void tile_writer(float *__restrict__ p, int64_t n, int K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t tiles = n / 64, tile = i / 64;
+    const int lane = (int)(i % 64);
+    for (int k = 0; k < K; ++k) {
+        float *base = p + ((int64_t)k * tiles + tile) * 400;     // 6 * 64 floats + 64 bytes = 1600 B = 400 floats
+        for (int c = 0; c < 6; ++c) {
+            if (NT) __builtin_nontemporal_store((float)(k + c), base + c * 64 + lane); else base[c * 64 + lane] = (float)(k + c);
+        }
+        uint8_t *d = reinterpret_cast<uint8_t *>(base + 384) + lane;
+        if (NT) __builtin_nontemporal_store((uint8_t)k, d); else *d = (uint8_t)k;
+    }
+}
+
 // grid-stride f4 fill (the classic streaming-store ceiling)
 template <int NT>
 __global__ __launch_bounds__(256) void fill4(f4 *__restrict__ p, int64_t n4) {
@@ -110,6 +128,8 @@ int main() {
         ms = time_ms([&] { packed_writer<0, 1, 0><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld packed rows + byte plain : %.1f GB/s\n", (long)n, gb / ms / 1e6);
         ms = time_ms([&] { packed_writer<1, 1, 1><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld packed rows + done-as-dword/4steps nt : %.1f GB/s\n", (long)n, gb / ms / 1e6);
         ms = time_ms([&] { packed_writer<0, 1, 1><<<n / 256, 256>>>(p, b, n, K); }); printf("n=%ld packed rows + done-as-dword/4steps plain : %.1f GB/s\n", (long)n, gb / ms / 1e6);
+        ms = time_ms([&] { tile_writer<1><<<n / 256, 256>>>(p, n, K); }); printf("n=%ld wave-tiled records nt : %.1f GB/s\n", (long)n, gb / ms / 1e6);
+        ms = time_ms([&] { tile_writer<0><<<n / 256, 256>>>(p, n, K); }); printf("n=%ld wave-tiled records plain : %.1f GB/s\n", (long)n, gb / ms / 1e6);
         // same bytes as f4 columns: n/4 threads... emulate "4 envs per lane" = 16 B per lane, 1.5 columns of f4
         const int64_t nq = n / 4;
         ms = time_ms([&] { col_writer<1, f4><<<nq / 256, 256>>>((f4 *)p, nq, K, 6); }); printf("n=%ld 6xdwordx4 nt (n/4 threads) : %.1f GB/s\n", (long)n, gb6 / ms / 1e6);
