@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import abc
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -390,6 +391,8 @@ class NND_MB_agent(NavigationRLAgent):
                  training_data=None, weights=None, biases=None, norm=None,
                  make_aggregated_dataset_noisy=True, nEpochs=30, fraction_use_new=0.9,
                  num_episodes_for_aggregation=3,
+                 save_dir_name="save_untitled", load_dir_name="untitled_load", model_root=None,
+                 save_training_data=False, load_existing_training_data=False,
                  make_training_dataset_noisy=True, num_rollouts_train=25, num_rollouts_val=20,
                  steps_per_rollout_train=333, steps_per_rollout_val=333,
                  device="cuda", precision="bf16_mfma", seed=1234, per_row_projection=False, **unused):
@@ -415,6 +418,15 @@ class NND_MB_agent(NavigationRLAgent):
         act_dim = env.action_space.shape[0]
         self._train_inputs = self._train_outputs = None
         self.states_val = self.controls_val = None
+        # the reference keeps its data under <models>/NND_MB_agent/<dir_name>/training_data (:35-44, :181-185)
+        root = model_root if model_root is not None else os.path.join(os.getcwd(), "models", "NND_MB_agent")
+        self.load_dir, self.save_dir = os.path.join(root, load_dir_name), os.path.join(root, save_dir_name)
+        if load_existing_training_data and training_data is None:
+            # :203-213 -- e.g. the reference's own models/NND_MB_agent/default/training_data/*.npy
+            d = os.path.join(self.load_dir, "training_data")
+            training_data = {k: np.load(os.path.join(d, k + ".npy")) for k in ("dataX", "dataY", "dataZ")}
+            self.states_val = np.load(os.path.join(d, "states_val.npy"))
+            self.controls_val = np.load(os.path.join(d, "controls_val.npy"))
         if norm is None and training_data is None:
             norm = self._collect_training_data(num_rollouts_train, steps_per_rollout_train, num_rollouts_val,
                                                steps_per_rollout_val, make_training_dataset_noisy)
@@ -427,6 +439,16 @@ class NND_MB_agent(NavigationRLAgent):
                 self._train_inputs = np.concatenate([nz(training_data["dataX"], norm["mean_x"], norm["std_x"]),
                                                      nz(training_data["dataY"], norm["mean_y"], norm["std_y"])], axis=1)
                 self._train_outputs = nz(training_data["dataZ"], norm["mean_z"], norm["std_z"])
+        if save_training_data:                                                  # :289-296
+            d = os.path.join(self.save_dir, "training_data")
+            os.makedirs(d, exist_ok=True)
+            src = training_data if training_data is not None else \
+                {k: getattr(self, k).double().cpu().numpy() for k in ("dataX", "dataY", "dataZ")}
+            for k in ("dataX", "dataY", "dataZ"):
+                np.save(os.path.join(d, k + ".npy"), np.asarray(src[k], np.float64))
+            if self.states_val is not None:
+                np.save(os.path.join(d, "states_val.npy"), np.asarray(self.states_val))
+                np.save(os.path.join(d, "controls_val.npy"), np.asarray(self.controls_val))
         if weights is None:
             gen = torch.Generator().manual_seed(self.seed)
             weights, biases = init_dynamics_weights(state_dim + act_dim, state_dim, num_fc_layers, depth_fc_layers, gen)

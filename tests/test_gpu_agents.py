@@ -160,6 +160,36 @@ def test_sharded_actor_learner_loop_world1_equals_vec_loop(ssc):
     assert not torch.equal(agent_b.actor_flat, setup()[1].actor_flat)          # it did learn something
 
 
+def test_navigator_loads_and_saves_training_data_like_the_reference(ssc, golden_dir, tmp_path):
+    """load_existing_training_data / save_training_data (NND_MB_agent.py:203-213, :289-296): the directory layout of
+    the reference (<models>/NND_MB_agent/<name>/training_data/*.npy), so its shipped data sets load unchanged."""
+    from smartstartcontinuous_amd.agents import NND_MB_agent
+    g = np.load(f"{golden_dir}/mc_reference_rollouts.npz")
+    d = tmp_path / "default" / "training_data"
+    d.mkdir(parents=True)
+    for k in ("dataX", "dataY", "dataZ", "states_val", "controls_val"):
+        np.save(d / (k + ".npy"), g[k])
+    env = ssc.make("MountainCarContinuous-v0", seed=2)
+    agent = NND_MB_agent(env, None, num_fc_layers=1, depth_fc_layers=32, precision="f32", model_root=str(tmp_path),
+                         load_existing_training_data=True, load_dir_name="default", save_training_data=True,
+                         save_dir_name="copy")
+    nm = NND_MB_agent.normalisation_from_data(g["dataX"], g["dataY"], g["dataZ"])
+    assert np.allclose([agent.dyn_model.norm.std_x[i] for i in range(2)], nm["std_x"], rtol=1e-6)
+    assert agent._train_inputs.shape == (8300, 3) and agent.states_val.shape == (20, 333, 2)
+    for k in ("dataX", "dataY", "dataZ", "states_val", "controls_val"):
+        assert np.array_equal(np.load(tmp_path / "copy" / "training_data" / (k + ".npy")), g[k])
+    # a self-collected data set is written in the same format
+    own = NND_MB_agent(env, None, num_fc_layers=1, depth_fc_layers=32, precision="f32", model_root=str(tmp_path),
+                       save_training_data=True, save_dir_name="own", num_rollouts_train=5, num_rollouts_val=3,
+                       steps_per_rollout_train=50, steps_per_rollout_val=40)
+    X = np.load(tmp_path / "own" / "training_data" / "dataX.npy")
+    assert X.shape == (5 * 49, 2) and X.dtype == np.float64 and np.array_equal(X, own.dataX.double().cpu().numpy())
+    assert np.load(tmp_path / "own" / "training_data" / "states_val.npy").shape == (3, 40, 2)
+    again = NND_MB_agent(env, None, num_fc_layers=1, depth_fc_layers=32, precision="f32", model_root=str(tmp_path),
+                         load_existing_training_data=True, load_dir_name="own")
+    assert np.allclose(again.dyn_model.norm.mean_x[0], own.dyn_model.norm.mean_x[0], rtol=1e-6)
+
+
 def test_rl_train_vec_summary(ssc):
     env = ssc.VecEnv("MountainCarContinuous-v0", 512, seed=9, max_episode_steps=50)
     seen = []
