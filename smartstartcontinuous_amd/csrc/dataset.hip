@@ -117,7 +117,6 @@ struct DatasetArgs {
     const int64_t *off;
     float *X, *Y, *Z;
     int64_t n, rs, capacity;
-    int32_t obs_dim, K;
 };
 
 // grid (ceil(n / 64), ceil((K - 1) / 64)); 256 threads = 4 waves; one block = 64 envs x 64 steps.
@@ -370,7 +369,6 @@ int ssc_dataset_build(const ssc_transition_log *log, int32_t obs_dim, int32_t K,
     DatasetArgs g;
     g.log = *log; g.len = d_len; g.off = d_off; g.X = d_X; g.Y = d_Y; g.Z = d_Z;
     g.n = n; g.rs = log->row_stride ? log->row_stride : n; g.capacity = capacity_rows;
-    g.obs_dim = obs_dim; g.K = K;
     const int64_t gx = (n + kGroup - 1) / kGroup, gy = (K - 1 + kTileK - 1) / kTileK;
     SSC_REQUIRE(gx <= 0x7fffffffLL && gy <= 65535, "ssc_dataset_build: grid too large");
     const dim3 grid((unsigned)gx, (unsigned)gy);
