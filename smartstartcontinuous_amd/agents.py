@@ -393,6 +393,7 @@ class NND_MB_agent(NavigationRLAgent):
                  num_episodes_for_aggregation=3,
                  save_dir_name="save_untitled", load_dir_name="untitled_load", model_root=None,
                  save_training_data=False, load_existing_training_data=False,
+                 save_resulting_dynamics_model=False, load_existing_dynamics_model=False,
                  make_training_dataset_noisy=True, num_rollouts_train=25, num_rollouts_val=20,
                  steps_per_rollout_train=333, steps_per_rollout_val=333,
                  device="cuda", precision="bf16_mfma", seed=1234, per_row_projection=False, **unused):
@@ -455,6 +456,8 @@ class NND_MB_agent(NavigationRLAgent):
         self.dyn_model = navigator.DynamicsModel(weights, biases, norm, state_dim, act_dim, device=device,
                                                  precision=precision)
         self.state_dim, self.act_dim = state_dim, act_dim
+        self.save_resulting_dynamics_model = save_resulting_dynamics_model   # :179
+        self.use_existing_dynamics_model = load_existing_dynamics_model      # :158
         self.desired_states = None
         self.radii = None                   # NND_MB_agent.py:168
         self.param_dict = None
@@ -509,7 +512,8 @@ class NND_MB_agent(NavigationRLAgent):
                                                                                 self.steps_per_waypoint))
         self.distances_left = distances_left(self.desired_states, self.distance_function)
         self._problems = None
-        if self._train_inputs is not None and self.num_episodes_finished % self.num_episodes_for_aggregation == 0:
+        can_train = self._train_inputs is not None or self.use_existing_dynamics_model
+        if can_train and self.num_episodes_finished % self.num_episodes_for_aggregation == 0:
             self.train_dynamics_model()                                       # :421-422
         self.num_episodes_finished += 1
 
@@ -609,6 +613,9 @@ class NND_MB_agent(NavigationRLAgent):
         (DynamicsModel.train -> ssc_mlp_train_step).  Without arguments the aggregated rows come from the
         replay buffer exactly as in the reference (``aggregated_dataset``); ``dataX_new`` / ``dataZ_new`` pass
         already normalised (x||y, z) rows instead."""
+        if self.use_existing_dynamics_model:                     # :463-468: restore instead of training
+            self.dyn_model.load(os.path.join(self.load_dir, "models", "finalModel.npz"))
+            return 0
         if self._train_inputs is None:
             raise RuntimeError("NND_MB_agent was built without training_data")
         if dataX_new is None and dataZ_new is None:
@@ -619,5 +626,12 @@ class NND_MB_agent(NavigationRLAgent):
             zn = np.zeros((0, out_dim)) if dataZ_new is None else np.asarray(dataZ_new)
         nEpoch = self.nEpochs if nEpoch is None else nEpoch
         fraction_use_new = self.fraction_use_new if fraction_use_new is None else fraction_use_new
-        return self.dyn_model.train(self._train_inputs, self._train_outputs, xn, zn, nEpoch, fraction_use_new,
+        loss = self.dyn_model.train(self._train_inputs, self._train_outputs, xn, zn, nEpoch, fraction_use_new,
                                     batchsize=batchsize, lr=lr, rng=rng)
+        if self.save_resulting_dynamics_model:                   # :475-480 (an .npz instead of a TF checkpoint)
+            d = os.path.join(self.save_dir, "models")
+            os.makedirs(d, exist_ok=True)
+            n_train = 1 + self.num_episodes_finished // self.num_episodes_for_aggregation
+            self.dyn_model.save(os.path.join(d, "model_numTrain%d.npz" % n_train))
+            self.dyn_model.save(os.path.join(d, "finalModel.npz"))
+        return loss

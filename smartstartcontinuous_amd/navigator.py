@@ -65,6 +65,26 @@ class DynamicsModel:
         self._image = None
         self.invalidate()
 
+    def save(self, path):
+        """Weights, biases and normalisation statistics as one ``.npz`` (the stand-in for the TF saver of
+        NND_MB_agent.py:470-480; TF checkpoints themselves are out of scope)."""
+        arrays = {f"W{l}": w.cpu().numpy() for l, w in enumerate(self.W)}
+        arrays.update({f"b{l}": b.cpu().numpy() for l, b in enumerate(self.b)})
+        nm = self.norm
+        sd, ad = self.state_dim, self.act_dim
+        for k, n in (("mean_x", sd), ("std_x", sd), ("mean_y", ad), ("std_y", ad), ("mean_z", sd), ("std_z", sd)):
+            arrays[k] = np.asarray([getattr(nm, k)[i] for i in range(n)], np.float64)
+        np.savez(path, **arrays)
+
+    def load(self, path):
+        """Restore what ``save`` wrote (same layer sizes or not: the descriptors are rebuilt)."""
+        z = np.load(path)
+        n = sum(1 for k in z.files if k.startswith("W"))
+        self.set_weights([z[f"W{l}"] for l in range(n)], [z[f"b{l}"] for l in range(n)])
+        self.set_norm({k: z[k] for k in ("mean_x", "std_x", "mean_y", "std_y", "mean_z", "std_z")})
+        if hasattr(self, "_adam"):
+            del self._adam                    # the optimiser state belongs to the old parameters
+
     def invalidate(self):
         """The weights or statistics changed: the packed image of the MFMA path is rebuilt on the next
         call.  ``set_weights``, ``set_norm`` and ``train_step`` call this; code that writes into

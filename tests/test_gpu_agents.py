@@ -188,6 +188,17 @@ def test_navigator_loads_and_saves_training_data_like_the_reference(ssc, golden_
     again = NND_MB_agent(env, None, num_fc_layers=1, depth_fc_layers=32, precision="f32", model_root=str(tmp_path),
                          load_existing_training_data=True, load_dir_name="own")
     assert np.allclose(again.dyn_model.norm.mean_x[0], own.dyn_model.norm.mean_x[0], rtol=1e-6)
+    # the trained model is kept (save_resulting_dynamics_model) and restored (load_existing_dynamics_model, :463-468)
+    own.save_resulting_dynamics_model = True
+    own.train_dynamics_model(nEpoch=2, rng=np.random.RandomState(0))
+    assert (tmp_path / "own" / "models" / "finalModel.npz").exists() and (tmp_path / "own" / "models" / "model_numTrain1.npz").exists()
+    restored = NND_MB_agent(env, None, num_fc_layers=1, depth_fc_layers=32, precision="f32", model_root=str(tmp_path),
+                            load_existing_training_data=True, load_existing_dynamics_model=True, load_dir_name="own", seed=99)
+    assert not torch.equal(restored.dyn_model.W[0], own.dyn_model.W[0])
+    path = np.load(tmp_path / "own" / "training_data" / "states_val.npy")[0]
+    restored.start_new_episode_plan(path[0], path)               # first plan "trains" = restores the saved model
+    assert all(torch.equal(a, b) for a, b in zip(restored.dyn_model.W + restored.dyn_model.b, own.dyn_model.W + own.dyn_model.b))
+    assert bytes(restored.dyn_model.norm) == bytes(own.dyn_model.norm)
 
 
 def test_rl_train_vec_summary(ssc):
