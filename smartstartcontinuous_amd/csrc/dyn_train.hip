@@ -8,9 +8,9 @@
 //     <= 512 units: 1x32 in the examples, 1x500 the class default).  Block b owns 32 batch rows: gather, forward,
 //     output delta, back-propagation and its share of every gradient, all in LDS/registers; the block that
 //     finishes last (atomic ticket) sums the per-block gradients in block order and applies Adam.
-//   * any other feedforward_network shape: gather -> per layer a forward GEMM -> output delta -> per layer
-//     {backward-data GEMM with the ReLU mask, weight-gradient GEMM with Adam in its epilogue}, all on the exact-fp32
-//     MFMA through one 32x32-tile kernel (gemm32_f32_kernel).
+//   * any other feedforward_network shape: gather -> per layer a forward GEMM -> output delta -> per hidden layer a
+//     backward-data GEMM with the ReLU mask -> ONE launch with the weight-gradient GEMMs of all layers, Adam in the
+//     epilogue; all on the exact-fp32 MFMA through one 32x32-tile routine (gemm32_tile).  2 L + 2 launches per step.
 // The bias-corrected step size comes from a device-side step counter, so any number of consecutive steps is
 // enqueued by one call without a host round trip.
 #include <stdlib.h>
@@ -121,8 +121,7 @@ __device__ __forceinline__ void gemm_load4(const float *__restrict__ P, int ld, 
 }
 
 template <bool A_ROWS, bool B_ROWS, int EPI>
-__global__ __launch_bounds__(256) void gemm32_f32_kernel(GemmArgs g) {
-    __shared__ float red[4][16][64];
+__device__ __forceinline__ void gemm32_tile(const GemmArgs &g, float (&red)[4][16][64]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int half = lane >> 5, l32 = lane & 31;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -165,6 +164,24 @@ __global__ __launch_bounds__(256) void gemm32_f32_kernel(GemmArgs g) {
             *th -= g.scal[0] * m1 / (sqrtf(v1) + g.eps);
         }
     }
+}
+
+template <bool A_ROWS, bool B_ROWS, int EPI>
+__global__ __launch_bounds__(256) void gemm32_f32_kernel(GemmArgs g) {
+    __shared__ float red[4][16][64];
+    gemm32_tile<A_ROWS, B_ROWS, EPI>(g, red);
+}
+
+// the weight-gradient GEMMs of ALL layers in one launch (they are independent once every delta exists):
+// blockIdx.z picks the layer, tiles outside its matrix leave at once
+struct GemmBatch {
+    GemmArgs p[SSC_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void gemm32_wgrad_batch_kernel(GemmBatch b) {
+    __shared__ float red[4][16][64];
+    const GemmArgs &g = b.p[blockIdx.z];
+    if ((int)blockIdx.x * 32 >= g.N || (int)blockIdx.y * 32 >= g.M) return;
+    gemm32_tile<false, false, EPI_ADAM>(g, red);
 }
 
 static bool vec_ok(const float *p, int ld, int K) {
@@ -465,10 +482,8 @@ size_t ssc_mlp_train_workspace_bytes(const ssc_mlp_train_desc *net, int32_t B) {
     if (net == nullptr || B <= 0 || net->n_layers < 1 || net->n_layers > SSC_MAX_LAYERS) return 0;
     size_t total = 256;  // scalars
     for (int l = 0; l <= net->n_layers; ++l) total += al256((size_t)B * net->dims[l] * 4);  // activations (0 = x batch)
-    int maxw = 0;
-    for (int l = 0; l <= net->n_layers; ++l) maxw = net->dims[l] > maxw ? net->dims[l] : maxw;
     total += al256((size_t)B * net->dims[net->n_layers] * 4);  // z batch
-    total += 2 * al256((size_t)B * maxw * 4);                  // delta ping-pong
+    for (int l = 1; l <= net->n_layers; ++l) total += al256((size_t)B * net->dims[l] * 4);  // delta of every layer
     if (net->n_layers == 2) {                                  // fused path: ticket + per-block gradients
         const size_t G = ((size_t)B + kFRows - 1) / kFRows;
         const size_t fused = 256 + al256(G * ((size_t)fused_param_count(net) + 1) * 4);
@@ -485,10 +500,8 @@ static int generic_step(const ssc_mlp_train_desc *net, const float *d_X, const f
     float *act[SSC_MAX_LAYERS + 1];
     for (int l = 0; l <= L; ++l) { act[l] = reinterpret_cast<float *>(w); w += al256((size_t)B * net->dims[l] * 4); }
     float *zb = reinterpret_cast<float *>(w); w += al256((size_t)B * net->dims[L] * 4);
-    int maxw = 0;
-    for (int l = 0; l <= L; ++l) maxw = net->dims[l] > maxw ? net->dims[l] : maxw;
-    float *d0 = reinterpret_cast<float *>(w); w += al256((size_t)B * maxw * 4);
-    float *d1 = reinterpret_cast<float *>(w);
+    float *dz[SSC_MAX_LAYERS + 1];      // dz[l]: delta at the output of layer l - 1 (l = 1..L)
+    for (int l = 1; l <= L; ++l) { dz[l] = reinterpret_cast<float *>(w); w += al256((size_t)B * net->dims[l] * 4); }
     const int in = net->dims[0], out = net->dims[L];
     hipLaunchKernelGGL(train_gather_kernel, dim3(blocks_for((int64_t)B * (in > out ? in : out))), dim3(256), 0, s, B, in,
                        out, d_X, d_Z, d_idx, act[0], zb, net->adam_t, net->lr, net->beta1, net->beta2, scal);
@@ -502,26 +515,29 @@ static int generic_step(const ssc_mlp_train_desc *net, const float *d_X, const f
         if (l != L - 1) launch_gemm<true, false, EPI_BIAS_RELU>(g, s);
         else launch_gemm<true, false, EPI_BIAS>(g, s);
     }
-    hipLaunchKernelGGL(train_out_delta_kernel, dim3(1), dim3(kDeltaThreads), 0, s, B * out, act[L], zb, d0, d_loss);
-    float *dz = d0, *dprev = d1;
-    for (int l = L - 1; l >= 0; --l) {
+    hipLaunchKernelGGL(train_out_delta_kernel, dim3(1), dim3(kDeltaThreads), 0, s, B * out, act[L], zb, dz[L], d_loss);
+    for (int l = L - 1; l >= 1; --l) {   // deltas of all layers first: they need the OLD weights
         const int K = net->dims[l], N = net->dims[l + 1];
-        if (l > 0) {   // delta of the previous layer from the OLD weights, before Adam touches them
-            g = GemmArgs{};
-            g.A = dz; g.lda = N; g.B = net->W[l]; g.ldb = N; g.M = B; g.N = K; g.K = N;
-            g.a_vec = vec_ok(dz, N, N); g.b_vec = vec_ok(net->W[l], N, N); g.ones_row = -1;
-            g.C = dprev; g.ldc = K; g.mask = act[l]; g.ldmask = K;
-            launch_gemm<true, true, EPI_MASK>(g, s);
-        }
-        // dW = act[l]^T dz with a row of ones appended (-> db); Adam in the epilogue
         g = GemmArgs{};
-        g.A = act[l]; g.lda = K; g.B = dz; g.ldb = N; g.M = K + 1; g.N = N; g.K = B;
-        g.ones_row = K;
-        g.W = net->W[l]; g.mW = net->mW[l]; g.vW = net->vW[l]; g.bb = net->b[l]; g.mb = net->mb[l]; g.vb = net->vb[l];
-        g.scal = scal; g.beta1 = net->beta1; g.beta2 = net->beta2; g.eps = net->epsilon;
-        launch_gemm<false, false, EPI_ADAM>(g, s);
-        float *t = dz; dz = dprev; dprev = t;
+        g.A = dz[l + 1]; g.lda = N; g.B = net->W[l]; g.ldb = N; g.M = B; g.N = K; g.K = N;
+        g.a_vec = vec_ok(dz[l + 1], N, N); g.b_vec = vec_ok(net->W[l], N, N); g.ones_row = -1;
+        g.C = dz[l]; g.ldc = K; g.mask = act[l]; g.ldmask = K;
+        launch_gemm<true, true, EPI_MASK>(g, s);
     }
+    // dW_l = act[l]^T dz[l + 1] with a row of ones appended (-> db_l), Adam in the epilogue: one launch for all layers
+    GemmBatch batch{};
+    int gx = 0, gy = 0;
+    for (int l = 0; l < L; ++l) {
+        const int K = net->dims[l], N = net->dims[l + 1];
+        GemmArgs &q = batch.p[l];
+        q.A = act[l]; q.lda = K; q.B = dz[l + 1]; q.ldb = N; q.M = K + 1; q.N = N; q.K = B;
+        q.ones_row = K;
+        q.W = net->W[l]; q.mW = net->mW[l]; q.vW = net->vW[l]; q.bb = net->b[l]; q.mb = net->mb[l]; q.vb = net->vb[l];
+        q.scal = scal; q.beta1 = net->beta1; q.beta2 = net->beta2; q.eps = net->epsilon;
+        gx = (N + 31) / 32 > gx ? (N + 31) / 32 : gx;
+        gy = (K + 1 + 31) / 32 > gy ? (K + 1 + 31) / 32 : gy;
+    }
+    hipLaunchKernelGGL(gemm32_wgrad_batch_kernel, dim3(gx, gy, L), dim3(256), 0, s, batch);
     return SSC_OK;
 }
 
