@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=4)
     ap.add_argument("--follow-steps", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--precision", choices=["bf16_mfma", "f32"], default="bf16_mfma",
+                    help="forward simulation of the MPC: bf16 MFMA kernel (default) or the fp32 parity path")
     args = ap.parse_args()
     env1 = ssc.make("MountainCarContinuous-v0", seed=args.seed)
 
@@ -49,7 +51,7 @@ def main():
     host = lambda t: t.cpu().numpy()
     norm = dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz))
     Ws, bs = init_dynamics_weights(3, 2, args.layers, args.depth, torch.Generator().manual_seed(args.seed))
-    model = nav.DynamicsModel(Ws, bs, norm, 2, 1, precision="f32")
+    model = nav.DynamicsModel(Ws, bs, norm, 2, 1, precision=args.precision)
     t0 = time.perf_counter()
     loss = model.train(inputs, outputs, np.zeros((0, 3)), np.zeros((0, 2)), args.epochs, 0.0,
                        rng=np.random.RandomState(args.seed))
