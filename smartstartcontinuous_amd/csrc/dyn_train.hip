@@ -8,9 +8,10 @@
 //     <= 512 units: 1x32 in the examples, 1x500 the class default).  Block b owns 32 batch rows: gather, forward,
 //     output delta, back-propagation and its share of every gradient, all in LDS/registers; the block that
 //     finishes last (atomic ticket) sums the per-block gradients in block order and applies Adam.
-//   * any other feedforward_network shape: gather -> per layer a forward GEMM -> output delta -> per hidden layer a
-//     backward-data GEMM with the ReLU mask -> ONE launch with the weight-gradient GEMMs of all layers, Adam in the
-//     epilogue; all on the exact-fp32 MFMA through one 32x32-tile routine (gemm32_tile).  2 L + 2 launches per step.
+//   * any other feedforward_network shape: gather -> per layer a forward GEMM (the output layer's epilogue leaves the
+//     output delta and per-tile loss sums) -> per hidden layer a backward-data GEMM with the ReLU mask -> ONE launch
+//     with the weight-gradient GEMMs of all layers, Adam in the epilogue; all on the exact-fp32 MFMA through one
+//     32x32-tile routine (gemm32_tile).  2 L + 1 launches per step.
 // The bias-corrected step size comes from a device-side step counter, so any number of consecutive steps is
 // enqueued by one call without a host round trip.
 #include <stdlib.h>
@@ -42,30 +43,6 @@ __global__ __launch_bounds__(256) void train_gather_kernel(int B, int in, int ou
     }
 }
 
-// dY = 2 (y - z) / (B * out)   (d mean((z - y)^2) / dy, dynamics_model.py:41) and the batch MSE; ONE block, fixed
-// summation order
-constexpr int kDeltaThreads = 1024;
-__global__ __launch_bounds__(kDeltaThreads) void train_out_delta_kernel(int n, const float *__restrict__ y,
-                                                                        const float *__restrict__ z, float *__restrict__ dy,
-                                                                        float *__restrict__ loss) {
-    __shared__ float part[kDeltaThreads / 64];
-    float l = 0.0f;
-    for (int e = threadIdx.x; e < n; e += kDeltaThreads) {
-        const float d = y[e] - z[e];
-        dy[e] = 2.0f * d / (float)n;
-        l = fmaf(d, d, l);
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
-    __syncthreads();
-    if (threadIdx.x == 0 && loss != nullptr) {
-        float a = 0.0f;
-        for (int w = 0; w < kDeltaThreads / 64; ++w) a += part[w];
-        loss[0] = a / (float)n;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // The three GEMMs of a layer on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32):
 //   forward   Y  = act(X W + b)         A = X  [B x K] rows,      B = W  [K x N] rows
@@ -79,7 +56,7 @@ __global__ __launch_bounds__(kDeltaThreads) void train_out_delta_kernel(int n, c
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_ADAM = 3 };
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_ADAM = 3, EPI_DELTA = 4 };
 
 struct GemmArgs {
     const float *A, *B;
@@ -89,6 +66,8 @@ struct GemmArgs {
     float *C; int ldc;             // EPI_BIAS / EPI_BIAS_RELU / EPI_MASK
     const float *bias;             // EPI_BIAS*
     const float *mask; int ldmask; // EPI_MASK
+    const float *z; float delta_scale; float *loss_part;   // EPI_DELTA: C = (acc + bias - z) * delta_scale (the output
+                                   // delta, d mean((z - y)^2) / dy, dynamics_model.py:41); loss_part[tile] = sum (y - z)^2
     float *W, *mW, *vW, *bb, *mb, *vb;   // EPI_ADAM: W [M - 1 or M][N], bias [N]
     const float *scal;             // scal[0] = lr_t
     float beta1, beta2, eps;
@@ -143,6 +122,7 @@ __device__ __forceinline__ void gemm32_tile(const GemmArgs &g, float (&red)[4][1
     __syncthreads();
     // wave w finishes accumulator registers 4w .. 4w + 3: rows m0 + 8w + 4 half + (i & 3), column n0 + l32
     const int n = n0 + l32;
+    float lsum = 0.0f;
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
         const int i = 4 * w + ii;
@@ -154,6 +134,10 @@ __device__ __forceinline__ void gemm32_tile(const GemmArgs &g, float (&red)[4][1
             g.C[(int64_t)m * g.ldc + n] = EPI == EPI_BIAS_RELU ? fmaxf(y, 0.0f) : y;
         } else if (EPI == EPI_MASK) {
             g.C[(int64_t)m * g.ldc + n] = g.mask[(int64_t)m * g.ldmask + n] > 0.0f ? v : 0.0f;
+        } else if (EPI == EPI_DELTA) {
+            const float d = v + g.bias[n] - g.z[(int64_t)m * g.ldc + n];
+            g.C[(int64_t)m * g.ldc + n] = d * g.delta_scale;
+            lsum = fmaf(d, d, lsum);
         } else {
             float *th, *mm, *vv;
             if (m == g.ones_row) { th = g.bb + n; mm = g.mb + n; vv = g.vb + n; }
@@ -163,6 +147,15 @@ __device__ __forceinline__ void gemm32_tile(const GemmArgs &g, float (&red)[4][1
             *mm = m1; *vv = v1;
             *th -= g.scal[0] * m1 / (sqrtf(v1) + g.eps);
         }
+    }
+    if (EPI == EPI_DELTA) {      // sum (y - z)^2 of this tile, fixed order: lanes (butterfly), then waves 0..3
+        __shared__ float lpart[4];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o);
+        if (lane == 0) lpart[w] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            g.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = ((lpart[0] + lpart[1]) + lpart[2]) + lpart[3];
     }
 }
 
@@ -176,9 +169,18 @@ __global__ __launch_bounds__(256) void gemm32_f32_kernel(GemmArgs g) {
 // blockIdx.z picks the layer, tiles outside its matrix leave at once
 struct GemmBatch {
     GemmArgs p[SSC_MAX_LAYERS];
+    const float *loss_part;      // per-tile sums of (y - z)^2 left by the EPI_DELTA GEMM
+    int n_loss_part;
+    float loss_scale;            // 1 / (B * out)
+    float *loss;                 // [1] or NULL
 };
 __global__ __launch_bounds__(256) void gemm32_wgrad_batch_kernel(GemmBatch b) {
     __shared__ float red[4][16][64];
+    if (b.loss != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        float a = 0.0f;                                    // the batch MSE, tiles summed in order
+        for (int i = 0; i < b.n_loss_part; ++i) a += b.loss_part[i];
+        b.loss[0] = a * b.loss_scale;
+    }
     const GemmArgs &g = b.p[blockIdx.z];
     if ((int)blockIdx.x * 32 >= g.N || (int)blockIdx.y * 32 >= g.M) return;
     gemm32_tile<false, false, EPI_ADAM>(g, red);
@@ -484,6 +486,7 @@ size_t ssc_mlp_train_workspace_bytes(const ssc_mlp_train_desc *net, int32_t B) {
     for (int l = 0; l <= net->n_layers; ++l) total += al256((size_t)B * net->dims[l] * 4);  // activations (0 = x batch)
     total += al256((size_t)B * net->dims[net->n_layers] * 4);  // z batch
     for (int l = 1; l <= net->n_layers; ++l) total += al256((size_t)B * net->dims[l] * 4);  // delta of every layer
+    total += al256((((size_t)B + 31) / 32) * (((size_t)net->dims[net->n_layers] + 31) / 32) * 4);  // per-tile loss sums
     if (net->n_layers == 2) {                                  // fused path: ticket + per-block gradients
         const size_t G = ((size_t)B + kFRows - 1) / kFRows;
         const size_t fused = 256 + al256(G * ((size_t)fused_param_count(net) + 1) * 4);
@@ -502,6 +505,7 @@ static int generic_step(const ssc_mlp_train_desc *net, const float *d_X, const f
     float *zb = reinterpret_cast<float *>(w); w += al256((size_t)B * net->dims[L] * 4);
     float *dz[SSC_MAX_LAYERS + 1];      // dz[l]: delta at the output of layer l - 1 (l = 1..L)
     for (int l = 1; l <= L; ++l) { dz[l] = reinterpret_cast<float *>(w); w += al256((size_t)B * net->dims[l] * 4); }
+    float *loss_part = reinterpret_cast<float *>(w);     // [(B/32) x (out/32) tiles]
     const int in = net->dims[0], out = net->dims[L];
     hipLaunchKernelGGL(train_gather_kernel, dim3(blocks_for((int64_t)B * (in > out ? in : out))), dim3(256), 0, s, B, in,
                        out, d_X, d_Z, d_idx, act[0], zb, net->adam_t, net->lr, net->beta1, net->beta2, scal);
@@ -512,10 +516,13 @@ static int generic_step(const ssc_mlp_train_desc *net, const float *d_X, const f
         g.A = act[l]; g.lda = K; g.B = net->W[l]; g.ldb = N; g.M = B; g.N = N; g.K = K;
         g.a_vec = vec_ok(act[l], K, K); g.ones_row = -1;
         g.C = act[l + 1]; g.ldc = N; g.bias = net->b[l];
-        if (l != L - 1) launch_gemm<true, false, EPI_BIAS_RELU>(g, s);
-        else launch_gemm<true, false, EPI_BIAS>(g, s);
+        if (l != L - 1) {
+            launch_gemm<true, false, EPI_BIAS_RELU>(g, s);
+        } else {       // the output layer leaves the output delta and the per-tile loss sums, not y
+            g.C = dz[L]; g.z = zb; g.delta_scale = 2.0f / (float)((int64_t)B * out); g.loss_part = loss_part;
+            launch_gemm<true, false, EPI_DELTA>(g, s);
+        }
     }
-    hipLaunchKernelGGL(train_out_delta_kernel, dim3(1), dim3(kDeltaThreads), 0, s, B * out, act[L], zb, dz[L], d_loss);
     for (int l = L - 1; l >= 1; --l) {   // deltas of all layers first: they need the OLD weights
         const int K = net->dims[l], N = net->dims[l + 1];
         g = GemmArgs{};
@@ -537,6 +544,8 @@ static int generic_step(const ssc_mlp_train_desc *net, const float *d_X, const f
         gx = (N + 31) / 32 > gx ? (N + 31) / 32 : gx;
         gy = (K + 1 + 31) / 32 > gy ? (K + 1 + 31) / 32 : gy;
     }
+    batch.loss_part = loss_part; batch.n_loss_part = ((B + 31) / 32) * ((out + 31) / 32);
+    batch.loss_scale = 1.0f / (float)((int64_t)B * out); batch.loss = d_loss;
     hipLaunchKernelGGL(gemm32_wgrad_batch_kernel, dim3(gx, gy, L), dim3(256), 0, s, batch);
     return SSC_OK;
 }
