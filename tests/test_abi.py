@@ -58,6 +58,41 @@ def test_argument_validation_without_gpu(built):
     assert lib.ssc_mc_step(ctypes.byref(_ffi.default_params(0)), 0, None, None, None, None, None, None, None) == 0
 
 
+def test_argument_validation_of_the_dataset_and_training_entry_points(built):
+    """Negative sizes, NULL pointers, unsupported column counts and too-small workspaces come back as SSC_EINVAL
+    with a message -- before any HIP call, so this runs without a GPU.  Empty inputs are fine where they mean
+    'nothing to do'."""
+    from smartstartcontinuous_amd import _ffi
+    lib = _ffi.lib()
+    log = _ffi.TransitionLog()
+    E = _ffi.SSC_EINVAL
+    assert lib.ssc_dataset_scan(None, 4, 8, None, None, None, 0, None) == E
+    assert lib.ssc_dataset_scan(ctypes.byref(log), -1, 8, None, None, None, 0, None) == E
+    assert lib.ssc_dataset_scan(ctypes.byref(log), 4, 8, None, None, None, 0, None) == E and b"d_off" in lib.ssc_last_error()
+    assert lib.ssc_dataset_scan_workspace_bytes(65536) == (65536 // 64 + 1) * 8 and lib.ssc_dataset_scan_workspace_bytes(-1) == 0
+    assert lib.ssc_dataset_build(ctypes.byref(log), 0, 4, 8, None, None, 10, None, None, None, None) == E      # obs_dim
+    assert lib.ssc_dataset_build(ctypes.byref(log), 2, 4, 8, None, None, 10, None, None, None, None) == E      # NULL
+    assert lib.ssc_dataset_build(ctypes.byref(log), 2, 1, 8, None, None, 10, None, None, None, None) == 0      # K = 1: no rows
+    assert lib.ssc_dataset_build(ctypes.byref(log), 2, 4, 0, None, None, 10, None, None, None, None) == 0      # no envs
+    assert lib.ssc_column_stats_workspace_bytes(3) == 2048 * 3 * 8 and lib.ssc_column_stats_workspace_bytes(65) == 0
+    assert lib.ssc_column_stats(None, 10, 65, None, None, None, 0, None) == E
+    assert lib.ssc_column_stats(None, 0, 3, None, None, None, 0, None) == E and b"at least one row" in lib.ssc_last_error()
+    assert lib.ssc_zscore(None, 5, 3, None, None, None, 2, 0, None) == E                                       # out_stride < cols
+    assert lib.ssc_zscore(None, 0, 3, None, None, None, 4, 1, None) == 0
+    assert lib.ssc_add_noise(None, 5, 300, None, 0.01, 1, 0, None) == E
+    assert lib.ssc_add_noise(None, 5, 3, None, 0.01, 1, 1 << 50, None) == E and b"stream_id" in lib.ssc_last_error()
+    assert lib.ssc_add_noise(None, 0, 3, None, 0.01, 1, 0, None) == 0
+    net = _ffi.MlpTrainDesc()
+    net.n_layers = 2
+    net.dims[0], net.dims[1], net.dims[2] = 3, 32, 2
+    assert lib.ssc_mlp_train_workspace_bytes(ctypes.byref(net), 512) > 0 and lib.ssc_mlp_train_workspace_bytes(None, 512) == 0
+    assert lib.ssc_mlp_train_steps(ctypes.byref(net), None, None, None, 512, 3, None, None, 0, None) == E       # NULL parameters
+    assert lib.ssc_mlp_train_steps(ctypes.byref(net), None, None, None, 0, 3, None, None, 0, None) == E         # batch 0
+    net.n_layers = 9
+    assert lib.ssc_mlp_train_steps(ctypes.byref(net), None, None, None, 512, 1, None, None, 0, None) == E and \
+        b"n_layers" in lib.ssc_last_error()
+
+
 def test_struct_layouts_match_header(built, tmp_path):
     """sizeof() of every descriptor struct as the C compiler sees it == ctypes.sizeof."""
     import subprocess
