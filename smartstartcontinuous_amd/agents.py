@@ -426,8 +426,8 @@ class NND_MB_agent(NavigationRLAgent):
             # :203-213 -- e.g. the reference's own models/NND_MB_agent/default/training_data/*.npy
             d = os.path.join(self.load_dir, "training_data")
             training_data = {k: np.load(os.path.join(d, k + ".npy")) for k in ("dataX", "dataY", "dataZ")}
-            self.states_val = np.load(os.path.join(d, "states_val.npy"))
-            self.controls_val = np.load(os.path.join(d, "controls_val.npy"))
+            self.states_val = np.load(os.path.join(d, "states_val.npy"), allow_pickle=True)
+            self.controls_val = np.load(os.path.join(d, "controls_val.npy"), allow_pickle=True)
         if norm is None and training_data is None:
             norm = self._collect_training_data(num_rollouts_train, steps_per_rollout_train, num_rollouts_val,
                                                steps_per_rollout_val, make_training_dataset_noisy)
@@ -448,8 +448,16 @@ class NND_MB_agent(NavigationRLAgent):
             for k in ("dataX", "dataY", "dataZ"):
                 np.save(os.path.join(d, k + ".npy"), np.asarray(src[k], np.float64))
             if self.states_val is not None:
-                np.save(os.path.join(d, "states_val.npy"), np.asarray(self.states_val))
-                np.save(os.path.join(d, "controls_val.npy"), np.asarray(self.controls_val))
+                def stacked(rollouts):       # equal-length rollouts stack; ragged ones (a rollout hit a terminal state)
+                    same = len({len(r) for r in rollouts}) <= 1          # become an object array, as numpy 1.15 made them
+                    if same:
+                        return np.asarray(rollouts)
+                    out = np.empty(len(rollouts), dtype=object)
+                    for i, r in enumerate(rollouts):
+                        out[i] = np.asarray(r)
+                    return out
+                np.save(os.path.join(d, "states_val.npy"), stacked(self.states_val), allow_pickle=True)
+                np.save(os.path.join(d, "controls_val.npy"), stacked(self.controls_val), allow_pickle=True)
         if weights is None:
             gen = torch.Generator().manual_seed(self.seed)
             weights, biases = init_dynamics_weights(state_dim + act_dim, state_dim, num_fc_layers, depth_fc_layers, gen)
