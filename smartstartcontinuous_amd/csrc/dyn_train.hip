@@ -110,12 +110,32 @@ __device__ __forceinline__ void gemm32_tile(const GemmArgs &g, float (&red)[4][1
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    for (int k8 = kb; k8 < ke; k8 += 8) {
-        float a[4], b[4];
-        gemm_load4<A_ROWS>(g.A, g.lda, m0 + l32, a_lim, k8 + 4 * half, ke, g.a_vec, A_ROWS ? -1 : g.ones_row, a);
-        gemm_load4<B_ROWS>(g.B, g.ldb, n0 + l32, g.N, k8 + 4 * half, ke, g.b_vec, -1, b);
+    // Chunks of 4 k-groups (32 k values), double-buffered: the operands of chunk c + 1 are requested before the 16
+    // MFMAs of chunk c, so a chunk costs max(load latency, MFMA time) instead of one load latency per k-group.
+    constexpr int CH = 4;
+    float a[2][CH][4], b[2][CH][4];
+    auto load_chunk = [&](int buf, int k0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+        for (int u = 0; u < CH; ++u) {      // past ke the loaders return zeros
+            gemm_load4<A_ROWS>(g.A, g.lda, m0 + l32, a_lim, k0 + 8 * u + 4 * half, ke, g.a_vec, A_ROWS ? -1 : g.ones_row,
+                               a[buf][u]);
+            gemm_load4<B_ROWS>(g.B, g.ldb, n0 + l32, g.N, k0 + 8 * u + 4 * half, ke, g.b_vec, -1, b[buf][u]);
+        }
+    };
+    auto mfma_chunk = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u][r], b[buf][u][r], acc, 0, 0, 0);
+    };
+    if (kb < ke) load_chunk(0, kb);
+    for (int k0 = kb; k0 < ke; k0 += 16 * CH) {      // two chunks per trip: static buffer indices
+        if (k0 + 8 * CH < ke) load_chunk(1, k0 + 8 * CH);
+        mfma_chunk(0);
+        if (k0 + 8 * CH < ke) {
+            if (k0 + 16 * CH < ke) load_chunk(0, k0 + 16 * CH);
+            mfma_chunk(1);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[i];
