@@ -33,71 +33,29 @@ GATHER_RECORDS = 1 << 20      # bounded gather: last G steps with G * N_total <=
 
 
 def cpu_baseline(budget_s=24.0):
-    """The CPU oracle timed on this box's host cores on a bounded sample of the same workload
-    (kind "port": the reference's Python/TF cannot travel)."""
-    import ctypes
-    import subprocess
+    """The CPU oracle timed on this box's host cores on a bounded sample of the same workload (kind "port": the
+    reference's Python/TF cannot travel).  SURVEY.md section 8(d): `value` = P independent scalar
+    rlTrain processes, P = the cores this process may use (stated as `cores`); the numpy-vectorised and C
+    restatements on 1 and P cores ride along as the "strong CPU" lines."""
+    from oracle import cpu_baseline as cb
+    return cb.run(budget_s, N_ENVS_PER_GPU)
 
-    import numpy as np
 
-    from oracle import ssc_oracle as O
+def dist_stats(ms):
+    """min / median / p90 / mean of a list of per-launch durations (ms)."""
+    v = sorted(ms)
+    n = len(v)
+    return {"n": n, "min": v[0], "median": v[n // 2], "p90": v[min(n - 1, int(0.9 * n))], "max": v[-1], "mean": sum(v) / n}
 
-    out = {}
-    # (1) numpy-vectorised fp64 oracle, 65 536 envs, random policy with the engine RNG, 1 core
-    n = N_ENVS_PER_GPU
-    ids = np.arange(n, dtype=np.uint64)
-    pos, vel = O.mc_reset_state(1234, ids, O.RESET_T0)
-    pos, vel = pos.astype(np.float64), vel.astype(np.float64)
-    el = np.zeros(n, np.int64)
-    t0 = time.perf_counter()
-    k = 0
-    while time.perf_counter() - t0 < budget_s / 3:
-        a = O.random_policy_actions(1234, ids, k).astype(np.float64)
-        pos, vel, r, d = O.mc_step(pos, vel, a)
-        el += 1
-        d = O.time_limit(d, el, 999)
-        if d.any():
-            rp, _ = O.mc_reset_state(1234, ids, k)
-            pos = np.where(d, rp, pos)
-            vel = np.where(d, 0.0, vel)
-            el = np.where(d, 0, el)
-        k += 1
-    dt = time.perf_counter() - t0
-    out["value"] = n * k / dt
-    out["sample"] = f"numpy fp64 oracle, {n} envs x {k} steps (random policy, engine RNG), {dt:.1f} s"
-    # (2) the reference's execution model: one env, scalar Python loop (rlTrain.py:63-114)
-    env = O.ScalarMountainCar(1.0, 999, seed=1234)
-    rng = np.random.RandomState(1234)
-    t0 = time.perf_counter()
-    total = 0
-    while time.perf_counter() - t0 < budget_s / 3:
-        _, steps = O.rl_train_scalar(env, lambda obs: rng.uniform(-1.0, 1.0, (1,)), num_episodes=3, max_steps=1000)
-        total += steps
-    out["scalar_python_steps_per_s"] = total / (time.perf_counter() - t0)
-    # (3) C scalar restatement, same RNG, 1 core
-    try:
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
-        lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libssc_oracle.so"))
-        lib.ssc_oracle_mc_rollout_random.restype = ctypes.c_int64
-        nn, K = 4096, 256
-        p, v = O.mc_reset_state(1234, np.arange(nn, dtype=np.uint64), O.RESET_T0)
-        p, v = p.astype(np.float64), v.astype(np.float64)
-        st = np.zeros(nn, np.int32)
-        dp = ctypes.POINTER(ctypes.c_double)
-        t0 = time.perf_counter()
-        done_steps, step0 = 0, 0
-        while time.perf_counter() - t0 < budget_s / 3:
-            done_steps += lib.ssc_oracle_mc_rollout_random(
-                ctypes.c_int64(nn), ctypes.c_int32(K), p.ctypes.data_as(dp), v.ctypes.data_as(dp),
-                st.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.c_double(0.0015), ctypes.c_int32(999),
-                ctypes.c_uint64(1234), ctypes.c_uint64(0), ctypes.c_uint64(step0), None)
-            step0 += K
-        out["c_scalar_steps_per_s"] = done_steps / (time.perf_counter() - t0)
-    except Exception as e:  # the C half is optional for the baseline
-        out["c_scalar_steps_per_s"] = None
-        out["c_scalar_error"] = str(e)
-    out.update(unit="env-steps/s", cores=1, kind="port")
-    return out
+
+def source_sha():
+    """sha256 over the sources of the headline kernel; profiles/*/traffic.json carries the same stamp, so a PMC
+    figure measured on other code is reported as stale instead of silently riding along."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rollout.hip", "ssc_device.h"):
+        h.update(open(os.path.join(ROOT, "smartstartcontinuous_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def bench_config3(args, torch):
@@ -122,7 +80,8 @@ def bench_config3(args, torch):
         a.record(); env.rollout(K, out=chunk, policy_desc=pd); b.record()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    kms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
+    per = [a.elapsed_time(b) for a, b in evs]
+    kms = sum(per) / args.steps
     rate = n * K * args.steps / el
     mfma_flops = 2.0 * 64 * 32 + 2.0 * 2 * 64          # hidden GEMM (bf16 MFMA) + layer 1 (fp32 MFMA) per env-step
     res = {"metric": "env-steps/sec, 65 536 MountainCar envs + DDPG actor 64-32 fwd (bf16 MFMA) + OU noise", "value": rate,
@@ -130,10 +89,14 @@ def bench_config3(args, torch):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (hidden GEMM), f32 elsewhere",
            "data": "synthetic", "config": {"workload": "BASELINE configs[2]: MountainCarContinuous-v0, %d envs, actor 64-32 "
                                           "lastLayerTanh, OU mu0.4 sigma0.6 theta0.15, %d env-steps per launch, full log" % (n, K)},
-           "roofline": {"bound": "mfma", "achieved": mfma_flops * n * K / (kms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                        "frac": mfma_flops * n * K / (kms * 1e-3) / 1e12 / 2500.0, "traffic": None, "kernel_ms": kms,
-                        "note": "VALU/transcendental-bound (33 tanh + 96 relu/convert per env-step); MFMA is ~15%% of issue; "
-                                "log traffic %.0f GB/s" % (25.0 * n * K / (kms * 1e-3) / 1e9)}}
+           "roofline": {"bound": "hbm", "achieved": 25.0 * n * K / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": 25.0 * n * K / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kms,
+                        "kernel_ms_dist": dist_stats(per),
+                        "mfma_tflops": mfma_flops * n * K / (kms * 1e-3) / 1e12,
+                        "mfma_frac_of_bf16_peak": mfma_flops * n * K / (kms * 1e-3) / 1e12 / 2500.0,
+                        "note": "neither contract roof binds: the kernel is VALU/transcendental-ISSUE-bound (33 tanh + 96 "
+                                "relu/convert + OU Box-Muller per env-step); reported against the HBM roof of its 25 B/step "
+                                "log (the only HBM traffic), with the MFMA-eligible rate beside it"}}
     if not args.no_cpu_baseline:
         wn = {k: v.numpy() for k, v in w.items()}
         obs = np.random.default_rng(0).uniform(-1, 1, (n, 2)).astype(np.float32)
@@ -251,18 +214,69 @@ def bench_config4(args, torch):
 
 def profiled_traffic():
     """HBM bytes per launch of the rollout kernel from the committed rocprofv3 PMC passes
-    (profiles/<tag>/traffic.json: WRITE_SIZE*1024 + 2*FETCH_SIZE*1024, gfx950 correction) -- the
-    counters cannot be read from inside the process, so the latest committed profile of this same
-    command is reported, or None."""
+    (profiles/<tag>/traffic.json: WRITE_SIZE*1024 + 2*FETCH_SIZE*1024, gfx950 correction) -- the counters cannot
+    be read from inside the process, so the latest committed profile of this same command is reported, but ONLY
+    when it was taken on the same kernel sources (`source_sha`); otherwise (None, "stale: ...")."""
     import glob
     best = None
+    sha = source_sha()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
         try:
             d = json.load(open(f))
-            best = (d["write_bytes"] + d["fetch_bytes_corrected"], os.path.relpath(f, ROOT))
+            rel = os.path.relpath(f, ROOT)
+            if d.get("source_sha") == sha:
+                best = (d["write_bytes"] + d["fetch_bytes_corrected"], rel)
+            elif best is None or best[0] is None:
+                best = (None, "stale: %s was measured on kernel sources %s, this build is %s"
+                        % (rel, d.get("source_sha", "<unstamped>"), sha))
         except Exception:
             pass
     return best
+
+
+def single_step_api(env, torch, steps=200):
+    """the gym-shaped single-step API (`ssc_mc_step`, one launch per env-step,
+    actions pre-generated in HBM) on the same 65 536 envs -- launch/L2-bound by construction (1.6 MB per step),
+    which is why the fused rollout exists.  -> dict (env-steps/s through the Python/ctypes call path, kernel us)."""
+    import ctypes
+
+    from smartstartcontinuous_amd import _ffi
+    n = env.n
+    acts = torch.rand((64, n), device=env.device) * 2.0 - 1.0            # pre-generated, resident
+    rew = torch.empty(n, device=env.device)
+    done = torch.empty(n, dtype=torch.uint8, device=env.device)
+    pos, vel, st = env.s0.clone(), env.s1.clone(), torch.zeros(n, dtype=torch.int32, device=env.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call(i):
+        _ffi.check(env.lib.ssc_mc_step(ctypes.byref(env.params), n, _ffi.ptr(pos), _ffi.ptr(vel), _ffi.ptr(acts[i & 63]),
+                                       _ffi.ptr(rew), _ffi.ptr(done), _ffi.ptr(st), stream))
+    for i in range(20):
+        call(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        call(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    # the same launches replayed from a HIP graph: the kernel + launch-boundary cost without the Python call path
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(64):
+            call(i)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us_graph = e0.elapsed_time(e1) * 1e3 / 256
+    return {"value": n * steps / el, "unit": "env-steps/s", "us_per_call": el / steps * 1e6,
+            "graph_replay_us_per_step": us_graph, "graph_replay_env_steps_per_s": n / (us_graph * 1e-6),
+            "hbm_frac_at_graph_rate": 25.0 * n / (us_graph * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "note": "ssc_mc_step, one launch per env-step, actions pre-generated in HBM; launch/L2-bound (1.6 MB per step)"}
 
 
 def main():
@@ -278,6 +292,10 @@ def main():
                     help="initialise the RCCL process group and run the gather path even at world size 1 "
                          "(single-GPU rehearsal of the N>1 code path)")
     ap.add_argument("--cpu-budget", type=float, default=24.0)
+    ap.add_argument("--steady-launches", type=int, default=400,
+                    help="extra untimed-for-`value` launches after the timed region whose per-launch distribution is "
+                         "reported as roofline.steady (N = 1 only; 0 disables)")
+    ap.add_argument("--no-single-step", action="store_true", help="skip the single-step-API (ssc_mc_step) line")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
                     help="BASELINE.json config (1-based): 2 = headline random-policy rollout (default), "
                          "3 = + DDPG actor MFMA, 4 = NND_MB 2x500 forward sim + MPC")
@@ -352,7 +370,22 @@ def main():
         gather.finish()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, args.steps)
+    per_launch = [a.elapsed_time(b) for a, b in evs]
+    kernel_ms = sum(per_launch) / max(1, args.steps)
+
+    # Steady-state leg (outside the timed region, N = 1): the launches of a short timed window start from an idle
+    # power state and slow down as the chip settles; `steady` is the distribution over
+    # --steady-launches further back-to-back launches of the same kernel.
+    steady = None
+    if world == 1 and args.steady_launches > 0 and gather is None:
+        sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steady_launches)]
+        for i, ev in enumerate(sev):
+            one_step(args.warmup + args.steps + i, ev)
+        torch.cuda.synchronize()
+        sl = [a.elapsed_time(b) for a, b in sev]
+        steady = dist_stats(sl[len(sl) // 4:])            # the settled three quarters
+        steady["first_quarter_mean"] = sum(sl[:len(sl) // 4]) / max(1, len(sl) // 4)
+        steady["launches"] = args.steady_launches
 
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -393,12 +426,20 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": "ssc::rollout_kernel<McEnv, RandomPolicy<2>>",
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
+                "kernel_ms_dist": dist_stats(per_launch),
             },
         }
+        if steady is not None:
+            steady["frac_at_median"] = per_launch_bytes / (steady["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            steady["frac_at_min"] = per_launch_bytes / (steady["min"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            steady["frac_at_p90"] = per_launch_bytes / (steady["p90"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            result["roofline"]["steady"] = steady
         tr = profiled_traffic()
         if tr is not None and n == N_ENVS_PER_GPU and K == CHUNK:
             result["roofline"]["traffic"] = tr[0]
             result["roofline"]["traffic_source"] = tr[1]
+        if world == 1 and not args.no_single_step and n == N_ENVS_PER_GPU:
+            result["single_step_api"] = single_step_api(env, torch)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(result), flush=True)

@@ -5,6 +5,9 @@
 #include <cstdint>
 #include <vector>
 #include <algorithm>
+#include <string>
+#include <ctime>
+#include <cstdlib>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -106,12 +109,43 @@ float time_ms(F f, int reps = 10) {
     return t[t.size() / 2];
 }
 
-int main() {
+// `membw series N`: N back-to-back launches of one shape, every launch bracketed by its own pair of events and
+// no host sync inside the series -- the per-launch durations as a TIME SERIES (one JSON line per shape), so that a
+// "ceiling" is a distribution under sustained load and not the median of ten launches after an idle gap.
+template <typename F>
+int series(const char *name, double bytes_per_launch, int n_launch, F f) {
+    std::vector<hipEvent_t> ev(2 * (size_t)n_launch);
+    for (auto &evt : ev) CK(hipEventCreate(&evt));
+    f(); f(); CK(hipDeviceSynchronize());
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double t0 = ts.tv_sec + 1e-9 * ts.tv_nsec;
+    for (int i = 0; i < n_launch; ++i) { CK(hipEventRecord(ev[2 * i])); f(); CK(hipEventRecord(ev[2 * i + 1])); }
+    CK(hipDeviceSynchronize());
+    printf("{\"shape\": \"%s\", \"bytes_per_launch\": %.0f, \"t0_monotonic\": %.6f, \"start_us\": [", name, bytes_per_launch, t0);
+    for (int i = 0; i < n_launch; ++i) { float ms; hipEventElapsedTime(&ms, ev[0], ev[2 * i]); printf("%s%.1f", i ? "," : "", ms * 1e3); }
+    printf("], \"dur_us\": [");
+    for (int i = 0; i < n_launch; ++i) { float ms; hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]); printf("%s%.1f", i ? "," : "", ms * 1e3); }
+    printf("]}\n");
+    fflush(stdout);
+    for (auto &evt : ev) hipEventDestroy(evt);
+    return 0;
+}
+
+int main(int argc, char **argv) {
     const size_t bytes = (size_t)2 << 30;
     float *p; uint8_t *b;
     CK(hipMalloc(&p, bytes)); CK(hipMalloc(&b, (size_t)256 << 20));
     const int64_t n4 = bytes / 16;
     float ms;
+    if (argc > 2 && std::string(argv[1]) == "series") {
+        const int nl = atoi(argv[2]);
+        const int64_t n = 65536; const int K = 1024;
+        const double gb6 = 6.0 * 4 * n * K, gb = gb6 + (double)n * K;
+        if (series("fill4 nt grid256 (2 GiB)", (double)bytes, nl, [&] { fill4<1><<<256, 256>>>((f4 *)p, n4); })) return 1;
+        if (series("packed rows + byte nt n=65536 K=1024", gb, nl, [&] { packed_writer<1, 1, 0><<<n / 256, 256>>>(p, b, n, K); })) return 1;
+        if (series("6xdword plain n=65536 K=1024", gb6, nl, [&] { col_writer<0, float><<<n / 256, 256>>>(p, n, K, 6); })) return 1;
+        return 0;
+    }
     ms = time_ms([&] { fill4<0><<<2048, 256>>>((f4 *)p, n4); }); printf("fill4 plain grid2048 : %.1f GB/s\n", bytes / ms / 1e6);
     ms = time_ms([&] { fill4<1><<<2048, 256>>>((f4 *)p, n4); }); printf("fill4 nt    grid2048 : %.1f GB/s\n", bytes / ms / 1e6);
     ms = time_ms([&] { fill4<1><<<256, 256>>>((f4 *)p, n4); });  printf("fill4 nt    grid256  : %.1f GB/s\n", bytes / ms / 1e6);

@@ -33,6 +33,11 @@ if os.path.exists(bj):
         alg = b["roofline"]["algorithmic_bytes_per_launch"]
         print("rollout kernel: WRITE_SIZE %.4g B, FETCH_SIZE(x2) %.4g B, algorithmic %.4g B, traffic/alg = %.4f"
               % (w, r, alg, (w + r) / alg))
+        # stamped with the sha of the kernel sources the box ran (= this tree: summarise right after the gpurun
+        # call that measured), so bench.py can tell a stale figure from a current one
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
         json.dump({"write_bytes": w, "fetch_bytes_corrected": r, "algorithmic_bytes": alg,
-                   "traffic_over_algorithmic": (w + r) / alg}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+                   "traffic_over_algorithmic": (w + r) / alg, "source_sha": bench.source_sha()},
+                  open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, "kernel_stats.csv")).read()[:600])
