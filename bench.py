@@ -246,9 +246,8 @@ def single_step_api(env, torch, steps=200):
     rew = torch.empty(n, device=env.device)
     done = torch.empty(n, dtype=torch.uint8, device=env.device)
     pos, vel, st = env.s0.clone(), env.s1.clone(), torch.zeros(n, dtype=torch.int32, device=env.device)
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-
     def call(i):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)      # (the capture stream inside a graph capture)
         _ffi.check(env.lib.ssc_mc_step(ctypes.byref(env.params), n, _ffi.ptr(pos), _ffi.ptr(vel), _ffi.ptr(acts[i & 63]),
                                        _ffi.ptr(rew), _ffi.ptr(done), _ffi.ptr(st), stream))
     for i in range(20):
@@ -295,6 +294,9 @@ def main():
     ap.add_argument("--steady-launches", type=int, default=400,
                     help="extra untimed-for-`value` launches after the timed region whose per-launch distribution is "
                          "reported as roofline.steady (N = 1 only; 0 disables)")
+    ap.add_argument("--settle-launches", type=int, default=300,
+                    help="untimed launches of the step between the W warm-up steps and the timed region, so that the "
+                         "timed K steps run past the post-idle power/clock transient (0 disables)")
     ap.add_argument("--no-single-step", action="store_true", help="skip the single-step-API (ssc_mc_step) line")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
                     help="BASELINE.json config (1-based): 2 = headline random-policy rollout (default), "
@@ -361,11 +363,18 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
+    # Settling: the first ~10 ms of sustained load after an idle GPU are a power/clock transient (the same launch
+    # takes 260 -> 340 -> 287 us over its first 25 repetitions, profiles/r02/drift).  W = 5
+    # warm-up launches end in the middle of it, so W is followed by --settle-launches further untimed launches of
+    # the same step: the timed K steps then measure the state a rollout engine actually runs in.
+    for i in range(args.settle_launches):
+        one_step(args.warmup + i)
+    warm_total = args.warmup + args.settle_launches
     barrier()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_step(args.warmup + i, evs[i])
+        one_step(warm_total + i, evs[i])
     if gather is not None:
         gather.finish()
     barrier()
@@ -380,7 +389,7 @@ def main():
     if world == 1 and args.steady_launches > 0 and gather is None:
         sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steady_launches)]
         for i, ev in enumerate(sev):
-            one_step(args.warmup + args.steps + i, ev)
+            one_step(warm_total + args.steps + i, ev)
         torch.cuda.synchronize()
         sl = [a.elapsed_time(b) for a, b in sev]
         steady = dist_stats(sl[len(sl) // 4:])            # the settled three quarters
@@ -407,6 +416,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_launches": args.settle_launches,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",

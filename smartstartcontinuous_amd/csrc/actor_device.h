@@ -245,4 +245,141 @@ struct ActorMfma {
     }
 };
 
+// ---------------------------------------------------------------------------------------
+// ActorMfma2<LAST_TANH>: the shipped shape (obs_dim 2, h1 <= 64, h2 <= 32; BASELINE config 3) with BOTH
+// contractions on the bf16 MFMA and no lane movement on the way in.
+//
+//  * Layer 1 at fp32-level accuracy on v_mfma_f32_32x32x16_bf16 (32 cycles per tile instead of the 64 of the
+//    exact-f32 shape): x = xh + xl, w = wh + wl (bf16 head + residual), x*w ~= xh*wh + xl*wh + xh*wl (the dropped
+//    xl*wl is <= 2^-16 |x w|; products of bf16 pairs are exact in the fp32 accumulator), and the bias rides in two
+//    more k slots against a constant 1 -- 2 inputs x 3 + 2 = 8 k slots, the accumulator starts from the inline
+//    constant 0.
+//  * The K = 16 slots of the shape split into the half held by lanes 0-31 (k 0..7) and by lanes 32-63 (k 8..15).
+//    The A operand carries the SAME 8 weight slots in both halves; the B operand of env tile 0 is {own slots in
+//    lanes 0-31, zeros in lanes 32-63}, that of env tile 1 {zeros, own slots}: lane l contributes its OWN env to
+//    the tile it belongs to, so the observation never changes lanes (the exact-f32 path needs a
+//    v_permlane32_swap per k-step).  Building both operands is 10 VALU ops per wave-step.
+//  * Everything from the hidden contraction on is ActorMfma<2,2,1,2>'s code; LAST_TANH is a template
+//    parameter so that the forward pass is ONE basic block (the scheduler can then run the caller's
+//    independent work -- noise generation -- under the MFMAs).
+template <bool LAST_TANH>
+struct ActorMfma2 {
+    static constexpr int kLanesPerEnv = 1;
+    static constexpr int UT = 2;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    bf16x8 a1[UT];        // layer-1 A fragments: 8 k slots of unit ut*32 + (lane & 31), identical in both lane halves
+    bf16x8 a2[UT][2];     // layer-2 A fragments (W2^T, k order matched to the layer-1 accumulator)
+    f32x16 c2;            // b2 in accumulator layout
+    float w3[16];         // W3[acc_row(reg)] (x -2 when LAST_TANH, see ActorMfma::init)
+    float b3;
+    uint32_t m0, m1;      // lane masks: all-ones in lanes 0-31 / 32-63
+    uint32_t one0, one1;  // the constant-1 slot pair (bias carrier) masked the same way
+
+    static __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+        const ssc_f32x2 v = {a, b};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ssc_bf16x2));
+    }
+    static __device__ __forceinline__ float bf16_head_f(float v) { return (float)(__bf16)v; }
+
+    __device__ void init(const ActorWeights &w) {
+        const int lane = threadIdx.x & 63;
+        const int r = lane & 31, half = lane >> 5;
+        const int H1 = w.h1, H2 = w.h2;
+        const float cs = LAST_TANH ? 2.88539008177792681472f : 1.0f;  // see ActorMfma::init
+        m0 = half ? 0u : 0xFFFFFFFFu;
+        m1 = ~m0;
+        one0 = 0x3F803F80u & m0;
+        one1 = 0x3F803F80u & m1;
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            const int unit = ut * 32 + r;
+            const bool ok = unit < H1;
+            const float w0 = ok ? w.W1[0 * H1 + unit] : 0.0f, w1 = ok ? w.W1[1 * H1 + unit] : 0.0f;
+            const float bb = ok ? w.b1[unit] : 0.0f;
+            const float w0h = bf16_head_f(w0), w1h = bf16_head_f(w1), bh = bf16_head_f(bb);
+            i32x4 p;
+            p[0] = (int)pack_bf16(w0h, w1h);            // x (xh0, xh1)
+            p[1] = p[0];                                // x (xl0, xl1)
+            p[2] = (int)pack_bf16(w0 - w0h, w1 - w1h);  // x (xh0, xh1)
+            p[3] = (int)pack_bf16(bh, bb - bh);         // x (1, 1)
+            a1[ut] = __builtin_bit_cast(bf16x8, p);
+        }
+        const int col = r;  // layer-2 output unit held by this lane's A row
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int u = ut * 32 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
+                    const float v = (u < H1 && col < H2) ? w.W2[u * H2 + col] * cs : 0.0f;
+                    a2[ut][s][j] = (__bf16)v;
+                }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int o = acc_row(reg, half);
+            c2[reg] = (o < H2) ? w.b2[o] * cs : 0.0f;
+            w3[reg] = (o < H2) ? w.W3[o] * (LAST_TANH ? -2.0f : 1.0f) : 0.0f;
+        }
+        b3 = w.b3[0];
+        if (LAST_TANH)
+            for (int j = 0; j < H2; ++j) b3 += w.W3[j];
+    }
+
+    // Wave-collective.  Returns the PRE-tanh output sum_j w3_j h2_j + b3 of this lane's env (the caller applies
+    // the final tanh, so that it can place it in its own dependent chain).
+    __device__ __forceinline__ float forward_pre(float x0, float x1) const {
+        const uint32_t H = pack_bf16(x0, x1);
+        const float h0 = __builtin_bit_cast(float, H << 16), h1 = __builtin_bit_cast(float, H & 0xFFFF0000u);
+        const uint32_t L = pack_bf16(x0 - h0, x1 - h1);
+        bf16x8 bop[2];
+        {
+            i32x4 q0 = {(int)(H & m0), (int)(L & m0), (int)(H & m0), (int)one0};
+            i32x4 q1 = {(int)(H & m1), (int)(L & m1), (int)(H & m1), (int)one1};
+            bop[0] = __builtin_bit_cast(bf16x8, q0);
+            bop[1] = __builtin_bit_cast(bf16x8, q1);
+        }
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // all four layer-1 tiles first (independent: 4 x 32 cycles of matrix pipe), then tile by tile ReLU + convert
+        // and the two hidden k-steps that consume it -- env tile 0's chain first, so that its tanh layer can start
+        // while env tile 1's MFMAs are still in the pipe
+        f32x16 d[2][UT];
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) d[et][ut] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ut], bop[et], zero, 0, 0, 0);
+        f32x16 acc2[2] = {c2, c2};
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    i32x4 packed;  // relu (models_editted.py:47) + bf16 convert
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        packed[j] = relu_pack_bf16(d[et][ut][8 * s + 2 * j], d[et][ut][8 * s + 2 * j + 1]);
+                    acc2[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ut][s], __builtin_bit_cast(bf16x8, packed),
+                                                                       acc2[et], 0, 0, 0);
+                }
+            }
+        }
+        float part[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};  // two partial sums per env tile: shorter dependent chains
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                const float v = acc2[et][reg];
+                const float h = LAST_TANH ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v) + 1.0f) : fmaxf(v, 0.0f);
+                part[et][reg & 1] = fmaf(h, w3[reg], part[et][reg & 1]);
+            }
+        // lanes 0-31 need tile 0's lo + hi halves, lanes 32-63 tile 1's: one swap + one add
+        float s_lo, s_hi;
+        half_swap(part[0][0] + part[0][1], part[1][0] + part[1][1], s_lo, s_hi);
+        return s_lo + s_hi + b3;
+    }
+
+    __device__ float forward(const float (&obs)[2]) const { return tanh_fast(forward_pre(obs[0], obs[1])); }
+};
+
 }  // namespace ssc

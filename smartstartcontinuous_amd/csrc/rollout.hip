@@ -100,6 +100,7 @@ struct PhiloxPipe {
 template <int OBS>
 struct RandomPolicy {
     static constexpr bool kPipelined = true;
+    static constexpr bool kFusedActor = false;
     static constexpr int kLanesPerEnv = 1;
     u32x4 cache;
     float low, span;
@@ -121,6 +122,7 @@ struct RandomPolicy {
 template <class Net, int OBS>
 struct ActorPolicy {
     static constexpr bool kPipelined = false;
+    static constexpr bool kFusedActor = false;
     static constexpr int kLanesPerEnv = Net::kLanesPerEnv;
     Net net;
     u32x4 cache;
@@ -160,6 +162,52 @@ struct ActorPolicy {
     __device__ void store(const RolloutArgs &ra, int64_t i) const {
         if (ra.st.ou_x != nullptr) ra.st.ou_x[i] = ou_x;
     }
+};
+
+// The same policy for the shape BASELINE config 3 runs (MountainCar: 2 observations, actor h1 <= 64 / h2 <= 32 on the
+// bf16 MFMA, action bounds [-1, 1], epsilon > 0), written so that one env-step is ONE basic block: every
+// wave-uniform choice of ActorPolicy (last_layer_tanh, epsilon > 0, the identity scale, the even/odd Philox word
+// pair) is a template parameter or resolved by the caller's two-step loop.  With one wave per SIMD the only thing
+// that can run under the MFMAs and in the bubbles of the dependent action -> env.step chain is independent work of
+// the same wave, and the scheduler only moves code inside a basic block: the noise generation (half a Philox
+// evaluation + Box-Muller per step) is that work.
+template <bool LAST_TANH>
+struct ActorPolicyFused {
+    static constexpr bool kPipelined = false;
+    static constexpr bool kFusedActor = true;
+    static constexpr int kLanesPerEnv = 1;
+    ActorMfma2<LAST_TANH> net;
+    float ou_x, mu, sig_sqrt_dt, theta_dt, eps;
+
+    __device__ void init(const PolicyArgs &pa, const RolloutArgs &ra, int64_t i) {
+        net.init(pa.actor);
+        mu = pa.ou_mu;
+        sig_sqrt_dt = pa.ou_sigma * sqrtf(pa.ou_dt);
+        theta_dt = pa.ou_theta * pa.ou_dt;
+        eps = pa.ou_eps;  // > 0 (dispatch)
+        ou_x = ra.st.ou_x[i];
+    }
+    // Box-Muller like gaussian_f32, with -2 ln(u1) = (-2 ln 2) log2(u1) on the bare v_log_f32: u1 >= 2^-24 is never
+    // denormal, so the range handling logf() wraps around the instruction (10 more VALU ops) is dead weight.
+    static __device__ __forceinline__ float gaussian(uint32_t x0, uint32_t x1) {
+        const float u1 = ((float)(x0 >> 8) + 1.0f) * (1.0f / 16777216.0f);
+        const float u2 = (float)(x1 >> 8) * (1.0f / 16777216.0f);
+        const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));
+        return r * __builtin_amdgcn_cosf(u2);
+    }
+    // DDPG_Baselines_agent.get_action for this lane's env; (w0, w1) = the step's two Philox words.
+    __device__ __forceinline__ float act(const float (&obs)[2], uint32_t w0, uint32_t w1) {
+        const float pre = net.forward_pre(obs[0], obs[1]);
+        const float g = gaussian(w0, w1);
+        ou_x = ou_x + theta_dt * (mu - ou_x) + sig_sqrt_dt * g;
+        const float a = tanh_fast(pre) + ou_x * eps;  // ddpg_editted.py:267-270
+        // clip (:271); scale(scale(.)) (DDPG_Baselines_agent.py:236-240) is the identity on a clipped action for
+        // bounds [-1, 1]
+        return fminf(fmaxf(a, -1.0f), 1.0f);
+    }
+    __device__ float from_word(uint32_t) const { return 0.0f; }
+    __device__ void on_reset() { ou_x = 0.0f; }
+    __device__ void store(const RolloutArgs &ra, int64_t i) const { ra.st.ou_x[i] = ou_x; }
 };
 
 // ----------------------------------------------------------------------------- kernel --
@@ -205,7 +253,11 @@ struct Rollout {
                 __builtin_nontemporal_store(obs[c], (float *)((char *)(ra.log.obs[c] + row) + voff));
             __builtin_nontemporal_store(a, (float *)((char *)(ra.log.act + row) + voff));
             __builtin_nontemporal_store(rew, (float *)((char *)(ra.log.rew + row) + voff));
-            __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), ra.log.done + drow + (voff >> 2));
+            // a PLAIN store for the byte column: a wave writes 64 B of it, half a 128-byte line; as a non-temporal
+            // store that half line goes to memory on its own, as a plain one the L2 merges it with the neighbour
+            // wave's half first.  tools/membw.hip `series .. rows` (profiles/r02/membw_rows.txt): fp32 columns nt +
+            // byte column plain 6.04 TB/s, all nt 5.61, all plain 5.44
+            ra.log.done[drow + (voff >> 2)] = (uint8_t)(done ? 1 : 0);
 #pragma unroll
             for (int c = 0; c < OBS; ++c)
                 __builtin_nontemporal_store(obs2[c], (float *)((char *)(ra.log.obs2[c] + row) + voff));
@@ -286,6 +338,29 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec
         const int32_t k_tail = k;
         for (; k < ra.K; ++k)
             r.step(r.pol.act(r.obs, ra.seed, r.env_id, ra.step0 + (uint64_t)k, k == k_tail), k);
+    } else if constexpr (PolT::kFusedActor) {
+        // Two steps per iteration: one Philox evaluation (counter t >> 1) serves the gaussians of an even / odd
+        // step pair, and the evaluation for the NEXT pair is split 5 + 5 rounds over the two step bodies.
+        uint64_t t = ra.step0;
+        u32x4 cur = rng_words(ra.seed, r.env_id, t >> 1, TAG_OU);
+        if ((t & 1) != 0 && k < ra.K) {  // odd first step: second word pair of its counter
+            r.step(r.pol.act(r.obs, cur.z, cur.w), k);
+            ++k; ++t;
+            cur = rng_words(ra.seed, r.env_id, t >> 1, TAG_OU);
+        }
+        for (; k + 2 <= ra.K; k += 2, t += 2) {
+            PhiloxPipe nx;
+            nx.start(ra.seed, r.env_id, (t >> 1) + 1, TAG_OU);
+            nx.rounds<5>(); nx.pin();
+            r.step(r.pol.act(r.obs, cur.x, cur.y), k);
+            nx.rounds<5>(); nx.pin();
+            r.step(r.pol.act(r.obs, cur.z, cur.w), k + 1);
+            cur = nx.get();
+        }
+        if (k < ra.K) {
+            r.step(r.pol.act(r.obs, cur.x, cur.y), k);
+            ++k;
+        }
     } else {
         for (; k < ra.K; ++k)
             r.step(r.pol.act(r.obs, ra.seed, r.env_id, ra.step0 + (uint64_t)k, k == 0), k);
@@ -353,6 +428,13 @@ static int dispatch_policy(const typename EnvT::Const &ec, const ssc_policy_desc
                          a.h1, a.h2);
     }
     if (a.precision == SSC_PREC_BF16_MFMA) {
+        if constexpr (OBS == 2) {
+            // the shipped shape on unit action bounds with exploration noise on: the straight-line fused policy
+            if (a.h1 <= 64 && a.h2 <= 32 && pa.act_low == -1.0f && pa.act_high == 1.0f && pa.ou_eps > 0.0f) {
+                if (a.last_layer_tanh) return launch_rollout<EnvT, ActorPolicyFused<true>>(ec, pa, ra, stream);
+                return launch_rollout<EnvT, ActorPolicyFused<false>>(ec, pa, ra, stream);
+            }
+        }
         if (a.h1 <= 64 && a.h2 <= 32)
             return launch_rollout<EnvT, ActorPolicy<ActorMfma<OBS, 2, 1, 2>, OBS>>(ec, pa, ra, stream);
         if (a.h1 <= 128 && a.h2 <= 64)

@@ -72,6 +72,33 @@ __global__ __launch_bounds__(256) void packed_writer(float *__restrict__ p, uint
     }
 }
 
+// rollout-shaped rows with switches: NTF / NTB = non-temporal float / byte stores; DONE: 0 none, 1 byte per step,
+// 2 one dword per 4 steps (4 rows x 16 lanes), 3 byte per step INSIDE the packed row (row = 25 n bytes, done last)
+template <int NTF, int NTB, int DONE>
+__global__ __launch_bounds__(256) void row_writer(float *__restrict__ p, uint8_t *__restrict__ b, int64_t n, int K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t row_f = (DONE == 3) ? (25 * n) / 4 : 6 * n;   // floats per row
+    for (int k = 0; k < K; ++k) {
+        float *row = p + (int64_t)k * row_f;
+        for (int c = 0; c < 6; ++c) {
+            float *dst = row + c * n + i;
+            if (NTF) __builtin_nontemporal_store((float)(k + c), dst); else *dst = (float)(k + c);
+        }
+        if (DONE == 1 || DONE == 3) {
+            uint8_t *d = (DONE == 3) ? reinterpret_cast<uint8_t *>(row + 6 * n) + i : b + (int64_t)k * n + i;
+            if (NTB) __builtin_nontemporal_store((uint8_t)k, d); else *d = (uint8_t)k;
+        } else if (DONE == 2) {
+            if ((k & 3) == 3) {
+                const int lane = threadIdx.x & 63;
+                const int64_t wave_base = i - lane;
+                uint32_t *d = (uint32_t *)(b + (int64_t)((k & ~3) + (lane >> 4)) * n + wave_base) + (lane & 15);
+                if (NTB) __builtin_nontemporal_store((uint32_t)k, d); else *d = (uint32_t)k;
+            }
+        }
+    }
+}
+
 // wave-tiled records: [K][n/64][6 fp32 columns + 64 done bytes][64 envs] -- the 7 stores of a wave-step land in ONE
 // contiguous 1600-byte block, and a step of all waves is one contiguous sweep
 template <int NT>
@@ -132,7 +159,7 @@ int series(const char *name, double bytes_per_launch, int n_launch, F f) {
 }
 
 int main(int argc, char **argv) {
-    const size_t bytes = (size_t)2 << 30;
+    const size_t bytes = (size_t)4 << 30;
     float *p; uint8_t *b;
     CK(hipMalloc(&p, bytes)); CK(hipMalloc(&b, (size_t)256 << 20));
     const int64_t n4 = bytes / 16;
@@ -141,6 +168,28 @@ int main(int argc, char **argv) {
         const int nl = atoi(argv[2]);
         const int64_t n = 65536; const int K = 1024;
         const double gb6 = 6.0 * 4 * n * K, gb = gb6 + (double)n * K;
+        if (argc > 3 && std::string(argv[3]) == "rows") {
+            // the store-flavour / done-column matrix of the rollout's row shape, two buffers alternating like bench.py
+            float *p2 = p + (bytes / 2) / 4; uint8_t *b2 = b + ((size_t)128 << 20);
+            int flip = 0;
+#define ROWS(NAME, NTF, NTB, DONE, BYTES) \
+            if (series(NAME, BYTES, nl, [&] { flip ^= 1; row_writer<NTF, NTB, DONE><<<n / 256, 256>>>(flip ? p : p2, flip ? b : b2, n, K); })) return 1;
+            ROWS("rows f:nt    done:none", 1, 0, 0, gb6)
+            ROWS("rows f:plain done:none", 0, 0, 0, gb6)
+            ROWS("rows f:nt    done:byte-nt", 1, 1, 1, gb)
+            ROWS("rows f:plain done:byte-plain", 0, 0, 1, gb)
+            ROWS("rows f:plain done:byte-nt", 0, 1, 1, gb)
+            ROWS("rows f:nt    done:byte-plain", 1, 0, 1, gb)
+            ROWS("rows f:nt    done:dword/4steps-nt", 1, 1, 2, gb)
+            ROWS("rows f:plain done:dword/4steps-plain", 0, 0, 2, gb)
+            ROWS("rows f:nt    done:dword/4steps-plain", 1, 0, 2, gb)
+            ROWS("rows f:nt    done:in-row byte-plain", 1, 0, 3, gb)
+            ROWS("rows f:nt    done:in-row byte-nt", 1, 1, 3, gb)
+            ROWS("rows f:plain done:in-row byte-plain", 0, 0, 3, gb)
+            if (series("rows f:nt done:byte-nt SAME buffer every launch", gb, nl, [&] { row_writer<1, 1, 1><<<n / 256, 256>>>(p, b, n, K); })) return 1;
+            if (series("rows f:plain done:none SAME buffer every launch", gb6, nl, [&] { row_writer<0, 0, 0><<<n / 256, 256>>>(p, b, n, K); })) return 1;
+            return 0;
+        }
         if (series("fill4 nt grid256 (2 GiB)", (double)bytes, nl, [&] { fill4<1><<<256, 256>>>((f4 *)p, n4); })) return 1;
         if (series("packed rows + byte nt n=65536 K=1024", gb, nl, [&] { packed_writer<1, 1, 0><<<n / 256, 256>>>(p, b, n, K); })) return 1;
         if (series("6xdword plain n=65536 K=1024", gb6, nl, [&] { col_writer<0, float><<<n / 256, 256>>>(p, n, K, 6); })) return 1;
