@@ -18,6 +18,13 @@
 #include "ssc_device.h"
 #include "ssc_host.h"
 
+#ifndef SSC_ROLLOUT_PLAIN
+#define SSC_ROLLOUT_PLAIN 0
+#endif
+#ifndef SSC_ROLLOUT_STAGGER
+#define SSC_ROLLOUT_STAGGER 0
+#endif
+
 namespace ssc {
 
 struct RolloutArgs {
@@ -118,7 +125,8 @@ struct RandomPolicy {
 //   a = actor(obs) + epsilon * OU();  a = clip(a, -1, 1)      (ddpg_editted.py:262-271)
 //   a = scale(scale(a))                                        (DDPG_Baselines_agent.py:236-240)
 // OU [third-party baselines 0.1.5 ddpg/noise.py]: x += theta*(mu-x)*dt + sigma*sqrt(dt)*N(0,1).
-// One Philox call serves the gaussians of 2 consecutive steps: counter t>>1.
+// One Philox call serves the gaussians of 4 consecutive steps (counter t >> 2, both Box-Muller outputs of both
+// word pairs: ou_gaussian_from_words).
 template <class Net, int OBS>
 struct ActorPolicy {
     static constexpr bool kPipelined = false;
@@ -148,11 +156,10 @@ struct ActorPolicy {
     __device__ float act(const float (&obs)[OBS], uint64_t seed, uint64_t env_id, uint64_t t, bool first) {
         float a = net.forward(obs);
         if (eps > 0.0f) {  // wave-uniform
-            if (first || (t & 1) == 0) cache = rng_words(seed, env_id, t >> 1, TAG_OU);
-            const bool odd = (t & 1) != 0;
-            const float g = gaussian_f32(odd ? cache.z : cache.x, odd ? cache.w : cache.y);
-            ou_x = ou_x + theta_dt * (mu - ou_x) + sig_sqrt_dt * g;
-            a += ou_x * eps;  // ddpg_editted.py:267-270
+            if (first || (t & 3) == 0) cache = rng_words(seed, env_id, t >> 2, TAG_OU);
+            const float g = ou_gaussian_from_words(cache, t);
+            ou_x = fmaf(sig_sqrt_dt, g, fmaf(theta_dt, mu - ou_x, ou_x));
+            a = fmaf(ou_x, eps, a);  // ddpg_editted.py:267-270
         }
         a = fminf(fmaxf(a, -1.0f), 1.0f);  // ddpg_editted.py:271 (action_range = (-1, 1))
         return scale(scale(a));
@@ -187,20 +194,27 @@ struct ActorPolicyFused {
         eps = pa.ou_eps;  // > 0 (dispatch)
         ou_x = ra.st.ou_x[i];
     }
-    // Box-Muller like gaussian_f32, with -2 ln(u1) = (-2 ln 2) log2(u1) on the bare v_log_f32: u1 >= 2^-24 is never
-    // denormal, so the range handling logf() wraps around the instruction (10 more VALU ops) is dead weight.
-    static __device__ __forceinline__ float gaussian(uint32_t x0, uint32_t x1) {
+    // Box-Muller like gaussian_f32 in three pieces, so that the radius and the sin output of a word pair computed in
+    // the even step are reused by the odd one.  -2 ln(u1) = (-2 ln 2) log2(u1) on the bare v_log_f32: u1 >= 2^-24 is
+    // never denormal, so the range handling logf() wraps around the instruction (10 more VALU ops) is dead weight.
+    static __device__ __forceinline__ float bm_radius(uint32_t x0) {
         const float u1 = ((float)(x0 >> 8) + 1.0f) * (1.0f / 16777216.0f);
-        const float u2 = (float)(x1 >> 8) * (1.0f / 16777216.0f);
-        const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));
-        return r * __builtin_amdgcn_cosf(u2);
+        return __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));
     }
-    // DDPG_Baselines_agent.get_action for this lane's env; (w0, w1) = the step's two Philox words.
-    __device__ __forceinline__ float act(const float (&obs)[2], uint32_t w0, uint32_t w1) {
+    static __device__ __forceinline__ float bm_cos(uint32_t x1) { return __builtin_amdgcn_cosf((float)(x1 >> 8) * (1.0f / 16777216.0f)); }
+    static __device__ __forceinline__ float bm_sin(uint32_t x1) { return __builtin_amdgcn_sinf((float)(x1 >> 8) * (1.0f / 16777216.0f)); }
+    static __device__ __forceinline__ float gaussian(const u32x4 &w, uint64_t t) {  // = ou_gaussian_from_words
+        const bool hi = (t & 2) != 0;
+        const uint32_t x0 = hi ? w.z : w.x, x1 = hi ? w.w : w.y;
+        return bm_radius(x0) * ((t & 1) ? bm_sin(x1) : bm_cos(x1));
+    }
+    // DDPG_Baselines_agent.get_action for this lane's env; g = the step's N(0,1) draw.  Every multiply-add is
+    // spelled out: the step body exists in several copies (head, the four bodies of the main loop, tail) and
+    // hipcc decides contraction per copy -- a rollout must not depend on how it was cut into chunks.
+    __device__ __forceinline__ float act(const float (&obs)[2], float g) {
         const float pre = net.forward_pre(obs[0], obs[1]);
-        const float g = gaussian(w0, w1);
-        ou_x = ou_x + theta_dt * (mu - ou_x) + sig_sqrt_dt * g;
-        const float a = tanh_fast(pre) + ou_x * eps;  // ddpg_editted.py:267-270
+        ou_x = fmaf(sig_sqrt_dt, g, fmaf(theta_dt, mu - ou_x, ou_x));
+        const float a = fmaf(ou_x, eps, tanh_fast(pre));  // ddpg_editted.py:267-270
         // clip (:271); scale(scale(.)) (DDPG_Baselines_agent.py:236-240) is the identity on a clipped action for
         // bounds [-1, 1]
         return fminf(fmaxf(a, -1.0f), 1.0f);
@@ -209,6 +223,22 @@ struct ActorPolicyFused {
     __device__ void on_reset() { ou_x = 0.0f; }
     __device__ void store(const RolloutArgs &ra, int64_t i) const { ra.st.ou_x[i] = ou_x; }
 };
+
+// (wave-uniform row pointer) + (32-bit per-lane byte offset) as the SGPR-base form of global_store: the row pointer
+// is pinned to SGPRs with readfirstlane (free for a value that already is uniform; otherwise the optimiser
+// re-associates base + (row + lane) and every store pays a 64-bit VALU add), and the result is an explicit
+// global-address-space pointer (the integer round trip hides the kernel-argument provenance, and a generic
+// pointer would turn the stores into flat_store).
+#define SSC_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ SSC_GLOBAL T *lane_ptr(T *row_uniform, uint32_t lane_byte_off) {
+    const uint64_t v = reinterpret_cast<uint64_t>(row_uniform);
+    // (the builtin returns a SIGNED int: without the casts the low half is sign-extended into the high one)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    const uint64_t u = ((uint64_t)hi << 32) | (uint64_t)lo;
+    return (SSC_GLOBAL T *)((SSC_GLOBAL char *)u + lane_byte_off);
+}
 
 // ----------------------------------------------------------------------------- kernel --
 // Per-thread rollout state + the one-step body shared by the generic and the pipelined loop.
@@ -248,19 +278,27 @@ struct Rollout {
         if (LOG && (PolT::kLanesPerEnv == 1 || owner)) {
             const int64_t row = (int64_t)k * ra.log.row_stride;  // wave-uniform
             const int64_t drow = (int64_t)k * ra.log.done_row_stride;
+            // The lane offset is re-materialised as a 32-bit value in every step: hoisted out of the loop it becomes a
+            // 64-bit VGPR pair and every store then pays a v_lshl_add_u64 (2 passes) for base + offset; a 32-bit
+            // VGPR offset against the wave-uniform row base is the SGPR-base form of global_store (no VALU op).
+            uint32_t vo = voff;
+            asm volatile("" : "+v"(vo));
+#if SSC_ROLLOUT_PLAIN   // diagnostic variant: plain instead of non-temporal fp32 stores
+#define SSC_STORE_F32(val, ptr) (*(ptr) = (val))
+#else
+#define SSC_STORE_F32(val, ptr) __builtin_nontemporal_store((val), (ptr))
+#endif
 #pragma unroll
-            for (int c = 0; c < OBS; ++c)
-                __builtin_nontemporal_store(obs[c], (float *)((char *)(ra.log.obs[c] + row) + voff));
-            __builtin_nontemporal_store(a, (float *)((char *)(ra.log.act + row) + voff));
-            __builtin_nontemporal_store(rew, (float *)((char *)(ra.log.rew + row) + voff));
+            for (int c = 0; c < OBS; ++c) SSC_STORE_F32(obs[c], lane_ptr(ra.log.obs[c] + row, vo));
+            SSC_STORE_F32(a, lane_ptr(ra.log.act + row, vo));
+            SSC_STORE_F32(rew, lane_ptr(ra.log.rew + row, vo));
             // a PLAIN store for the byte column: a wave writes 64 B of it, half a 128-byte line; as a non-temporal
             // store that half line goes to memory on its own, as a plain one the L2 merges it with the neighbour
             // wave's half first.  tools/membw.hip `series .. rows` (profiles/r02/membw_rows.txt): fp32 columns nt +
-            // byte column plain 6.04 TB/s, all nt 5.61, all plain 5.44
-            ra.log.done[drow + (voff >> 2)] = (uint8_t)(done ? 1 : 0);
+            // byte column plain 6.0 TB/s, all nt 5.6, all plain 5.4
+            *lane_ptr(ra.log.done + drow, vo >> 2) = (uint8_t)(done ? 1 : 0);
 #pragma unroll
-            for (int c = 0; c < OBS; ++c)
-                __builtin_nontemporal_store(obs2[c], (float *)((char *)(ra.log.obs2[c] + row) + voff));
+            for (int c = 0; c < OBS; ++c) SSC_STORE_F32(obs2[c], lane_ptr(ra.log.obs2[c] + row, vo));
         }
 #pragma unroll
         for (int c = 0; c < OBS; ++c) obs[c] = obs2[c];
@@ -339,28 +377,46 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec
         for (; k < ra.K; ++k)
             r.step(r.pol.act(r.obs, ra.seed, r.env_id, ra.step0 + (uint64_t)k, k == k_tail), k);
     } else if constexpr (PolT::kFusedActor) {
-        // Two steps per iteration: one Philox evaluation (counter t >> 1) serves the gaussians of an even / odd
-        // step pair, and the evaluation for the NEXT pair is split 5 + 5 rounds over the two step bodies.
+#if SSC_ROLLOUT_STAGGER
+        {   // diagnostic variant: spread the waves' step phases over one step period
+            const uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+            const uint32_t d = __builtin_amdgcn_readfirstlane((int)(__builtin_bitreverse32(w) >> 27));
+            for (uint32_t q = 0; q < d; ++q) __builtin_amdgcn_s_sleep(1);
+        }
+#endif
+        // Four steps per iteration: one Philox evaluation (counter t >> 2) serves them (ou_gaussian_from_words),
+        // and the evaluation for the NEXT four is split 3 + 3 + 2 + 2 rounds over the four step bodies.
         uint64_t t = ra.step0;
-        u32x4 cur = rng_words(ra.seed, r.env_id, t >> 1, TAG_OU);
-        if ((t & 1) != 0 && k < ra.K) {  // odd first step: second word pair of its counter
-            r.step(r.pol.act(r.obs, cur.z, cur.w), k);
-            ++k; ++t;
-            cur = rng_words(ra.seed, r.env_id, t >> 1, TAG_OU);
+        u32x4 cur = rng_words(ra.seed, r.env_id, t >> 2, TAG_OU);
+        for (; k < ra.K && (t & 3) != 0; ++k, ++t) r.step(r.pol.act(r.obs, PolT::gaussian(cur, t)), k);  // head
+        if (k + 4 <= ra.K) {
+            if (k != 0) cur = rng_words(ra.seed, r.env_id, t >> 2, TAG_OU);
+            for (; k + 4 <= ra.K; k += 4, t += 4) {
+#if SSC_ACT_ABL == 3
+                r.step(r.pol.act(r.obs, 0.5f), k);
+                r.step(r.pol.act(r.obs, -0.25f), k + 1);
+                r.step(r.pol.act(r.obs, 0.125f), k + 2);
+                r.step(r.pol.act(r.obs, -1.0f), k + 3);
+#else
+                PhiloxPipe nx;
+                nx.start(ra.seed, r.env_id, (t >> 2) + 1, TAG_OU);
+                nx.rounds<3>(); nx.pin();
+                const float r0 = PolT::bm_radius(cur.x), s0 = PolT::bm_sin(cur.y);
+                r.step(r.pol.act(r.obs, r0 * PolT::bm_cos(cur.y)), k);
+                nx.rounds<3>(); nx.pin();
+                r.step(r.pol.act(r.obs, r0 * s0), k + 1);
+                nx.rounds<2>(); nx.pin();
+                const float r1 = PolT::bm_radius(cur.z), s1 = PolT::bm_sin(cur.w);
+                r.step(r.pol.act(r.obs, r1 * PolT::bm_cos(cur.w)), k + 2);
+                nx.rounds<2>(); nx.pin();
+                r.step(r.pol.act(r.obs, r1 * s1), k + 3);
+                cur = nx.get();
+#endif
+            }
+        } else if (k < ra.K && k != 0) {
+            cur = rng_words(ra.seed, r.env_id, t >> 2, TAG_OU);
         }
-        for (; k + 2 <= ra.K; k += 2, t += 2) {
-            PhiloxPipe nx;
-            nx.start(ra.seed, r.env_id, (t >> 1) + 1, TAG_OU);
-            nx.rounds<5>(); nx.pin();
-            r.step(r.pol.act(r.obs, cur.x, cur.y), k);
-            nx.rounds<5>(); nx.pin();
-            r.step(r.pol.act(r.obs, cur.z, cur.w), k + 1);
-            cur = nx.get();
-        }
-        if (k < ra.K) {
-            r.step(r.pol.act(r.obs, cur.x, cur.y), k);
-            ++k;
-        }
+        for (; k < ra.K; ++k, ++t) r.step(r.pol.act(r.obs, PolT::gaussian(cur, t)), k);  // tail (< 4 steps, t & 3 == 0 at its start)
     } else {
         for (; k < ra.K; ++k)
             r.step(r.pol.act(r.obs, ra.seed, r.env_id, ra.step0 + (uint64_t)k, k == 0), k);

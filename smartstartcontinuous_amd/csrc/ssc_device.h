@@ -59,19 +59,27 @@ SSC_HD float uniform_f32(uint32_t x, float low, float span) {
     return fmaf(u, span, low);
 }
 
-// Box-Muller, first output.  u1 in (0,1], u2 in [0,1).  On the device the transcendental
-// pipe is used directly: v_log_f32, v_sqrt_f32 and v_cos_f32 (whose input is in revolutions,
-// i.e. it evaluates cos(2*pi*u2) with no range reduction).
-SSC_HD float gaussian_f32(uint32_t x0, uint32_t x1) {
+// Box-Muller.  u1 in (0,1], u2 in [0,1); second = false -> r cos(2 pi u2), true -> r sin(2 pi u2).  On the device
+// the transcendental pipe is used directly: v_log_f32, v_sqrt_f32 and v_cos_f32 / v_sin_f32 (whose input is in
+// revolutions, i.e. they evaluate cos(2*pi*u2) with no range reduction).
+SSC_HD float gaussian_f32(uint32_t x0, uint32_t x1, bool second = false) {
     const float u1 = ((float)(x0 >> 8) + 1.0f) * (1.0f / 16777216.0f);
     const float u2 = (float)(x1 >> 8) * (1.0f / 16777216.0f);
 #if defined(__HIP_DEVICE_COMPILE__)
     const float r = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1));
-    return r * __builtin_amdgcn_cosf(u2);
+    return r * (second ? __builtin_amdgcn_sinf(u2) : __builtin_amdgcn_cosf(u2));
 #else
     const float r = sqrtf(-2.0f * logf(u1));
-    return r * cosf(6.28318530717958647692f * u2);
+    return r * (second ? sinf(6.28318530717958647692f * u2) : cosf(6.28318530717958647692f * u2));
 #endif
+}
+
+// The OU-noise gaussian of global step t (oracle/ssc_oracle.py:ou_gaussian): ONE Philox evaluation (counter
+// t >> 2, TAG_OU) serves four consecutive steps -- word pair (x, y) for t & 2 == 0, (z, w) otherwise; each pair is
+// one Box-Muller transform whose cos output goes to the even and whose sin output to the odd step.
+SSC_HD float ou_gaussian_from_words(const u32x4 &w, uint64_t t) {
+    const bool hi = (t & 2) != 0;
+    return gaussian_f32(hi ? w.z : w.x, hi ? w.w : w.y, (t & 1) != 0);
 }
 
 // ---------------------------------------------------------------------------------------

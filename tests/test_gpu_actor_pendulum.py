@@ -124,6 +124,32 @@ def test_rollout_actor_mountaincar_teacher_forced(ssc, precision, tol):
         assert res["max_dact"] <= TOL_ACT_BF16_EMU, res
 
 
+@pytest.mark.parametrize("llt", [True, False])
+def test_rollout_actor_chunks_compose(ssc, llt):
+    """The fused actor rollout must not depend on how the steps were cut into launches: chunks of 7 + 1 + 18 + 14
+    steps from an unaligned start reproduce ONE chunk of 40 steps bit for bit (the step body exists in head / main-loop
+    / tail copies inside the kernel, and one Philox call serves 4 steps)."""
+    n, seed = 2000, 11
+    w = {k: torch.as_tensor(v) for k, v in actor_weights(2, 64, 32, seed=3, w3_scale=0.5).items()}
+
+    def fresh():
+        env = ssc.VecEnv("MountainCarContinuous-v0", n, seed=seed, env_id0=5)
+        env.reset()
+        env.steps.fill_(985)
+        env.t = 2
+        return env
+    pol = ssc.ActorPolicy(w, precision="bf16_mfma", last_layer_tanh=llt)
+    env = fresh()
+    whole = env.rollout(40, pol)
+    env2 = fresh()
+    parts = [env2.rollout(k, pol) for k in (7, 1, 18, 14)]
+    torch.cuda.synchronize()
+    for col in ("obs", "act", "rew", "done", "obs2"):
+        assert torch.equal(getattr(whole, col), torch.cat([getattr(p, col) for p in parts], dim=-2)), col
+    assert torch.equal(env.ou_x, env2.ou_x) and torch.equal(env.s0, env2.s0) and torch.equal(env.stats[1:], env2.stats[1:])
+    assert abs(float(env.stats[0] - env2.stats[0])) < 1e-2          # per-launch fp32 partial sums of the rewards
+
+
 def test_rollout_actor_without_noise_equals_actor_forward(ssc):
     n, K = 320, 9
     w = actor_weights(2, 64, 32, seed=9, w3_scale=0.5)

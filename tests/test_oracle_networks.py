@@ -103,6 +103,14 @@ def test_ou_and_action_path():
     assert np.allclose(O.scale_action(np.array([-2.0, 0.0, 0.5]), -2.0, 2.0), [-2.0, 0.0, 1.0])
     g = O.ou_gaussian(7, np.arange(200000, dtype=np.uint64), 5)
     assert abs(g.mean()) < 0.01 and abs(g.std() - 1) < 0.01
+    # the four steps served by one Philox call (counter t >> 2: two word pairs x cos / sin output) are four
+    # independent N(0,1) draws
+    ids = np.arange(200000, dtype=np.uint64)
+    gs = np.stack([O.ou_gaussian(7, ids, t) for t in (8, 9, 10, 11, 12)])
+    assert np.all(np.abs(gs.mean(axis=1)) < 0.01) and np.all(np.abs(gs.std(axis=1) - 1) < 0.01)
+    c = np.corrcoef(gs)
+    assert np.max(np.abs(c - np.eye(5))) < 0.01
+    assert np.max(np.abs(np.corrcoef(gs ** 2) - np.eye(5))) < 0.01
 
 
 def test_pendulum_restatement_properties(oracle_clib):
