@@ -290,6 +290,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the gather path even at world size 1 "
                          "(single-GPU rehearsal of the N>1 code path)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend for N > 1: nccl = RCCL over xGMI (the measured configuration); gloo = the "
+                         "packed payload staged through pinned host memory -- a rehearsal of the N > 1 control flow "
+                         "(rank -> env_id0, barriers, MAX-reduced timings, rank-0 JSON) that also runs with several ranks "
+                         "on ONE GPU; its numbers are not RCCL numbers")
     ap.add_argument("--cpu-budget", type=float, default=24.0)
     ap.add_argument("--steady-launches", type=int, default=400,
                     help="extra untimed-for-`value` launches after the timed region whose per-launch distribution is "
@@ -322,13 +327,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and args.backend != "gloo":
+        sys.exit("bench.py: rank %d has no GPU of its own (%d visible); only --backend gloo may share a GPU" % (rank, n_dev))
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where the timing reductions live
 
     from smartstartcontinuous_amd import RandomPolicy, TransitionChunk, VecEnv
     from smartstartcontinuous_amd.sharding import TransitionGather
@@ -397,10 +410,10 @@ def main():
         steady["launches"] = args.steady_launches
 
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        kms = torch.tensor([kernel_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
         kernel_ms = float(kms.item())
 
@@ -429,6 +442,7 @@ def main():
                 "envs_per_gpu": n, "chunk_steps": K, "global_envs": n * world,
                 "parallelism": "env-sharded x%d" % world,
                 "gather": (args.gather if use_dist else "none"),
+                "backend": (("rccl" if args.backend == "nccl" else "gloo (host-staged rehearsal)") if use_dist else "none"),
                 "gather_steps_per_chunk": (gather.g_steps if gather is not None else 0),
             },
             "roofline": {
@@ -458,6 +472,9 @@ def main():
             # the learner rank really received every rank's last steps
             obs, act, rew, obs2, done = gather.unpack(world - 1)
             assert obs.shape == (env.obs_dim, gather.g_steps, n) and bool(torch.isfinite(act).all())
+            # ... and the statistics that rode in the payloads add up to every rank's env-steps so far
+            st = gather.global_stats.cpu().numpy()
+            assert st[2] == float(n) * K * world * (args.warmup + args.settle_launches + args.steps), st
         dist.barrier()
         dist.destroy_process_group()
 

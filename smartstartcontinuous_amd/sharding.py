@@ -39,30 +39,68 @@ def record_bytes(obs_dim):
     return 8 * obs_dim + 9
 
 
+def _backend(group=None):
+    return dist.get_backend(group) if dist.is_available() and dist.is_initialized() else None
+
+
 class TransitionGather:
     """Packs the last ``g_steps`` steps of a TransitionChunk plus a snapshot of the chunk statistics
     into one contiguous byte buffer and gathers it to ``dst`` -- ONE collective per chunk; the learner
     sums the statistics out of the payload (``allreduce_stats=True`` adds an all-reduce so that every
     rank knows them).  On CUDA the pack is a single kernel (``ssc_pack_transitions``) on the producing
-    stream and the collective runs on a side stream, overlapping the next chunk's rollout."""
+    stream and the collective runs on a side stream, overlapping the next chunk's rollout.
 
-    def __init__(self, obs_dim, g_steps, n, world, rank, device, dst=0, group=None, allreduce_stats=False):
+    Shards may differ in size (``shard_range`` balances to within one env): every rank's ``n`` is exchanged
+    once at construction, every send / receive slot is sized for the largest shard (a gather needs equal
+    message sizes), and ``unpack(src)`` cuts the views with the SOURCE rank's ``n``.
+
+    Both the send and the receive side are double-buffered by ``slot`` (= chunk index & 1): the collective of
+    chunk i fills ``recv[i & 1]`` while the learner may still be reading chunk i-1 out of ``recv[(i-1) & 1]``.
+
+    ``host_staging`` (automatic for a gloo group with CUDA buffers): the packed payload travels through pinned
+    host memory and the collective runs on host tensors -- the rehearsal path for the N > 1 control flow on a
+    box without RCCL peers; it is synchronous."""
+
+    def __init__(self, obs_dim, g_steps, n, world, rank, device, dst=0, group=None, allreduce_stats=False,
+                 host_staging=None, n_all=None):
         self.allreduce_stats = allreduce_stats
         self.obs_dim, self.g_steps, self.n = obs_dim, int(g_steps), int(n)
         self.world, self.rank, self.dst, self.group = world, rank, dst, group
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
-        rec = self.g_steps * self.n * record_bytes(obs_dim)
-        self.stats_off = (rec + 7) & ~7
-        self.nbytes = self.stats_off + 32
-        self.send = [torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        if host_staging is None:
+            host_staging = self.cuda and world > 1 and _backend(group) == "gloo"
+        self.host_staging = bool(host_staging)
+        # every rank's shard size, exchanged once (ADVICE r1: unequal shards must not reach dist.gather unsized)
+        if n_all is not None:
+            self.n_all = [int(x) for x in n_all]
+        elif world > 1:
+            mine = torch.tensor([self.n], dtype=torch.int64, device="cpu" if (not self.cuda or self.host_staging) else self.device)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine, group=group)
+            self.n_all = [int(t.item()) for t in every]
+        else:
+            self.n_all = [self.n]
+        if len(self.n_all) != world or self.n_all[rank] != self.n:
+            raise ValueError(f"TransitionGather: shard sizes {self.n_all} do not match world {world} / local n {self.n}")
+        self.n_total = sum(self.n_all)
+        self._nbytes_of = [self._layout(m)[1] for m in self.n_all]
+        self.stats_off, self.nbytes = self._layout(self.n)
+        self.slot_bytes = max(self._nbytes_of)
+        self.send = [torch.zeros(self.slot_bytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.recv = None
         if rank == dst:
-            self.recv = [torch.empty(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(world)]
+            self.recv = [[torch.empty(self.slot_bytes, dtype=torch.uint8, device=self.device) for _ in range(world)]
+                         for _ in range(2)]
+        if self.host_staging:
+            self._h_send = torch.zeros(self.slot_bytes, dtype=torch.uint8).pin_memory()
+            self._h_recv = [torch.empty(self.slot_bytes, dtype=torch.uint8).pin_memory() for _ in range(world)] if rank == dst else None
         self._global_stats = torch.zeros(4, dtype=torch.float64, device=self.device)
         self._stats_from_payload = False
-        self.side = torch.cuda.Stream(self.device) if self.cuda else None
-        self.packed = [None, None]
+        self.side = torch.cuda.Stream(self.device) if (self.cuda and not self.host_staging) else None
+        self.packed = [None, None]        # event: send[slot] was consumed by its collective
+        self.received = [None, None]      # event: recv[slot] holds the chunk (dst only)
+        self.last_slot = None
         self.chunks_gathered = 0
         if self.cuda:
             import ctypes
@@ -70,9 +108,14 @@ class TransitionGather:
             self._ffi, self._ct = _ffi, ctypes
             assert _ffi.lib().ssc_pack_bytes(obs_dim, self.g_steps, self.n) == self.nbytes
 
+    def _layout(self, n):
+        rec = self.g_steps * n * record_bytes(self.obs_dim)
+        off = (rec + 7) & ~7
+        return off, off + 32
+
     # layout of the packed buffer: [obs(obs_dim x g x n) f32 | act | rew | obs2 | done(u8) | pad | stats f64[4]]
-    def _views(self, buf):
-        g, n, d = self.g_steps, self.n, self.obs_dim
+    def _views(self, buf, n=None):
+        g, n, d = self.g_steps, (self.n if n is None else n), self.obs_dim
         f = buf[: 4 * g * n * (2 * d + 2)].view(torch.float32)
         o = 0
         obs = f[o:o + d * g * n].view(d, g, n); o += d * g * n
@@ -82,8 +125,9 @@ class TransitionGather:
         done = buf[4 * o:4 * o + g * n].view(g, n)
         return obs, act, rew, obs2, done
 
-    def _stats_view(self, buf):
-        return buf[self.stats_off:self.stats_off + 32].view(torch.float64)
+    def _stats_view(self, buf, n=None):
+        off = self.stats_off if n is None else self._layout(n)[0]
+        return buf[off:off + 32].view(torch.float64)
 
     def pack(self, chunk, slot, stats):
         g = self.g_steps
@@ -102,28 +146,51 @@ class TransitionGather:
         done.copy_(chunk.done[chunk.K - g:])
         self._stats_view(self.send[slot]).copy_(stats)
 
-    def unpack(self, src_rank):
-        """Views (obs, act, rew, obs2, done) of the records received from ``src_rank`` (dst only)."""
-        return self._views(self.recv[src_rank])
+    def unpack(self, src_rank, slot=None):
+        """Views (obs, act, rew, obs2, done) of the records received from ``src_rank`` in the newest gathered chunk
+        (or in receive slot ``slot``); dst only.  Shapes follow the SOURCE rank's shard size."""
+        slot = self.last_slot if slot is None else slot
+        return self._views(self.recv[slot][src_rank], self.n_all[src_rank])
 
-    def received_stats(self, src_rank):
-        return self._stats_view(self.recv[src_rank])
+    def received_stats(self, src_rank, slot=None):
+        slot = self.last_slot if slot is None else slot
+        return self._stats_view(self.recv[slot][src_rank], self.n_all[src_rank])
 
     def wait_buffer_free(self, slot):
         """Kept for callers that overwrite a chunk from another stream; with ``submit`` the pack runs
         in order on the producing stream, so the chunk buffer is free as soon as ``submit`` returns."""
         return None
 
+    def wait_received(self, slot):
+        """Make the current stream wait until receive slot ``slot`` holds its chunk (dst only; no host sync)."""
+        if self.cuda and self.received[slot] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.received[slot])
+
     def _collective(self, slot):
-        dist.gather(self.send[slot], self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
-        if self.allreduce_stats:
-            # every rank learns the global statistics (the analogue of training_editted.py:173)
-            self._global_stats.copy_(self._stats_view(self.send[slot]))
-            dist.all_reduce(self._global_stats, op=dist.ReduceOp.SUM, group=self.group)
+        if self.host_staging:
+            self._h_send.copy_(self.send[slot])                       # D2H (synchronous: pinned destination, same stream)
+            torch.cuda.current_stream(self.device).synchronize()
+            dist.gather(self._h_send, self._h_recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                for r in range(self.world):
+                    self.recv[slot][r].copy_(self._h_recv[r], non_blocking=True)
+            if self.allreduce_stats:
+                h = self._stats_view(self._h_send).clone()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                self._global_stats.copy_(h)
+            else:
+                self._stats_from_payload = True
         else:
-            # the (cumulative) statistics ride in the gathered payload: the learner sums the newest snapshots
-            # when somebody asks (global_stats) -- no second collective and no per-chunk reduction kernels
-            self._stats_from_payload = True
+            dist.gather(self.send[slot], self.recv[slot] if self.rank == self.dst else None, dst=self.dst, group=self.group)
+            if self.allreduce_stats:
+                # every rank learns the global statistics (the analogue of training_editted.py:173)
+                self._global_stats.copy_(self._stats_view(self.send[slot]))
+                dist.all_reduce(self._global_stats, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                # the (cumulative) statistics ride in the gathered payload: the learner sums the newest snapshots
+                # when somebody asks (global_stats) -- no second collective and no per-chunk reduction kernels
+                self._stats_from_payload = True
+        self.last_slot = slot
         self.chunks_gathered += 1
 
     @property
@@ -132,7 +199,7 @@ class TransitionGather:
         (float64 [4]; on the learner rank, or on every rank with ``allreduce_stats``)."""
         if self._stats_from_payload and self.rank == self.dst:
             self.finish()
-            self._global_stats.copy_(torch.stack([self._stats_view(r) for r in self.recv]).sum(dim=0))
+            self._global_stats.copy_(torch.stack([self.received_stats(r) for r in range(self.world)]).sum(dim=0))
             self._stats_from_payload = False
         return self._global_stats
 
@@ -141,8 +208,11 @@ class TransitionGather:
 
         The pack (one small kernel, ~10 us) runs IN ORDER on the producing stream, so the rollout
         stream never waits on another stream for its 1.7 GB chunk buffer; only the collective runs on
-        the side stream, double-buffered through the two send slots."""
-        if not self.cuda:
+        the side stream, double-buffered through the two send slots (and the two receive slots on ``dst``:
+        the caller must be done reading ``recv[slot]`` -- i.e. the chunk gathered two submits ago -- on the
+        CURRENT stream before it calls ``submit`` with that slot again; the side stream waits for the current
+        stream's work up to here)."""
+        if not self.cuda or self.host_staging:
             self.pack(chunk, slot, stats)
             self._collective(slot)
             return
@@ -151,16 +221,17 @@ class TransitionGather:
             main.wait_event(self.packed[slot])        # send[slot] was consumed by its collective
         self.pack(chunk, slot, stats)
         ready = torch.cuda.Event()
-        ready.record(main)
+        ready.record(main)                            # also orders the learner's reads of recv[slot] before the refill
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
             self._collective(slot)
             sent = torch.cuda.Event()
             sent.record(self.side)
             self.packed[slot] = sent
+            self.received[slot] = sent
 
     def finish(self):
-        if self.cuda:
+        if self.cuda and self.side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
 
 
@@ -170,50 +241,116 @@ def broadcast_flat(flat, src=0, group=None):
     return flat
 
 
+def _views_like(flat, like):
+    """dict of views into ``flat`` with the shapes (and order) of the weight dict ``like`` (agents.flatten_params)."""
+    views, o = {}, 0
+    for k, v in like.items():
+        n = v.numel()
+        views[k] = flat[o:o + n].view(v.shape)
+        o += n
+    return views
+
+
 def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, learner=0, gather_steps=None,
-                          replay_capacity=1 << 20, train_iters=None, seed=0, group=None, ring_capacity=1 << 20):
+                          replay_capacity=1 << 20, train_iters=None, seed=0, group=None, ring_capacity=1 << 20,
+                          pipelined=False):
     """The actor-learner loop of ``rl_train_vec_ddpg`` over ``world`` GPUs (one process each, ``env`` = this rank's
     shard of one global env-id space).  Per chunk:
 
-      every rank     rolls its envs out under the CURRENT actor (fused kernel, OU noise), packs the last
+      every rank     rolls its envs out under the actor (fused kernel, OU noise), packs the last
                      ``gather_steps`` steps (default: 2^20 / N_total) and joins ONE gather to the learner;
       learner rank   appends every rank's records to its device replay ring, runs ``train_iters`` DDPG iterations
                      (``ssc_ddpg_train``), then
-      every rank     joins ONE broadcast of the learner's flat actor parameters -- the rollout policy reads views
-                     of that array, so the next chunk acts with the new weights.
+      every rank     joins ONE broadcast of the learner's flat actor parameters (``MpiAdam.sync``,
+                     ddpg_editted.py:331-336).
+
+    ``pipelined=False`` (the reference's own ordering: act, store, train, act ...): the gather is waited for, the
+    learner trains, and the broadcast lands in ``agent.actor_flat`` -- which the rollout policy reads through views --
+    before the next chunk starts.  Every actor idles while the learner trains.
+
+    ``pipelined=True``: nothing on an actor's rollout stream waits for the learner.  Gather AND broadcast run on the
+    side stream; the parameters are double-buffered (generation g, = trained on the chunks <= g, lands in buffer
+    g & 1) and chunk j is rolled with generation j - 2, so the learner trains on chunk j-1 while every rank already
+    rolls chunk j: ONE CHUNK STALE compared with the synchronous loop (which rolls chunk j with generation j - 1).
+    The receive side is double-buffered too (``TransitionGather``), so the gather of chunk j never overwrites what
+    the learner is still appending from chunk j-1.
 
     Returns (Summary of THIS rank's finished episodes, losses per chunk [learner only], replay [learner only])."""
     from .replay_buffer import DeviceReplayBuffer
     from .rl_train import Summary
-    from .vec_env import EpisodeRing, TransitionChunk
-    n_total = env.n * world
-    g = int(gather_steps) if gather_steps is not None else max(1, min(chunk_steps, (1 << 20) // n_total))
-    gather = TransitionGather(env.obs_dim, g, env.n, world, rank, env.device, dst=learner, group=group)
+    from .vec_env import ActorPolicy, EpisodeRing, TransitionChunk
+    gather = TransitionGather(env.obs_dim, 1, env.n, world, rank, env.device, dst=learner, group=group) \
+        if gather_steps is None else None
+    if gather is not None:      # the default G needs the TRUE global N (shards may differ by one env)
+        g = max(1, min(chunk_steps, (1 << 20) // gather.n_total))
+        n_all = gather.n_all
+    else:
+        g, n_all = int(gather_steps), None
+    gather = TransitionGather(env.obs_dim, g, env.n, world, rank, env.device, dst=learner, group=group, n_all=n_all)
     summary = Summary("sharded_ddpg_" + env.spec.id)
     ring = EpisodeRing(ring_capacity, env.device)
-    chunk = TransitionChunk(env.obs_dim, chunk_steps, env.n, env.device)
+    chunks = [TransitionChunk(env.obs_dim, chunk_steps, env.n, env.device) for _ in range(2 if pipelined else 1)]
     replay = DeviceReplayBuffer(replay_capacity, env.obs_dim, 1, env.device, seed=seed) if rank == learner else None
     broadcast_flat(agent.actor_flat, src=learner, group=group)          # MpiAdam.sync: start from the root's parameters
     losses = []
     generations = 0.0
+    cuda = env.device.type == "cuda" and gather.side is not None
+    if pipelined:
+        wbuf = [agent.actor_flat.clone(), agent.actor_flat.clone()]     # generation g lives in wbuf[g & 1]
+        wviews = [_views_like(b, agent.weights) for b in wbuf]
+        bcast_done = [None, None]
+
+    def learn(slot):
+        gather.wait_received(slot)
+        for src in range(world):
+            replay.append_chunk(TransitionChunk.from_columns(*gather.unpack(src, slot)), reward_scale=agent.reward_scale)
+        l = agent.train_from(replay, train_iters)
+        if l is not None:
+            losses.append(l)
+
     for i in range(num_chunks):
-        pd = env.policy_desc(agent.as_policy())
-        env.rollout(chunk_steps, out=chunk, ring=ring, policy_desc=pd)
-        gather.submit(chunk, i & 1, env.stats)
-        gather.finish()
-        if rank == learner:
-            for src in range(world):
-                replay.append_chunk(TransitionChunk.from_columns(*gather.unpack(src)),
-                                    reward_scale=agent.reward_scale)
-            l = agent.train_from(replay, train_iters)
-            if l is not None:
-                losses.append(l)
-        broadcast_flat(agent.actor_flat, src=learner, group=group)
+        slot = i & 1
+        if not pipelined:
+            pd = env.policy_desc(agent.as_policy())
+            env.rollout(chunk_steps, out=chunks[0], ring=ring, policy_desc=pd)
+            gather.submit(chunks[0], slot, env.stats)
+            gather.finish()
+            if rank == learner:
+                learn(slot)
+            broadcast_flat(agent.actor_flat, src=learner, group=group)
+        else:
+            main = torch.cuda.current_stream(env.device) if cuda else None
+            if cuda and bcast_done[slot] is not None:
+                main.wait_event(bcast_done[slot])                       # generation i-2 has landed in wbuf[slot]
+            pol = agent.as_policy()
+            pol = ActorPolicy(wviews[slot], last_layer_tanh=pol.last_layer_tanh, precision=pol.precision, ou_mu=pol.ou_mu,
+                              ou_sigma=pol.ou_sigma, ou_theta=pol.ou_theta, ou_dt=pol.ou_dt, ou_epsilon=pol.ou_epsilon)
+            env.rollout(chunk_steps, out=chunks[slot], ring=ring, policy_desc=env.policy_desc(pol))
+            gather.submit(chunks[slot], slot, env.stats)                # side stream: gather(i) after this rollout
+            if rank == learner:
+                learn(slot)                                             # generation i (main stream waits for gather(i) only)
+                wbuf[slot].copy_(agent.actor_flat)                      # after rollout(i) on this stream: wbuf[slot] is free
+            if cuda:
+                trained = torch.cuda.Event()
+                trained.record(main)
+                with torch.cuda.stream(gather.side):                    # same order on every rank: gather(i), broadcast(i)
+                    gather.side.wait_event(trained)
+                    broadcast_flat(wbuf[slot], src=learner, group=group)
+                    ev = torch.cuda.Event()
+                    ev.record(gather.side)
+                    bcast_done[slot] = ev
+            else:
+                broadcast_flat(wbuf[slot], src=learner, group=group)
         (ids, lens, rets), _d = ring.drain()
         summary.extend_records(lens, rets)
         generations += len(lens) / float(env.n)      # epsilon decays once per episode per env (DDPG_Baselines_agent.py:255-258)
         while generations >= 1.0:
             agent.decaying_ou_action_noise.reduce_epsilon()
             generations -= 1.0
+    if pipelined:
+        gather.finish()
+        if rank != learner:
+            # the actors end with the newest generation they received
+            newest = (num_chunks - 1) & 1
+            agent.actor_flat.copy_(wbuf[newest])
     return summary, losses, replay
-

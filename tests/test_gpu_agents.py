@@ -151,8 +151,37 @@ def test_sharded_actor_learner_loop_world1_equals_vec_loop(ssc):
         env_b, agent_b = setup()
         s_b, losses_b, replay_b = rl_train_sharded_ddpg(env_b, agent_b, num_chunks=4, chunk_steps=48, rank=0, world=1,
                                                         gather_steps=8, replay_capacity=4096, seed=3)
+        # pipelined mode: chunk j is rolled with parameter generation j - 2 (one chunk stale) -- replayed by hand
+        env_c, agent_c = setup()
+        s_c, losses_c, replay_c = rl_train_sharded_ddpg(env_c, agent_c, num_chunks=5, chunk_steps=48, rank=0, world=1,
+                                                        gather_steps=8, replay_capacity=4096, seed=3, pipelined=True)
+        torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+    from smartstartcontinuous_amd.replay_buffer import DeviceReplayBuffer
+    from smartstartcontinuous_amd.sharding import _views_like
+    env_d, agent_d = setup()
+    replay_d = DeviceReplayBuffer(4096, 2, 1, env_d.device, seed=3)
+    gens = {-2: agent_d.actor_flat.clone(), -1: agent_d.actor_flat.clone()}
+    losses_d = []
+    from smartstartcontinuous_amd.vec_env import EpisodeRing
+    ring_d, finished = EpisodeRing(1 << 16, env_d.device), 0.0
+    for j in range(5):
+        pol = agent_d.as_policy()
+        pol.weights = _views_like(gens[j - 2], agent_d.weights)
+        chunk = env_d.rollout(48, pol, ring=ring_d)
+        tail = ssc.TransitionChunk.from_columns(chunk.obs[:, -8:], chunk.act[-8:], chunk.rew[-8:], chunk.obs2[:, -8:], chunk.done[-8:])
+        replay_d.append_chunk(tail, reward_scale=agent_d.reward_scale)
+        losses_d.append(agent_d.train_from(replay_d, None))
+        gens[j] = agent_d.actor_flat.clone()
+        (_, lens, _), _ = ring_d.drain()
+        finished += len(lens) / float(env_d.n)          # epsilon decays once per episode per env, like the loop under test
+        while finished >= 1.0:
+            agent_d.decaying_ou_action_noise.reduce_epsilon()
+            finished -= 1.0
+    assert torch.equal(agent_c.actor_flat, agent_d.actor_flat) and torch.equal(agent_c.critic_flat, agent_d.critic_flat)
+    assert len(losses_c) == 5 and all(torch.equal(x, y) for x, y in zip(losses_c, losses_d))
+    assert torch.equal(replay_c.s, replay_d.s) and torch.equal(env_c.s0, env_d.s0)
     assert torch.equal(agent_a.actor_flat, agent_b.actor_flat) and torch.equal(agent_a.critic_flat, agent_b.critic_flat)
     assert len(losses_a) == len(losses_b) == 4 and all(torch.equal(x, y) for x, y in zip(losses_a, losses_b))
     assert sorted(s_a.episodes) == sorted(s_b.episodes) and len(s_a) > 0      # ring order is atomics order

@@ -35,12 +35,18 @@ class FakeChunk:
         self.done = ((torch.arange(K * N).reshape(K, N) + rank) % 7 == 0).to(torch.uint8)
 
 
-def _worker(rank, world, port, obs_dim, g, tmp, allreduce=True):
+def _worker(rank, world, port, obs_dim, g, tmp, allreduce=True, unequal=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     K, N = 12, 37
+    if unequal:                         # shard_range(75, 2): 38 + 37 envs -- the shards differ by one env
+        lo, hi = shard_range(75, world, rank)
+        N = hi - lo
     tg = TransitionGather(obs_dim, g, N, world, rank, "cpu", allreduce_stats=allreduce)
+    assert tg.n_all == [shard_range(75, world, r)[1] - shard_range(75, world, r)[0] for r in range(world)] if unequal \
+        else tg.n_all == [N] * world
+    assert tg.n_total == sum(tg.n_all)
     for it in range(3):
         chunk = FakeChunk(obs_dim, K, N, rank)
         chunk.act += it
@@ -51,13 +57,13 @@ def _worker(rank, world, port, obs_dim, g, tmp, allreduce=True):
     ok = True
     if rank == 0:
         for src in range(world):
-            ref = FakeChunk(obs_dim, K, N, src)
+            ref = FakeChunk(obs_dim, K, tg.n_all[src], src)
             ref.act += 2
             obs, act, rew, obs2, done = tg.unpack(src)
             ok &= torch.equal(obs, ref.obs[:, K - g:]) and torch.equal(obs2, ref.obs2[:, K - g:])
             ok &= torch.equal(act, ref.act[K - g:]) and torch.equal(rew, ref.rew[K - g:])
             ok &= torch.equal(done, ref.done[K - g:])
-    exp = torch.tensor([1.5 * sum(r + 1 for r in range(world)), sum(range(world)), world * K * N, 2 * world],
+    exp = torch.tensor([1.5 * sum(r + 1 for r in range(world)), sum(range(world)), K * tg.n_total, 2 * world],
                        dtype=torch.float64)
     if allreduce or rank == 0:
         ok &= torch.equal(tg.global_stats, exp)
@@ -65,7 +71,8 @@ def _worker(rank, world, port, obs_dim, g, tmp, allreduce=True):
     if rank == 0:
         # what the learner of rl_train_sharded_ddpg appends to its replay ring: a chunk over the received columns
         got = TransitionChunk.from_columns(*tg.unpack(world - 1))
-        ok &= (got.K, got.N, got.obs_dim) == (g, N, obs_dim) and got.act.stride(0) == N
+        nl = tg.n_all[world - 1]
+        ok &= (got.K, got.N, got.obs_dim) == (g, nl, obs_dim) and got.act.stride(0) == nl
     # parameter sync (MpiAdam.sync, ddpg_editted.py:331-336): the views every rank's policy reads alias the flat array
     flat = torch.arange(10, dtype=torch.float32) + 100.0 * rank
     view = flat[2:8].view(2, 3)
@@ -76,11 +83,12 @@ def _worker(rank, world, port, obs_dim, g, tmp, allreduce=True):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("obs_dim,g,allreduce", [(2, 3, True), (3, 12, False)])
-def test_gather_and_allreduce_world2_gloo(tmp_path, obs_dim, g, allreduce):
+@pytest.mark.parametrize("obs_dim,g,allreduce,unequal", [(2, 3, True, False), (3, 12, False, False), (2, 5, False, True),
+                                                         (3, 2, True, True)])
+def test_gather_and_allreduce_world2_gloo(tmp_path, obs_dim, g, allreduce, unequal):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, obs_dim, g, str(tmp_path), allreduce), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, obs_dim, g, str(tmp_path), allreduce, unequal), nprocs=2, join=True)
     assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
