@@ -378,6 +378,16 @@ typedef struct ssc_replay_ring {
     float *s2;
     int64_t capacity;
     int32_t obs_dim, act_dim;
+    /* Episode index (both NULL: not kept).  The reference keeps episode_starting_indices beside its deque
+     * (replay_buffer.py:33-44, 109-115, 209-213) so that the path to any stored state can be recovered; a chunk of n
+     * parallel envs interleaves n episodes, so the device ring keeps, per record, the number of steps of ITS env's
+     * running episode up to and including the record (ep_steps [capacity], 1 = the episode's first recorded step).
+     * Records of one env lie n record numbers apart (record number = steps * n + env), hence the episode of record j
+     * is records j - (ep_steps-1)*n, ..., j - n, j -- valid for path recovery while the first of them is still in the
+     * ring.  ep_run [n] carries every env's running step count from one append to the next (zero-initialised; the
+     * caller zeroes it when it skips steps between two appends). */
+    int32_t *ep_steps;
+    int32_t *ep_run;
 } ssc_replay_ring;
 
 /* ReplayBuffer.add for a whole rollout chunk (replay_buffer.py:49-74; called per step from
@@ -394,6 +404,26 @@ int ssc_replay_append(const ssc_replay_ring *ring, const ssc_transition_log *log
  * Philox(seed; counter0 + batch, attempt << 8 | slot, TAG_REPLAY); oracle: replay_sample_indices. */
 int ssc_replay_sample(uint64_t seed, uint64_t counter0, int64_t size, int32_t n_batches, int32_t batch_size,
                       int32_t *d_idx, ssc_stream_t stream);
+
+/* ReplayBuffer.get_possible_smart_start_indices (replay_buffer.py:136-152: random.sample(range(first, len), n_ss), first =
+ * the oldest episode start still in the buffer) on the device ring: up to n_ss DISTINCT buffer indices (0 = oldest
+ * record, size-1 = newest; size = min(count, capacity)) drawn uniformly from the records whose whole episode prefix is
+ * still in the ring.  Rounds of Philox(seed; counter, round << 20 | slot, TAG_SMART_START) candidates; in a round a slot
+ * keeps its candidate unless it is invalid, already taken, or wanted by a lower slot (deterministic; oracle:
+ * smart_start_indices).  d_idx [n_ss] int32 (unfilled slots -1), *d_n = number of indices delivered (< n_ss only when
+ * fewer valid records exist or after max_rounds = 64).  n_ss <= 4096.  count = records appended so far, n = envs per
+ * step of the appended chunks.  Workspace: ssc_replay_smart_start_workspace_bytes(n_ss). */
+size_t ssc_replay_smart_start_workspace_bytes(int32_t n_ss);
+int ssc_replay_smart_start_indices(const ssc_replay_ring *ring, int64_t count, int64_t n, int32_t n_ss, uint64_t seed,
+                                   uint64_t counter, int32_t *d_idx, int32_t *d_n, void *d_workspace,
+                                   size_t workspace_bytes, ssc_stream_t stream);
+
+/* ReplayBuffer.get_episodic_path_to_buffer_index (replay_buffer.py:154-176): the states of the episode that contains
+ * buffer index *d_buffer_index (device int32; e.g. an entry of d_idx above) up to that record, plus its s2:
+ * d_path [max_len + 1][obs_dim], *d_len = number of rows written (episode steps so far + 1; 0 when the record's
+ * episode start has left the ring; at most the newest max_len steps of the prefix are kept). */
+int ssc_replay_episode_path(const ssc_replay_ring *ring, int64_t count, int64_t n, const int32_t *d_buffer_index,
+                            int32_t max_len, float *d_path, int32_t *d_len, ssc_stream_t stream);
 
 /* n_iters sequential training iterations in ONE launch (one workgroup: the iterations are a serial
  * chain through the parameters).  d_batch_idx [n_iters][batch_size] are record indices

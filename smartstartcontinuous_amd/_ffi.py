@@ -120,7 +120,8 @@ class ReplayView(Structure):
 
 class ReplayRing(Structure):
     _fields_ = [("s", c_void_p), ("a", c_void_p), ("r", c_void_p), ("t", c_void_p), ("s2", c_void_p),
-                ("capacity", c_int64), ("obs_dim", c_int32), ("act_dim", c_int32)]
+                ("capacity", c_int64), ("obs_dim", c_int32), ("act_dim", c_int32),
+                ("ep_steps", c_void_p), ("ep_run", c_void_p)]
 
 
 # symbol -> (restype, argtypes); every function include/ssc.h declares must be listed here
@@ -151,6 +152,11 @@ _SIGNATURES = {
     "ssc_replay_append": (c_int, [POINTER(ReplayRing), POINTER(TransitionLog), c_int32, c_int64, c_int64, c_float,
                                   c_void_p]),
     "ssc_replay_sample": (c_int, [c_uint64, c_uint64, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "ssc_replay_smart_start_workspace_bytes": (c_size_t, [c_int32]),
+    "ssc_replay_smart_start_indices": (c_int, [POINTER(ReplayRing), c_int64, c_int64, c_int32, c_uint64, c_uint64,
+                                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ssc_replay_episode_path": (c_int, [POINTER(ReplayRing), c_int64, c_int64, c_void_p, c_int32, c_void_p, c_void_p,
+                                        c_void_p]),
     "ssc_ddpg_train": (c_int, [POINTER(DdpgDesc), POINTER(ReplayView), c_void_p, c_int32, c_void_p, c_void_p]),
     "ssc_dataset_scan_workspace_bytes": (c_size_t, [c_int64]),
     "ssc_dataset_scan": (c_int, [POINTER(TransitionLog), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,

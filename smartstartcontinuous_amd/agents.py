@@ -192,6 +192,8 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         self.actor_flat, self.weights = flatten_params(weights, self.device)
         self.target_actor_flat = self.actor_flat.clone()        # target_init_updates (ddpg_editted.py:331-336)
         self._adam_actor = (torch.zeros_like(self.actor_flat), torch.zeros_like(self.actor_flat))
+        if hasattr(self, "_adam_t"):
+            self._adam_t[0] = 0                                  # fresh moments start their bias correction over
         w = self.weights
         self.obs_dim, self.h1 = w["W1"].shape
         self.h2, self.act_dim = w["W3"].shape
@@ -262,9 +264,14 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         """:197-204 -> DDPG_editted.get_q_value (ddpg_editted.py:274-279): Q(s, pi(s)) without noise.
         Returns [n, 1] for a batch, a length-1 array for a single state (like ``sess.run(...)[0]``)."""
         single = np.ndim(state) == 1 if not torch.is_tensor(state) else state.dim() == 1
-        o = torch.as_tensor(state, dtype=torch.float32, device=self.device).reshape(-1, self.obs_dim)
-        q = self.critic(o, self.actor(o)).reshape(-1, 1).double().cpu().numpy()
+        q = self.state_value_device(state).reshape(-1, 1).double().cpu().numpy()
         return q[0] if single else q
+
+    def state_value_device(self, state):
+        """Q(s, pi(s)) for a batch of states as a DEVICE tensor [m] (no host round trip: the SmartStart selection of the
+        vectorised loop feeds candidate states gathered from the device replay ring)."""
+        o = torch.as_tensor(state, dtype=torch.float32, device=self.device).reshape(-1, self.obs_dim)
+        return self.critic(o, self.actor(o)).reshape(-1)
 
     def observe(self, state, action, reward, new_state, done):
         """:242-247 (store_transition, ddpg_editted.py:281-285)"""

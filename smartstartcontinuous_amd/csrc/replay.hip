@@ -13,7 +13,7 @@
 
 namespace ssc {
 
-enum : uint32_t { TAG_REPLAY = 5 };
+enum : uint32_t { TAG_REPLAY = 5, TAG_SMART_START = 7 };
 
 struct ReplayAppendArgs {
     ssc_replay_ring ring;
@@ -40,6 +40,171 @@ __global__ __launch_bounds__(kBlock) void replay_append_kernel(ReplayAppendArgs 
     g.ring.a[pos] = g.log.act[src];
     g.ring.r[pos] = g.log.rew[src] * g.reward_scale;   // DDPG_Baselines_agent.observe scales the reward (:238-240)
     g.ring.t[pos] = g.log.done[k * g.done_row_stride + e];
+}
+
+// The same append with the episode index (ssc_replay_ring::ep_steps / ep_run): one thread per env walks its column
+// of the chunk in step order (coalesced across envs on both sides), counting the steps of its running episode.
+__global__ __launch_bounds__(kBlock) void replay_append_indexed_kernel(ReplayAppendArgs g, int32_t K) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= g.n) return;
+    const int od = g.ring.obs_dim;
+    int32_t run = g.ring.ep_run[e];
+    for (int32_t k = 0; k < K; ++k) {
+        const int64_t src = (int64_t)k * g.row_stride + e;
+        const uint8_t t = g.log.done[(int64_t)k * g.done_row_stride + e];
+        run += 1;
+        const int64_t j = (int64_t)k * g.n + e;
+        if (j >= g.first) {
+            const int64_t pos = (g.start + j) % g.ring.capacity;
+#pragma unroll
+            for (int c = 0; c < SSC_MAX_OBS; ++c)
+                if (c < od) {
+                    g.ring.s[pos * od + c] = g.log.obs[c][src];
+                    g.ring.s2[pos * od + c] = g.log.obs2[c][src];
+                }
+            g.ring.a[pos] = g.log.act[src];
+            g.ring.r[pos] = g.log.rew[src] * g.reward_scale;
+            g.ring.t[pos] = t;
+            g.ring.ep_steps[pos] = run;
+        }
+        if (t) run = 0;  // rlTrain breaks on done and the next step opens a new episode (rlTrain.py:97, replay_buffer.py:109-115)
+    }
+    g.ring.ep_run[e] = run;
+}
+
+// ---- smart-start index queries --------------------------------------------------------------------------------
+struct SmartStartArgs {
+    const int32_t *ep_steps;
+    int64_t capacity, count, size, n;
+    int32_t n_ss;
+    uint64_t seed, counter;
+    int32_t *idx, *n_out;
+    int32_t tsize;     // hash-set cells: power of two >= 4 * n_ss
+};
+
+// buffer index i (0 = oldest) is a possible smart start iff the first recorded step of its episode is still in the ring
+__device__ __forceinline__ bool smart_start_valid(const SmartStartArgs &a, int64_t i) {
+    const int64_t rec = a.count - a.size + i;
+    const int32_t L = a.ep_steps[rec % a.capacity];
+    return L >= 1 && rec - (int64_t)(L - 1) * a.n >= a.count - a.size;
+}
+
+constexpr int kSmartBlock = 1024, kSmartMaxRounds = 64;
+
+// ONE workgroup; slot s (< n_ss) is served by thread s % 1024.  An open-addressing hash set in the workspace:
+// keys[h] = buffer index + 1 (0 = empty, claimed by atomicCAS), owners[h] = (round << 12 | slot) of the slot that
+// holds the key, lowered with atomicMin -- so of all the slots that want a key in a round the LOWEST owns it whatever
+// the thread order, and a key taken in an earlier round (smaller round field) can never be taken over.
+__global__ __launch_bounds__(kSmartBlock) void smart_start_indices_kernel(SmartStartArgs a, uint32_t *keys, uint32_t *owners) {
+    constexpr int SPT = 4;  // slots per thread: n_ss <= 4096
+    __shared__ int n_unresolved, n_done;
+    const uint32_t mask = (uint32_t)a.tsize - 1u;
+    for (int i = threadIdx.x; i < a.tsize; i += kSmartBlock) {
+        keys[i] = 0u;
+        owners[i] = 0xFFFFFFFFu;
+    }
+    int32_t val[SPT];
+    bool done[SPT];
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        val[q] = -1;
+        done[q] = (int)(threadIdx.x + q * kSmartBlock) >= a.n_ss;
+    }
+    __syncthreads();
+    for (int round = 0; round < kSmartMaxRounds; ++round) {
+        if (threadIdx.x == 0) n_unresolved = 0;
+        __syncthreads();
+        uint32_t cand[SPT];
+        bool ok[SPT];
+        // phase 1: draw, and bid for the candidate's key
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const uint32_t slot = threadIdx.x + q * kSmartBlock;
+            ok[q] = false;
+            cand[q] = 0;
+            if (done[q]) continue;
+            const u32x4 w = rng_words(a.seed, a.counter, ((uint64_t)round << 20) | slot, TAG_SMART_START);
+            cand[q] = (uint32_t)(((uint64_t)w.x * (uint64_t)a.size) >> 32);
+            if (!smart_start_valid(a, cand[q])) continue;
+            ok[q] = true;
+            uint32_t h = (cand[q] * 2654435761u) & mask;
+            for (int probe = 0; probe < a.tsize; ++probe) {
+                const uint32_t prev = atomicCAS(&keys[h], 0u, cand[q] + 1u);
+                if (prev == 0u || prev == cand[q] + 1u) {
+                    atomicMin(&owners[h], ((uint32_t)round << 12) | slot);
+                    break;
+                }
+                h = (h + 1u) & mask;
+            }
+        }
+        __syncthreads();
+        // phase 2: whoever owns its key keeps it
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const uint32_t slot = threadIdx.x + q * kSmartBlock;
+            if (done[q]) continue;
+            if (ok[q]) {
+                uint32_t h = (cand[q] * 2654435761u) & mask;
+                for (int probe = 0; probe < a.tsize; ++probe) {
+                    if (keys[h] == cand[q] + 1u) {
+                        if (owners[h] == (((uint32_t)round << 12) | slot)) { val[q] = (int32_t)cand[q]; done[q] = true; }
+                        break;
+                    }
+                    h = (h + 1u) & mask;
+                }
+            }
+            if (!done[q]) atomicAdd(&n_unresolved, 1);
+        }
+        __syncthreads();
+        if (n_unresolved == 0) break;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_done = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int slot = threadIdx.x + q * kSmartBlock;
+        if (slot < a.n_ss) {
+            a.idx[slot] = val[q];
+            if (val[q] >= 0) atomicAdd(&n_done, 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *a.n_out = n_done;
+}
+
+struct EpisodePathArgs {
+    ssc_replay_ring ring;
+    int64_t count, size, n;
+    const int32_t *buffer_index;
+    int32_t max_len;
+    float *path;
+    int32_t *len;
+};
+
+__global__ __launch_bounds__(kBlock) void episode_path_kernel(EpisodePathArgs a) {
+    const int64_t i = *a.buffer_index;
+    const int od = a.ring.obs_dim;
+    int32_t rows = 0;
+    int64_t rec = 0;
+    int32_t L = 0;
+    if (i >= 0 && i < a.size) {
+        rec = a.count - a.size + i;
+        L = a.ring.ep_steps[rec % a.ring.capacity];
+        if (L >= 1 && rec - (int64_t)(L - 1) * a.n >= a.count - a.size) rows = (L < a.max_len ? L : a.max_len) + 1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.len = rows;
+    if (rows == 0) return;
+    const int32_t steps = rows - 1;   // the newest `steps` states of the prefix, oldest first, then s2 of the record
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < (int64_t)rows * od; e += (int64_t)gridDim.x * kBlock) {
+        const int32_t m = (int32_t)(e / od), c = (int32_t)(e % od);
+        if (m < steps) {
+            const int64_t r = rec - (int64_t)(steps - 1 - m) * a.n;
+            a.path[e] = a.ring.s[(r % a.ring.capacity) * od + c];
+        } else {
+            a.path[e] = a.ring.s2[(rec % a.ring.capacity) * od + c];
+        }
+    }
 }
 
 // One wave per batch.  Slot i draws candidate (word0(Philox(seed; batch id, attempt << 8 | i)) * size) >> 32 in
@@ -95,8 +260,67 @@ int ssc_replay_append(const ssc_replay_ring *ring, const ssc_transition_log *log
     g.count = total < ring->capacity ? total : ring->capacity;  // older records of the chunk would be overwritten anyway
     g.first = total - g.count;
     g.start = start; g.reward_scale = reward_scale;
+    SSC_REQUIRE((ring->ep_steps == nullptr) == (ring->ep_run == nullptr), "ssc_replay_append: ep_steps and ep_run come together");
+    if (ring->ep_steps != nullptr) {
+        SSC_REQUIRE(start % n == 0, "ssc_replay_append: an indexed ring takes whole steps of n = %lld envs (start = %lld)",
+                    (long long)n, (long long)start);
+        hipLaunchKernelGGL(replay_append_indexed_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream), g, K);
+        return check_launch("ssc_replay_append");
+    }
     hipLaunchKernelGGL(replay_append_kernel, dim3(blocks_for(g.count)), dim3(kBlock), 0, as_stream(stream), g);
     return check_launch("ssc_replay_append");
+}
+
+static int smart_table_size(int32_t n_ss) {
+    int t = 1024;
+    while (t < 4 * n_ss) t <<= 1;
+    return t;
+}
+
+size_t ssc_replay_smart_start_workspace_bytes(int32_t n_ss) {
+    return n_ss > 0 ? (size_t)smart_table_size(n_ss) * 8 : 256;
+}
+
+int ssc_replay_smart_start_indices(const ssc_replay_ring *ring, int64_t count, int64_t n, int32_t n_ss, uint64_t seed,
+                                   uint64_t counter, int32_t *d_idx, int32_t *d_n, void *d_workspace,
+                                   size_t workspace_bytes, ssc_stream_t stream) {
+    SSC_REQUIRE(ring != nullptr, "ssc_replay_smart_start_indices: NULL ring");
+    SSC_REQUIRE(ring->ep_steps != nullptr, "ssc_replay_smart_start_indices: the ring keeps no episode index (ep_steps NULL)");
+    SSC_REQUIRE(ring->capacity > 0 && count >= 0 && n >= 1, "ssc_replay_smart_start_indices: bad sizes");
+    SSC_REQUIRE(n_ss >= 0 && n_ss <= 4096, "ssc_replay_smart_start_indices: n_ss %d not in 0..4096", n_ss);
+    SSC_REQUIRE(d_n != nullptr, "ssc_replay_smart_start_indices: d_n NULL");
+    const int64_t size = count < ring->capacity ? count : ring->capacity;
+    SSC_REQUIRE(size <= 0x7fffffffLL, "ssc_replay_smart_start_indices: ring too large for int32 buffer indices");
+    if (n_ss == 0 || size == 0) {
+        return check_hip(hipMemsetAsync(d_n, 0, sizeof(int32_t), as_stream(stream)), "hipMemsetAsync(d_n)");
+    }
+    SSC_REQUIRE(d_idx != nullptr, "ssc_replay_smart_start_indices: d_idx NULL");
+    SSC_REQUIRE(d_workspace && workspace_bytes >= ssc_replay_smart_start_workspace_bytes(n_ss),
+                "ssc_replay_smart_start_indices: workspace too small");
+    SmartStartArgs a;
+    a.ep_steps = ring->ep_steps; a.capacity = ring->capacity; a.count = count; a.size = size; a.n = n;
+    a.n_ss = n_ss; a.seed = seed; a.counter = counter; a.idx = d_idx; a.n_out = d_n;
+    a.tsize = smart_table_size(n_ss);
+    uint32_t *keys = static_cast<uint32_t *>(d_workspace);
+    hipLaunchKernelGGL(smart_start_indices_kernel, dim3(1), dim3(kSmartBlock), 0, as_stream(stream), a, keys, keys + a.tsize);
+    return check_launch("ssc_replay_smart_start_indices");
+}
+
+int ssc_replay_episode_path(const ssc_replay_ring *ring, int64_t count, int64_t n, const int32_t *d_buffer_index,
+                            int32_t max_len, float *d_path, int32_t *d_len, ssc_stream_t stream) {
+    SSC_REQUIRE(ring != nullptr, "ssc_replay_episode_path: NULL ring");
+    SSC_REQUIRE(ring->ep_steps != nullptr, "ssc_replay_episode_path: the ring keeps no episode index (ep_steps NULL)");
+    SSC_REQUIRE(ring->capacity > 0 && count >= 0 && n >= 1 && max_len >= 1, "ssc_replay_episode_path: bad sizes");
+    SSC_REQUIRE(ring->obs_dim >= 1 && ring->obs_dim <= SSC_MAX_OBS, "ssc_replay_episode_path: obs_dim out of range");
+    SSC_REQUIRE(ring->s && ring->s2 && d_buffer_index && d_path && d_len, "ssc_replay_episode_path: NULL device pointer");
+    EpisodePathArgs a;
+    a.ring = *ring; a.count = count; a.size = count < ring->capacity ? count : ring->capacity; a.n = n;
+    a.buffer_index = d_buffer_index; a.max_len = max_len; a.path = d_path; a.len = d_len;
+    const int64_t elems = ((int64_t)max_len + 1) * ring->obs_dim;
+    int64_t blocks = blocks_for(elems);
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(episode_path_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a);
+    return check_launch("ssc_replay_episode_path");
 }
 
 int ssc_replay_sample(uint64_t seed, uint64_t counter0, int64_t size, int32_t n_batches, int32_t batch_size,

@@ -195,10 +195,15 @@ class DeviceReplayBuffer:
     device too (``ssc_replay_sample``, uniform without replacement inside a batch like ``random.sample``,
     replay_buffer.py:79-83), so rollout -> replay -> ``ssc_ddpg_train`` never goes through the host.
 
-    The SmartStart index queries (episode starts, smart-start paths) stay with the host
-    :class:`ReplayBuffer`; this ring serves the learner's data path."""
+    ``track_episodes=True`` (needs ``n_envs``, the env count of the chunks it is fed) keeps the episode index on the
+    device too -- per record the step count of its env's running episode (``ssc_replay_ring::ep_steps``) -- and with it
+    the SmartStart queries of the reference buffer: :meth:`get_possible_smart_start_indices`
+    (replay_buffer.py:136-152), :meth:`get_episodic_path_to_buffer_index` (:154-176) and :meth:`get_all_states`
+    (:102-103), all returning DEVICE tensors.  Buffer indices count from the oldest record in the ring (0) to the newest
+    (len - 1), records in append order (step-major, then env)."""
 
-    def __init__(self, capacity, obs_dim, act_dim=1, device="cuda", seed=0):
+    def __init__(self, capacity, obs_dim, act_dim=1, device="cuda", seed=0, track_episodes=False, n_envs=None,
+                 max_path_len=1001):
         import ctypes
         import torch
         from . import _ffi
@@ -216,6 +221,19 @@ class DeviceReplayBuffer:
         self.t = f(self.capacity, dt=torch.uint8)
         self.count = 0            # records appended so far (the reference's running next_episode_number-like count)
         self.seed, self._batches_drawn = int(seed), 0
+        self.track_episodes = bool(track_episodes)
+        self.ep_steps = self.ep_run = None
+        if self.track_episodes:
+            if n_envs is None:
+                raise ValueError("track_episodes needs n_envs (records of one env lie n_envs apart in the ring)")
+            self.n_envs = int(n_envs)
+            self.ep_steps = f(self.capacity, dt=torch.int32)
+            self.ep_run = f(self.n_envs, dt=torch.int32)
+            self.max_path_len = int(max_path_len)
+            self._next_step0 = None       # global step index the next contiguous chunk starts at
+            self._queries = 0
+            self._path = f(self.max_path_len + 1, obs_dim)
+            self._path_len = f(1, dt=torch.int32)
 
     def __len__(self):
         return min(self.count, self.capacity)
@@ -229,12 +247,22 @@ class DeviceReplayBuffer:
         r = self._ffi.ReplayRing()
         r.s, r.a, r.r, r.t, r.s2 = (x.data_ptr() for x in (self.s, self.a, self.r, self.t, self.s2))
         r.capacity, r.obs_dim, r.act_dim = self.capacity, self.obs_dim, self.act_dim
+        if self.track_episodes:
+            r.ep_steps, r.ep_run = self.ep_steps.data_ptr(), self.ep_run.data_ptr()
         return r
 
     def append_chunk(self, chunk, reward_scale=1.0, last_steps=None):
         """``ReplayBuffer.add`` for every record of a :class:`TransitionChunk` (step-major, then env);
         ``last_steps`` keeps only the newest steps of the chunk."""
         K = chunk.K if last_steps is None else min(int(last_steps), chunk.K)
+        if self.track_episodes:
+            if chunk.N != self.n_envs:
+                raise ValueError(f"this ring indexes episodes of {self.n_envs} envs, the chunk has {chunk.N}")
+            # an env's running step count carries over only when this chunk continues where the last append stopped
+            first_step = chunk.step0 + chunk.K - K
+            if self._next_step0 is not None and first_step != self._next_step0:
+                self.ep_run.zero_()
+            self._next_step0 = chunk.step0 + chunk.K
         log = chunk.as_struct()
         if K < chunk.K:                       # skip the first chunk.K - K steps: advance every column pointer
             skip = chunk.K - K
@@ -263,3 +291,64 @@ class DeviceReplayBuffer:
         """(s, a, r, t, s2) device tensors of one batch -- the ReplayBuffer.sample_batch tuple."""
         i = self.sample_indices(1, batch_size)[0].long()
         return self.s[i], self.a[i], self.r[i], self.t[i].bool(), self.s2[i]
+
+    # ------------------------------------------------------------ SmartStart queries (track_episodes) --
+    def _need_index(self):
+        if not self.track_episodes:
+            raise RuntimeError("this DeviceReplayBuffer was built without track_episodes=True")
+
+    def get_all_states(self):
+        """replay_buffer.py:102-103: every s (oldest first) plus the newest record's s2 -- a device tensor."""
+        torch = self._torch
+        size = len(self)
+        if size == 0:
+            return torch.zeros((0, self.obs_dim), device=self.device)
+        if self.count <= self.capacity:
+            s = self.s[:size]
+        else:
+            h = self.count % self.capacity
+            s = torch.cat([self.s[h:], self.s[:h]])
+        return torch.cat([s, self.s2[(self.count - 1) % self.capacity][None, :]])
+
+    def physical(self, buffer_index):
+        """ring rows of buffer indices (tensor or int; 0 = oldest record)."""
+        return (buffer_index + (self.count - len(self))) % self.capacity
+
+    def get_possible_smart_start_indices(self, n_ss):
+        """replay_buffer.py:136-152 on the device: up to ``n_ss`` distinct buffer indices (int64 device tensor) drawn
+        uniformly from the records whose episode start is still in the ring; None when there is none."""
+        self._need_index()
+        torch, ct, ffi = self._torch, self._ctypes, self._ffi
+        n_ss = int(n_ss)
+        if len(self) == 0 or n_ss <= 0:
+            return None
+        if n_ss > 4096:
+            raise ValueError("n_ss <= 4096 on the device path")
+        idx = torch.empty(n_ss, dtype=torch.int32, device=self.device)
+        n_out = torch.zeros(1, dtype=torch.int32, device=self.device)
+        nb = self.lib.ssc_replay_smart_start_workspace_bytes(n_ss)
+        ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        ring = self.ring_struct()
+        with torch.cuda.device(self.device):
+            ffi.check(self.lib.ssc_replay_smart_start_indices(ct.byref(ring), self.count, self.n_envs, n_ss, self.seed ^ 0x5353,
+                                                              self._queries, ffi.ptr(idx), ffi.ptr(n_out), ffi.ptr(ws), nb,
+                                                              self._stream()))
+        self._queries += 1
+        got = idx[idx >= 0].long()
+        return got if got.numel() > 0 else None
+
+    def get_episodic_path_to_buffer_index(self, buffer_index):
+        """replay_buffer.py:154-176 on the device: [L + 1, obs_dim] device tensor -- the states of the episode containing
+        ``buffer_index`` (an int or a 1-element device tensor, e.g. one entry of get_possible_smart_start_indices) up to
+        that record, then its s2.  Raises if the episode start has left the ring."""
+        self._need_index()
+        torch, ct, ffi = self._torch, self._ctypes, self._ffi
+        bi = torch.as_tensor(buffer_index, device=self.device).reshape(1).to(torch.int32)
+        ring = self.ring_struct()
+        with torch.cuda.device(self.device):
+            ffi.check(self.lib.ssc_replay_episode_path(ct.byref(ring), self.count, self.n_envs, ffi.ptr(bi), self.max_path_len,
+                                                       ffi.ptr(self._path), ffi.ptr(self._path_len), self._stream()))
+        rows = int(self._path_len.item())          # the ONE host read of a smart-start query: the path length
+        if rows == 0:
+            raise ValueError(": (   -   the episode start of this record is no longer in the ring")
+        return self._path[:rows].clone()

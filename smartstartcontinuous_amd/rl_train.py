@@ -236,18 +236,22 @@ def rl_train_vec(env, policy, num_chunks, chunk_steps=1024, ring_capacity=1 << 2
 
 
 def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1 << 20, train_iters=None,
-                      replay_last_steps=None, seed=0, ring_capacity=1 << 20):
+                      replay_last_steps=None, seed=0, ring_capacity=1 << 20, track_episodes=False):
     """Actor-learner loop entirely in HBM: every chunk is a fused rollout of ``chunk_steps`` steps of all
     ``env.n`` envs under the agent's current actor (+ OU noise), appended to a device replay ring, followed
     by ``train_iters`` DDPG iterations (default ``agent.num_train_iterations``) on batches drawn from it.
     The vectorised counterpart of rlTrain + DDPG_Baselines_agent.observe/train
-    (rlTrain.py:75-100, DDPG_Baselines_agent.py:238-273).  Returns (Summary, losses per chunk, replay)."""
+    (rlTrain.py:75-100, DDPG_Baselines_agent.py:238-273).  ``track_episodes`` keeps the episode index in the device
+    ring as well, so that ``smartstart.device_smart_start_path(replay, agent, radii, n_ss)`` can pick a smart-start
+    state and recover the path to it without the replay contents leaving HBM.
+    Returns (Summary, losses per chunk, replay)."""
     from .replay_buffer import DeviceReplayBuffer
     from .vec_env import EpisodeRing, TransitionChunk
     summary = Summary("vec_ddpg_" + env.spec.id)
     ring = EpisodeRing(ring_capacity, env.device)
     chunk = TransitionChunk(env.obs_dim, chunk_steps, env.n, env.device)
-    replay = DeviceReplayBuffer(replay_capacity, env.obs_dim, 1, env.device, seed=seed)
+    replay = DeviceReplayBuffer(replay_capacity, env.obs_dim, 1, env.device, seed=seed, track_episodes=track_episodes,
+                                n_envs=env.n, max_path_len=(env.spec.max_episode_steps or 1000) + 1)
     losses = []
     generations = 0.0   # finished episodes / env.n: epsilon decays once per episode PER ENV (DDPG_Baselines_agent.py:255-258)
     for _ in range(num_chunks):

@@ -14,7 +14,7 @@ import torch
 from . import _ffi
 from .agents import NND_MB_agent, ReplayBufferRLAgent, RLAgent
 from .numerical import volume_of_n_dimensional_hyperellipsoid
-from .replay_buffer import ReplayBuffer
+from .replay_buffer import DeviceReplayBuffer, ReplayBuffer
 
 
 def _stream():
@@ -58,6 +58,30 @@ def ucb_argmax(values, pdf, buffer_len, volume, exploitation_param, exploration_
                                              float(exploitation_param), float(exploration_param), float(buffer_len),
                                              float(volume), _ffi.ptr(ucb), _ffi.ptr(best), _stream()))
     return ucb, best
+
+
+def device_smart_start_path(replay, agent, radii, n_ss, exploitation_param=1., exploration_param=2.):
+    """``get_smart_start_path`` (smartexplorationcontinuous.py:223-305) with everything up to the chosen path on the
+    device: candidates from the device ring's episode index (``DeviceReplayBuffer.get_possible_smart_start_indices``),
+    V = Q(s, pi(s)) (``agent.state_value_device``), the Gaussian KDE over every state in the ring, UCB1 argmax, and the
+    episodic path of the winner gathered out of the ring -- the replay contents never visit the host (the reference
+    re-reads its whole buffer per episode, :258-260).  -> (path [L + 1, obs_dim] device tensor, buffer index) or None."""
+    if not isinstance(replay, DeviceReplayBuffer) or not replay.track_episodes:
+        raise TypeError("device_smart_start_path needs a DeviceReplayBuffer(track_episodes=True)")
+    if len(replay) == 0:
+        return None
+    idx = replay.get_possible_smart_start_indices(n_ss)                                       # :243-246
+    if idx is None:
+        return None
+    all_states = replay.get_all_states()                                                      # :258
+    wh, norm = kde_scott_bandwidth(all_states)                                                # :260
+    volume = volume_of_n_dimensional_hyperellipsoid(radii) if radii is not None else 1         # :262-268
+    cand = replay.s2[replay.physical(idx)]                                                     # :272-273
+    values = agent.state_value_device(cand)                                                    # :274
+    pdf = kde_evaluate(all_states, cand, wh, norm)                                             # :275
+    _, best = ucb_argmax(values, pdf, len(replay), volume, exploitation_param, exploration_param)   # :276-280
+    chosen = idx[best.long()]                                                                  # stays on the device
+    return replay.get_episodic_path_to_buffer_index(chosen), chosen
 
 
 class SmartStartContinuous(RLAgent):
@@ -119,6 +143,10 @@ class SmartStartContinuous(RLAgent):
 
     def get_smart_start_path(self):
         """:223-305"""
+        if isinstance(self.replay_buffer, DeviceReplayBuffer):
+            got = device_smart_start_path(self.replay_buffer, self.agent, self.nnd_mb_agent.radii, self.n_ss,
+                                          self.exploitation_param, self.exploration_param)
+            return None if got is None else [row for row in got[0].double().cpu().numpy()]
         if len(self.replay_buffer) == 0:
             return None
         possible_start_indices = self.replay_buffer.get_possible_smart_start_indices(self.n_ss)

@@ -98,17 +98,17 @@ def test_struct_layouts_match_header(built, tmp_path):
     import subprocess
     from smartstartcontinuous_amd import _ffi
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "ssc.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "ssc.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(ssc_env_params),sizeof(ssc_actor_desc),sizeof(ssc_ou_desc),sizeof(ssc_policy_desc),'
                    'sizeof(ssc_rollout_state),sizeof(ssc_transition_log),sizeof(ssc_episode_ring),'
-                   'sizeof(ssc_mlp_desc),sizeof(ssc_norm),sizeof(ssc_mpc_problems),sizeof(ssc_critic_desc),sizeof(ssc_ddpg_desc),sizeof(ssc_replay_view),sizeof(ssc_mlp_train_desc));return 0;}\n')
+                   'sizeof(ssc_mlp_desc),sizeof(ssc_norm),sizeof(ssc_mpc_problems),sizeof(ssc_critic_desc),sizeof(ssc_ddpg_desc),sizeof(ssc_replay_view),sizeof(ssc_mlp_train_desc),sizeof(ssc_replay_ring));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     expect = [ctypes.sizeof(c) for c in (_ffi.EnvParams, _ffi.ActorDesc, _ffi.OuDesc, _ffi.PolicyDesc,
                                          _ffi.RolloutState, _ffi.TransitionLog, _ffi.EpisodeRing, _ffi.MlpDesc,
                                          _ffi.Norm, _ffi.MpcProblems, _ffi.CriticDesc,
-                                         _ffi.DdpgDesc, _ffi.ReplayView, _ffi.MlpTrainDesc)]
+                                         _ffi.DdpgDesc, _ffi.ReplayView, _ffi.MlpTrainDesc, _ffi.ReplayRing)]
     assert sizes == expect
 
 

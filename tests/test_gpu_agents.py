@@ -471,3 +471,136 @@ def test_rl_train_vec_ddpg_loop_in_hbm(ssc):
     # the newest records in the ring are the last rollout's: rewards scaled, dynamics consistent
     r = replay.r.cpu().numpy(); a = replay.a.cpu().numpy()[:, 0]; t = replay.t.cpu().numpy()
     assert np.allclose(r[t == 0], 0.5 * (-0.1 * a[t == 0] ** 2), atol=1e-6)
+
+
+def _fake_chunk(ssc, K, n, done, step0, base=0.0):
+    """A TransitionChunk with recognisable content: obs = (global step, env), obs2 = (global step + 1, env)."""
+    chunk = ssc.TransitionChunk(2, K, n, "cuda")
+    k = torch.arange(K, dtype=torch.float32, device="cuda")[:, None] + float(step0) + base
+    e = torch.arange(n, dtype=torch.float32, device="cuda")[None, :].expand(K, n)
+    chunk.obs[0].copy_(k.expand(K, n)); chunk.obs[1].copy_(e)
+    chunk.obs2[0].copy_(k.expand(K, n) + 1.0); chunk.obs2[1].copy_(e)
+    chunk.act.zero_(); chunk.rew.zero_()
+    chunk.done.copy_(torch.as_tensor(done, dtype=torch.uint8, device="cuda"))
+    chunk.step0 = step0
+    return chunk
+
+
+def test_device_replay_episode_index_matches_reference_trace(ssc, golden_dir):
+    """The device ring's episode index against the REFERENCE ReplayBuffer's own trace (tests/golden/replay_buffer_kats.npz:
+    12 episodes of 3-30 steps through a 50-record buffer, generated by running smartstart/RLAgents/replay_buffer.py):
+    same first smart-start index, same episodic paths (replay_buffer.py:154-176), same get_all_states (:102-103).  n = 1
+    is the reference's setting; the ring is fed in three chunks so that the per-env step count carries across appends."""
+    from smartstartcontinuous_amd.replay_buffer import DeviceReplayBuffer
+    g = np.load(f"{golden_dir}/replay_buffer_kats.npz")
+    total = int(g["ep_lens"].sum())
+    done = np.zeros((total, 1), np.uint8)
+    done[np.cumsum(g["ep_lens"]) - 1, 0] = 1                     # an episode ends where the trace starts the next one
+    replay = DeviceReplayBuffer(50, 2, 1, seed=1, track_episodes=True, n_envs=1, max_path_len=64)
+    k0 = 0
+    for K in (100, 100, total - 200):
+        replay.append_chunk(_fake_chunk(ssc, K, 1, done[k0:k0 + K], k0))
+        k0 += K
+    assert len(replay) == 50 and replay.count == total
+    eps = replay.ep_steps.cpu().numpy()
+    valid = O.smart_start_valid(eps, 50, total, 1)
+    assert int(np.argmax(valid)) == int(g["final_first_index"]) and valid[int(g["final_first_index"]):].all()
+    for j in range(3):
+        path = replay.get_episodic_path_to_buffer_index(int(g[f"path_idx_{j}"])).double().cpu().numpy()
+        assert np.array_equal(path, g[f"path_to_{j}"]), j
+    with pytest.raises(ValueError):
+        replay.get_episodic_path_to_buffer_index(0)             # its episode start was evicted
+    assert np.array_equal(replay.get_all_states().double().cpu().numpy(), g["all_states"])
+    idx = replay.get_possible_smart_start_indices(10).cpu().numpy()
+    assert len(idx) == 10 and len(set(idx.tolist())) == 10 and idx.min() >= int(g["final_first_index"])
+    assert np.array_equal(idx, O.smart_start_indices(valid, 10, 1 ^ 0x5353, 0))
+    # more requested than valid records exist: every valid index once
+    many = replay.get_possible_smart_start_indices(64)
+    assert sorted(many.cpu().tolist()) == np.nonzero(valid)[0].tolist()
+
+
+@pytest.mark.parametrize("n,K,cap,chunks", [(37, 23, 1000, 3), (64, 40, 1500, 4), (300, 9, 4096, 5)])
+def test_device_replay_episode_index_many_envs(ssc, n, K, cap, chunks):
+    """n interleaved envs with random episode ends: ep_steps, the valid set, the Philox-keyed sample and the recovered
+    paths against the restatement; each path must also equal what the HOST ReplayBuffer (the reference's
+    bookkeeping, pinned by the reference trace) recovers for the same env fed alone."""
+    from smartstartcontinuous_amd.replay_buffer import DeviceReplayBuffer, ReplayBuffer
+    rng = np.random.default_rng(n)
+    replay = DeviceReplayBuffer(cap, 2, 1, seed=9, track_episodes=True, n_envs=n, max_path_len=4096)
+    dones, run, k0 = [], None, 0
+    for c in range(chunks):
+        d = (rng.random((K, n)) < 0.08).astype(np.uint8)
+        replay.append_chunk(_fake_chunk(ssc, K, n, d, k0))
+        dones.append(d)
+        k0 += K
+    done = np.concatenate(dones)
+    steps, _ = O.replay_episode_steps(done)
+    count = chunks * K * n
+    size = min(count, cap)
+    ring_steps = np.zeros(cap, np.int64)
+    rec = np.arange(count - size, count)
+    ring_steps[rec % cap] = steps.reshape(-1)[rec]
+    assert np.array_equal(replay.ep_steps.cpu().numpy()[rec % cap], ring_steps[rec % cap])
+    valid = O.smart_start_valid(ring_steps, cap, count, n)
+    got = replay.get_possible_smart_start_indices(200).cpu().numpy()
+    want = O.smart_start_indices(valid, 200, 9 ^ 0x5353, 0)
+    assert np.array_equal(got, want[want >= 0]) and valid[got].all() and len(set(got.tolist())) == len(got)
+    s_ring, s2_ring = replay.s.cpu().numpy(), replay.s2.cpu().numpy()
+    for bi in got[:12]:
+        path = replay.get_episodic_path_to_buffer_index(int(bi)).cpu().numpy()
+        assert np.array_equal(path, O.replay_episode_path(s_ring, s2_ring, ring_steps, cap, count, n, int(bi), 4096))
+        # the same env alone through the host buffer (reference semantics): identical path
+        r = count - size + int(bi)
+        k_rec, e = r // n, r % n
+        host, agent = None, object()
+        host = ReplayBuffer(agent, 10 ** 6)
+        host.start_new_episode(agent)
+        for k in range(k_rec + 1):
+            host.add(agent, np.array([k, e], float), [0.0], 0.0, bool(done[k, e]), np.array([k + 1, e], float))
+            if done[k, e] and k < k_rec:
+                host.start_new_episode(agent)
+        assert np.array_equal(path, np.asarray(host.get_episodic_path_to_buffer_index(k_rec)))
+    # a gap between two appends restarts every env's running episode
+    replay.append_chunk(_fake_chunk(ssc, 3, n, np.zeros((3, n), np.uint8), k0 + 50))
+    newest = (replay.count - 1 - np.arange(n)) % cap
+    assert (replay.ep_steps.cpu().numpy()[newest] == 3).all()
+
+
+def test_device_smart_start_selection_without_host_replay(ssc):
+    """get_smart_start_path (smartexplorationcontinuous.py:223-305) over the device ring: candidates, V(s), KDE, UCB1 and
+    the winner's episodic path never leave the GPU; checked against the restatement fed the ring's contents."""
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    from smartstartcontinuous_amd.replay_buffer import DeviceReplayBuffer
+    from smartstartcontinuous_amd.smartstart import device_smart_start_path
+    n, K = 128, 60
+    env = ssc.VecEnv("MountainCarContinuous-v0", n, seed=21, max_episode_steps=25)
+    one = ssc.SingleEnvView(ssc.VecEnv("MountainCarContinuous-v0", 1, seed=21))
+    agent = DDPG_Baselines_agent(one, None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32, lastLayerTanh=True, seed=2)
+    replay = DeviceReplayBuffer(5000, 2, 1, seed=4, track_episodes=True, n_envs=n)
+    for _ in range(2):
+        replay.append_chunk(env.rollout(K, ssc.RandomPolicy()))
+    radii = np.array([0.01, 0.002])
+    path, chosen = device_smart_start_path(replay, agent, radii, n_ss=300)
+    torch.cuda.synchronize()
+    count, cap = replay.count, replay.capacity
+    size = min(count, cap)
+    eps = replay.ep_steps.cpu().numpy()
+    valid = O.smart_start_valid(eps, cap, count, n)
+    idx = O.smart_start_indices(valid, 300, 4 ^ 0x5353, 0)
+    idx = idx[idx >= 0]
+    phys = (idx + count - size) % cap
+    s_ring, s2_ring = replay.s.cpu().numpy().astype(np.float64), replay.s2.cpu().numpy().astype(np.float64)
+    order = (np.arange(size) + count - size) % cap
+    all_states = np.concatenate([s_ring[order], s2_ring[(count - 1) % cap][None]])
+    cand = s2_ring[phys]
+    _cov, wh, norm = O.kde_scott(all_states)
+    pdf = O.kde_evaluate(all_states, cand, wh, norm)
+    cw = {k: v.cpu().numpy().astype(np.float64) for k, v in agent.critic_weights.items()}
+    aw = {k: v.cpu().numpy().astype(np.float64) for k, v in agent.weights.items()}
+    values = O.critic_forward(cand, O.actor_forward(cand, **aw), **cw)[:, 0]
+    ucb, best = O.smart_start_ucb(values, pdf, size, O.hyperellipsoid_volume(radii))
+    # fp32 kernels vs fp64 restatement: the device winner must be (near-)optimal under the restatement's scores
+    pos = int(np.nonzero(idx == int(chosen.item()))[0][0])
+    assert ucb[pos] >= ucb[best] - 1e-3 * abs(ucb[best])
+    want = O.replay_episode_path(replay.s.cpu().numpy(), replay.s2.cpu().numpy(), eps, cap, count, n, int(chosen.item()), 1001)
+    assert np.array_equal(path.cpu().numpy(), want) and path.shape[0] >= 2

@@ -220,3 +220,31 @@ def test_add_noise_matches_reference_rule():
     assert abs((out[:, 0] - data[:, 0]).std() - 0.02) < 1e-3 and abs((out[:, 0] - data[:, 0]).mean()) < 1e-3
     assert abs((out[:, 3] - data[:, 3]).std() - 0.005) < 3e-4
     assert add_noise(np.zeros((0, 3)), 0.01).shape == (0, 3)
+
+
+def test_oracle_episode_index_matches_reference_trace(golden_dir):
+    """The restatement of the VECTORISED ring's episode index (oracle.replay_episode_steps / smart_start_valid /
+    replay_episode_path -- what the device kernels are checked against) on the reference buffer's own trace
+    (replay_buffer_kats.npz, n = 1): same first smart-start index and the same episodic paths as
+    smartstart/RLAgents/replay_buffer.py:136-176 produced."""
+    from oracle import ssc_oracle as O
+    g = np.load(f"{golden_dir}/replay_buffer_kats.npz")
+    total, cap = int(g["ep_lens"].sum()), 50
+    done = np.zeros((total, 1), bool)
+    done[np.cumsum(g["ep_lens"]) - 1, 0] = True
+    steps, run = O.replay_episode_steps(done)
+    assert run[0] == 0 and steps[:, 0].max() == g["ep_lens"].max()
+    s = np.stack([np.arange(total, dtype=float), np.zeros(total)], 1)
+    s_ring, s2_ring, ring_steps = np.zeros((cap, 2)), np.zeros((cap, 2)), np.zeros(cap, np.int64)
+    for j in range(total):                       # FIFO: record j lives at j % capacity
+        s_ring[j % cap], s2_ring[j % cap], ring_steps[j % cap] = s[j], s[j] + [1, 0], steps[j, 0]
+    valid = O.smart_start_valid(ring_steps, cap, total, 1)
+    first = int(g["final_first_index"])
+    assert not valid[:first].any() and valid[first:].all()
+    for j in range(3):
+        path = O.replay_episode_path(s_ring, s2_ring, ring_steps, cap, total, 1, int(g[f"path_idx_{j}"]), 1000)
+        assert np.array_equal(path, g[f"path_to_{j}"])
+    idx = O.smart_start_indices(valid, 20, 5, 0)
+    assert (idx >= first).all() and len(set(idx.tolist())) == 20
+    more = O.smart_start_indices(valid, 64, 5, 1)            # more slots than valid records: every valid index once
+    assert sorted(more[more >= 0].tolist()) == np.nonzero(valid)[0].tolist()
