@@ -73,6 +73,10 @@ typedef struct ssc_actor_desc {
     const float *W1, *b1, *W2, *b2, *W3, *b3; /* device */
     int32_t last_layer_tanh;                  /* models_editted.py:53-56 */
     int32_t precision;                        /* SSC_PREC_*: hidden GEMM in fp32 VALU or bf16 MFMA */
+    float obs_clip;                           /* > 0: the observation is clipped to [-obs_clip, obs_clip] before layer 1 --
+                                                 DDPG_editted feeds its networks tf.clip_by_value(obs, observation_range)
+                                                 (ddpg_editted.py:106-109, observation_range = (-5, 5) in every run);
+                                                 0: no clip (bare Actor_Editted.__call__) */
 } ssc_actor_desc;
 
 /* Exploration noise of DDPG_editted.pi (ddpg_editted.py:266-271):
@@ -318,6 +322,7 @@ typedef struct ssc_critic_desc {
     int32_t obs_dim, act_dim, h1, h2;
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     int32_t last_layer_tanh;
+    float obs_clip;             /* as in ssc_actor_desc (ddpg_editted.py:106-109); 0: no clip */
 } ssc_critic_desc;
 
 /* q[m] = Critic(obs[m][obs_dim], act[m][act_dim]) -- the batched get_q_value of
@@ -358,6 +363,8 @@ typedef struct ssc_ddpg_desc {
     int32_t *adam_t;                                      /* device [2]: MpiAdam step counters (actor, critic) */
     float gamma, tau, actor_lr, critic_lr;
     float beta1, beta2, epsilon;                          /* MpiAdam: 0.9, 0.999, 1e-8 (ddpg_editted.py:176,198) */
+    float obs_clip;                                       /* > 0: obs0 / obs1 clipped to [-obs_clip, obs_clip] before every
+                                                             network (ddpg_editted.py:106-109); 0: no clip */
 } ssc_ddpg_desc;
 
 /* Replay storage the batches are drawn from: row-major device arrays of `capacity` records

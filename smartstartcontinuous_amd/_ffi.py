@@ -40,7 +40,7 @@ class ActorDesc(Structure):
     _fields_ = [("obs_dim", c_int32), ("h1", c_int32), ("h2", c_int32), ("act_dim", c_int32),
                 ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
                 ("W3", c_void_p), ("b3", c_void_p),
-                ("last_layer_tanh", c_int32), ("precision", c_int32)]
+                ("last_layer_tanh", c_int32), ("precision", c_int32), ("obs_clip", c_float)]
 
 
 class OuDesc(Structure):
@@ -92,7 +92,7 @@ class MpcProblems(Structure):
 class CriticDesc(Structure):
     _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("h1", c_int32), ("h2", c_int32),
                 ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
-                ("W3", c_void_p), ("b3", c_void_p), ("last_layer_tanh", c_int32)]
+                ("W3", c_void_p), ("b3", c_void_p), ("last_layer_tanh", c_int32), ("obs_clip", c_float)]
 
 
 class MlpTrainDesc(Structure):
@@ -110,7 +110,7 @@ class DdpgDesc(Structure):
                 ("adam_m_actor", c_void_p), ("adam_v_actor", c_void_p), ("adam_m_critic", c_void_p),
                 ("adam_v_critic", c_void_p), ("adam_t", c_void_p),
                 ("gamma", c_float), ("tau", c_float), ("actor_lr", c_float), ("critic_lr", c_float),
-                ("beta1", c_float), ("beta2", c_float), ("epsilon", c_float)]
+                ("beta1", c_float), ("beta2", c_float), ("epsilon", c_float), ("obs_clip", c_float)]
 
 
 class ReplayView(Structure):

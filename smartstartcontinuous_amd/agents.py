@@ -3,9 +3,10 @@ smartstart/reinforcementLearningCore/agents_abstract_classes.py and GPU-backed c
 ``DDPG_Baselines_agent`` (action path) and ``NND_MB_agent`` (the SmartStart navigator).
 
 Constructor keyword names follow the reference classes so existing call sites keep working; the
-TensorFlow session argument ``sess`` is accepted and ignored.  The DDPG learner step runs on the GPU
-(``ssc_ddpg_train``); dynamics-model training is still "next": the
-navigator's weights are plain torch tensors that a trainer may overwrite through ``set_weights``.
+TensorFlow session argument ``sess`` is accepted and ignored.  Both learners run on the GPU: the DDPG step
+(``ssc_ddpg_train``) and the dynamics-model training of the navigator
+(``ssc_mlp_train_steps``, rank 3; ``NND_MB_agent.train_dynamics_model``).  Weights stay plain torch tensors
+(TensorFlow layout) that a caller may also overwrite through ``set_weights``.
 """
 from __future__ import annotations
 
@@ -173,6 +174,9 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         if critic_l2_reg or clip_norm is not None:
             raise NotImplementedError("critic_l2_reg / clip_norm are not on the accelerated path (unused by every shipped run)")
         self.lastLayerTanh = bool(lastLayerTanh)
+        # DDPG_editted clips what it feeds its networks to observation_range (ddpg_editted.py:66,106-109); the reference
+        # agent never overrides the default (-5, 5), and it applies with normalize_observations=False too
+        self.observation_range = (-5.0, 5.0)
         self.precision = precision
         self.replay_buffer = replay_buffer if replay_buffer is not None else ReplayBuffer(self, buffer_size)
         self.training_enabled = training
@@ -202,6 +206,7 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         d.W1, d.b1, d.W2, d.b2, d.W3, d.b3 = (w[k].data_ptr() for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
         d.last_layer_tanh = int(self.lastLayerTanh)
         d.precision = _ffi.SSC_PREC_F32 if self.precision == "f32" else _ffi.SSC_PREC_BF16_MFMA
+        d.obs_clip = float(self.observation_range[1])
         self._desc = d
 
     def set_critic_weights(self, weights):
@@ -217,6 +222,7 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         c.act_dim = w["W2"].shape[0] - c.h1
         c.W1, c.b1, c.W2, c.b2, c.W3, c.b3 = (w[k].data_ptr() for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
         c.last_layer_tanh = int(self.lastLayerTanh)
+        c.obs_clip = float(self.observation_range[1])
         self._critic_desc = c
 
     def critic(self, obs, act):
@@ -258,7 +264,7 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         n = self.decaying_ou_action_noise
         return ActorPolicy(self.weights, last_layer_tanh=self.lastLayerTanh, precision=precision or "bf16_mfma",
                            ou_mu=float(self.ou["mu"]), ou_sigma=float(self.ou["sigma"]), ou_theta=float(self.ou["theta"]),
-                           ou_dt=n.dt, ou_epsilon=float(max(n.epsilon, 0)))
+                           ou_dt=n.dt, ou_epsilon=float(max(n.epsilon, 0)), obs_clip=float(self.observation_range[1]))
 
     def get_state_value(self, state):
         """:197-204 -> DDPG_editted.get_q_value (ddpg_editted.py:274-279): Q(s, pi(s)) without noise.
@@ -281,7 +287,8 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
             self.train()
 
     def start_new_episode(self, state):
-        self.replay_buffer.start_new_episode(self)
+        """:249-250 -- ``pass`` in the reference: a bare DDPG agent never marks episode starts in its buffer (only the
+        SmartStart wrapper, the buffer's main agent then, does: smartexplorationcontinuous.py:369)."""
 
     def render(self, env, **kwargs):
         return env.render()
@@ -310,6 +317,7 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         d.adam_t = self._adam_t.data_ptr()
         d.gamma, d.tau, d.actor_lr, d.critic_lr = self.gamma, self.tau, self.actor_lr, self.critic_lr
         d.beta1, d.beta2, d.epsilon = 0.9, 0.999, 1e-8          # ddpg_editted.py:176,198
+        d.obs_clip = float(self.observation_range[1])
         return d
 
     def train_on(self, s, a, r, t, s2, batch_idx, n_iters):

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(kBlock) void actor_f32_kernel(ActorWeights w, int64
     const int64_t i = active ? gi : m - 1;
     float o[OBS];
 #pragma unroll
-    for (int c = 0; c < OBS; ++c) o[c] = obs[i * OBS + c];
+    for (int c = 0; c < OBS; ++c) o[c] = clip_obs(obs[i * OBS + c], w.obs_clip);
     ActorF32<OBS, H1, H2> net;
     net.init(w);  // block-cooperative LDS staging: no thread may have exited
     const float a = net.forward(o);
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kBlock) void actor_mfma_kernel(ActorWeights w, int6
     const int64_t i = active ? gi : m - 1;  // whole waves must run the collective forward
     float o[OBS];
 #pragma unroll
-    for (int c = 0; c < OBS; ++c) o[c] = obs[i * OBS + c];
+    for (int c = 0; c < OBS; ++c) o[c] = clip_obs(obs[i * OBS + c], w.obs_clip);
     ActorMfma<OBS, UT, JT> net;
     net.init(w);
     const float a = net.forward(o);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void actor_generic_kernel(ActorWeights w, int a
     const int64_t i = active ? gi : m - 1;
     float o[SSC_MAX_STATE];
 #pragma unroll
-    for (int c = 0; c < SSC_MAX_STATE; ++c) o[c] = (c < w.obs_dim) ? obs[i * w.obs_dim + c] : 0.0f;
+    for (int c = 0; c < SSC_MAX_STATE; ++c) o[c] = (c < w.obs_dim) ? clip_obs(obs[i * w.obs_dim + c], w.obs_clip) : 0.0f;
     for (int j = 0; j < w.h1; ++j) {
         float acc = w.b1[j];
 #pragma unroll
@@ -90,7 +90,7 @@ extern "C" int ssc_actor_forward(const ssc_actor_desc *a, int64_t m, const float
     if (m == 0) return SSC_OK;
     SSC_REQUIRE(a->W1 && a->b1 && a->W2 && a->b2 && a->W3 && a->b3 && d_obs && d_act,
                 "ssc_actor_forward: NULL device pointer");
-    const ActorWeights w{a->W1, a->b1, a->W2, a->b2, a->W3, a->b3, a->obs_dim, a->h1, a->h2, a->last_layer_tanh};
+    const ActorWeights w{a->W1, a->b1, a->W2, a->b2, a->W3, a->b3, a->obs_dim, a->h1, a->h2, a->last_layer_tanh, a->obs_clip};
     hipStream_t s = as_stream(stream);
     const dim3 grid(blocks_for(m)), block(kBlock);
     if (a->precision == SSC_PREC_BF16_MFMA) {

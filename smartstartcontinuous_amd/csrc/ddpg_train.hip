@@ -265,9 +265,10 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
                 if (tid < kB) {
                     const int64_t rec = g.batch_idx[(int64_t)it * kB + tid];
                     float *S = lds + g.off_S, *S2 = lds + g.off_S2, *RT = lds + g.off_RT, *XA = lds + g.off_X2act;
-                    for (int c = 0; c < d.obs_dim; ++c) {
-                        S[c * kP + tid] = g.rp.s[rec * d.obs_dim + c];
-                        S2[c * kP + tid] = g.rp.s2[rec * d.obs_dim + c];
+                    for (int c = 0; c < d.obs_dim; ++c) {   // obs0 / obs1 enter every network clipped (ddpg_editted.py:106-109)
+                        const float v0 = g.rp.s[rec * d.obs_dim + c], v1 = g.rp.s2[rec * d.obs_dim + c];
+                        S[c * kP + tid] = d.obs_clip > 0.0f ? fminf(fmaxf(v0, -d.obs_clip), d.obs_clip) : v0;
+                        S2[c * kP + tid] = d.obs_clip > 0.0f ? fminf(fmaxf(v1, -d.obs_clip), d.obs_clip) : v1;
                     }
                     for (int c = 0; c < d.act_dim; ++c) XA[c * kP + tid] = g.rp.a[rec * d.act_dim + c];
                     RT[0 * kP + tid] = g.rp.r[rec];

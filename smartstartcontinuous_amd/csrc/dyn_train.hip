@@ -480,13 +480,14 @@ static int fused_param_count(const ssc_mlp_train_desc *net) {
 template <int IN, int OUT>
 static int launch_fused(const FusedTrainArgs &g, hipStream_t s) {
     const size_t lds_bytes = fused_lds_floats(g.hd_pad, g.S, IN, OUT) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // The opt-in is a per-DEVICE attribute of the function: set it on every launch that needs it (like actor.hip,
+    // ddpg_train.hip and dyn_mfma.hip do) -- a process-wide "done" flag would skip it on a second device or race
+    // between threads.
+    if (lds_bytes > 64 * 1024) {
         if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_train_fused_kernel<IN, OUT>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
                                "hipFuncSetAttribute(mlp_train_fused_kernel)"))
             return rc;
-        attr_set = true;
     }
     hipLaunchKernelGGL((mlp_train_fused_kernel<IN, OUT>), dim3(g.G), dim3(kFT), lds_bytes, s, g);
     return SSC_OK;

@@ -135,7 +135,7 @@ struct ActorPolicy {
     Net net;
     u32x4 cache;
     float ou_x, mu, sig_sqrt_dt, theta_dt, eps;
-    float low, high;
+    float low, high, obs_clip;
     bool identity_scale;
 
     __device__ void init(const PolicyArgs &pa, const RolloutArgs &ra, int64_t i) {
@@ -147,6 +147,7 @@ struct ActorPolicy {
         ou_x = (ra.st.ou_x != nullptr) ? ra.st.ou_x[i] : 0.0f;
         low = pa.act_low;
         high = pa.act_high;
+        obs_clip = pa.actor.obs_clip;
         identity_scale = (low == -1.0f && high == 1.0f);
     }
     __device__ float scale(float a) const {  // DDPG_Baselines_agent.py:236-240
@@ -154,7 +155,10 @@ struct ActorPolicy {
         return identity_scale ? a : fmaf((a + 1.0f) * 0.5f, high - low, low);
     }
     __device__ float act(const float (&obs)[OBS], uint64_t seed, uint64_t env_id, uint64_t t, bool first) {
-        float a = net.forward(obs);
+        float oc[OBS];   // the network sees the clipped observation (ddpg_editted.py:106-109); the log keeps the raw one
+#pragma unroll
+        for (int c = 0; c < OBS; ++c) oc[c] = clip_obs(obs[c], obs_clip);
+        float a = net.forward(oc);
         if (eps > 0.0f) {  // wave-uniform
             if (first || (t & 3) == 0) cache = rng_words(seed, env_id, t >> 2, TAG_OU);
             const float g = ou_gaussian_from_words(cache, t);
@@ -486,7 +490,11 @@ static int dispatch_policy(const typename EnvT::Const &ec, const ssc_policy_desc
     if (a.precision == SSC_PREC_BF16_MFMA) {
         if constexpr (OBS == 2) {
             // the shipped shape on unit action bounds with exploration noise on: the straight-line fused policy
-            if (a.h1 <= 64 && a.h2 <= 32 && pa.act_low == -1.0f && pa.act_high == 1.0f && pa.ou_eps > 0.0f) {
+            // (MountainCar observations are bounded by the env's own clamps: an observation clip at or beyond them
+            // -- DDPG's (-5, 5) against |pos| <= 1.2, |vel| <= 0.07 -- never acts, so the fused policy skips it)
+            const float obs_bound = fmaxf(fmaxf(fabsf(ec.min_position), fabsf(ec.max_position)), fabsf(ec.max_speed));
+            const bool clip_inert = !(a.obs_clip > 0.0f) || a.obs_clip >= obs_bound;
+            if (a.h1 <= 64 && a.h2 <= 32 && pa.act_low == -1.0f && pa.act_high == 1.0f && pa.ou_eps > 0.0f && clip_inert) {
                 if (a.last_layer_tanh) return launch_rollout<EnvT, ActorPolicyFused<true>>(ec, pa, ra, stream);
                 return launch_rollout<EnvT, ActorPolicyFused<false>>(ec, pa, ra, stream);
             }
@@ -682,7 +690,7 @@ extern "C" int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *polic
         const ssc_actor_desc &a = policy->actor;
         SSC_REQUIRE(a.W1 && a.b1 && a.W2 && a.b2 && a.W3 && a.b3, "ssc_rollout: NULL actor weight pointer");
         SSC_REQUIRE(a.h1 > 0 && a.h2 > 0, "ssc_rollout: bad actor sizes");
-        pa.actor = ActorWeights{a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.obs_dim, a.h1, a.h2, a.last_layer_tanh};
+        pa.actor = ActorWeights{a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.obs_dim, a.h1, a.h2, a.last_layer_tanh, a.obs_clip};
         pa.ou_mu = policy->ou.mu;
         pa.ou_sigma = policy->ou.sigma;
         pa.ou_theta = policy->ou.theta;

@@ -15,6 +15,7 @@ namespace ssc {
 struct CriticW {
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     int32_t obs_dim, act_dim, h1, h2, last_tanh;
+    float obs_clip;
 };
 
 // one row per lane; layer-1 activations (+ the action, models_editted.py:89) parked in LDS as [unit][lane]
@@ -27,7 +28,10 @@ __global__ __launch_bounds__(64) void critic_kernel(CriticW w, int64_t m, const 
     const int64_t i = active ? gi : m - 1;
     float o[SSC_MAX_STATE];
 #pragma unroll
-    for (int c = 0; c < SSC_MAX_STATE; ++c) o[c] = (c < w.obs_dim) ? obs[i * w.obs_dim + c] : 0.0f;
+    for (int c = 0; c < SSC_MAX_STATE; ++c) {   // ddpg_editted.py:106-109
+        const float v = (c < w.obs_dim) ? obs[i * w.obs_dim + c] : 0.0f;
+        o[c] = w.obs_clip > 0.0f ? fminf(fmaxf(v, -w.obs_clip), w.obs_clip) : v;
+    }
     for (int j = 0; j < w.h1; ++j) {
         float acc = w.b1[j];
 #pragma unroll
@@ -167,7 +171,7 @@ int ssc_critic_forward(const ssc_critic_desc *c, int64_t m, const float *d_obs, 
     if (m == 0) return SSC_OK;
     SSC_REQUIRE(c->W1 && c->b1 && c->W2 && c->b2 && c->W3 && c->b3 && d_obs && d_act && d_q,
                 "ssc_critic_forward: NULL device pointer");
-    const CriticW w{c->W1, c->b1, c->W2, c->b2, c->W3, c->b3, c->obs_dim, c->act_dim, c->h1, c->h2, c->last_layer_tanh};
+    const CriticW w{c->W1, c->b1, c->W2, c->b2, c->W3, c->b3, c->obs_dim, c->act_dim, c->h1, c->h2, c->last_layer_tanh, c->obs_clip};
     const size_t lds = (size_t)(c->h1 + c->act_dim) * 64 * sizeof(float);
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_kernel),

@@ -63,6 +63,8 @@ class DynamicsModel:
         self.in_dim, self.out_dim = d.dims[0], d.dims[d.n_layers]
         self._mfma_ok = None
         self._image = None
+        if hasattr(self, "_adam"):
+            del self._adam                    # Adam moments and step counter belong to the parameters they were built for
         self.invalidate()
 
     def save(self, path):

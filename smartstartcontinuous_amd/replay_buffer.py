@@ -164,6 +164,34 @@ class ReplayBuffer:
         s = self._s[self._phys(idx)]
         return [row for row in s] + [self._s2[self._phys(buffer_index)]]
 
+    # ------------------------------------------------------------------------ persistence --
+    def save(self, path='replay_buffer.obj'):
+        """replay_buffer.py:117-124: pickles the record sequence (a list of ``(s, a, r, t, s2)`` tuples like the
+        reference's deque contents) -- to ``replay_buffer.obj`` in the working directory by default, like the reference."""
+        import pickle
+        with open(path, 'wb') as f:
+            pickle.dump([self.buffer[i] for i in range(self._len)], f)
+
+    def load(self, path='replay_buffer.obj'):
+        """replay_buffer.py:126-134: restores the records; like the reference the episode markers are NOT restored
+        (``next_episode_number = len(buffer)``) and a missing file is reported, not raised."""
+        import pickle
+        try:
+            with open(path, 'rb') as f:
+                records = list(pickle.load(f))
+        except (OSError, EOFError):
+            print('there was no file to load')
+            return False
+        self._head = self._len = 0
+        self._s = None
+        self.episode_starting_indices.clear()
+        self.next_episode_number = 0
+        agent = self.main_agent
+        for (s, a, r, t, s2) in records[-self.max_buffer_size:]:
+            self.add(agent, s, a, r, t, s2)
+        self.next_episode_number = self._len
+        return True
+
     def step_to_s(self, step):
         return np.array(step[0])
 

@@ -69,6 +69,7 @@ class ActorPolicy:
     ou_theta: float = 0.15
     ou_dt: float = 1e-2
     ou_epsilon: float = 1.0
+    obs_clip: float = 0.0              # > 0: the actor sees clip(obs, -obs_clip, obs_clip) (ddpg_editted.py:106-109: 5.0)
 
 
 @dataclass
@@ -296,6 +297,7 @@ class VecEnv:
         a.obs_dim, a.h1, a.h2, a.act_dim = obs_dim, h1, h2, 1
         a.W1, a.b1, a.W2, a.b2, a.W3, a.b3 = (w[k].data_ptr() for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
         a.last_layer_tanh = int(policy.last_layer_tanh)
+        a.obs_clip = float(policy.obs_clip)
         a.precision = {"f32": _ffi.SSC_PREC_F32, "bf16_mfma": _ffi.SSC_PREC_BF16_MFMA}[policy.precision]
         pd.ou.mu, pd.ou.sigma, pd.ou.theta = policy.ou_mu, policy.ou_sigma, policy.ou_theta
         pd.ou.dt, pd.ou.epsilon = policy.ou_dt, policy.ou_epsilon
@@ -344,11 +346,17 @@ class VecEnv:
         if nav.problems.d != self.obs_dim:
             raise ValueError("the navigator plans in observation space")
         chunk = None
-        cache = self.__dict__.setdefault("_mpc_graphs", {})
+        # The captured launches bake in the navigator's geometry (N, H) and the address of every buffer they touch.
+        # Graphs therefore LIVE ON THE NAVIGATOR (a NavigatorBatch owns most of those buffers and its N / H never
+        # change): a graph dies with the object whose memory it references, and a new NavigatorBatch -- e.g. the same
+        # problems with another num_control_samples -- starts with an empty cache instead of inheriting a graph through
+        # a recycled id().  What can still change under a live navigator is in the key.
+        cache = nav.__dict__.setdefault("_graphs", {})
+        default_chunks = self.__dict__.setdefault("_mpc_chunks", {})
         if log:
             # the graph bakes the log pointers in: without `out` the steps are logged into a chunk kept with the
-            # graph and the caller gets a copy (a fresh chunk per call would mean a fresh capture per call)
-            chunk = out if out is not None else cache.setdefault(("chunk", K), TransitionChunk(self.obs_dim, K, self.n, self.device))
+            # env and the caller gets a copy (a fresh chunk per call would mean a fresh capture per call)
+            chunk = out if out is not None else default_chunks.setdefault(K, TransitionChunk(self.obs_dim, K, self.n, self.device))
             if (chunk.K, chunk.N, chunk.obs_dim) != (K, self.n, self.obs_dim):
                 raise ValueError("out chunk has the wrong shape")
             chunk.step0, chunk.env_id0 = self.t, self.env_id0
@@ -356,14 +364,23 @@ class VecEnv:
         fb["t"].fill_(self.t)
         fb["k"].zero_()
         fb["plan"].copy_(self.observe())
-        # the captured launches bake pointers in: the graph is per (navigator, weight tensors, log chunk, ring);
-        # weights trained IN PLACE keep their graph -- only the packed image of the MFMA path is refreshed
-        model = nav.model
-        key = (id(nav), self.n, None if chunk is None else chunk.act.data_ptr(), None if ring is None else ring.cursor.data_ptr(),
-               model.precision, tuple(w.data_ptr() for w in model.W), tuple(b.data_ptr() for b in model.b),
-               bytes(model.norm),   # the fp32 path takes the statistics by value: baked into the capture
-               nav.problems.wp.data_ptr(), nav.problems.cur_idx.data_ptr())
+        model, pr = nav.model, nav.problems
         model.refresh_prepared_image()
+        ptr = lambda t: None if t is None else t.data_ptr()
+
+        def make_key():
+            return (nav.P, nav.N, nav.H, self.n, self.kind, bytes(self.params), self._seed, self.env_id0,
+                    tuple(ptr(x) for x in (self.s0, self.s1, self.steps, self.ep_ret, self.ou_x, self.stats)),
+                    None if chunk is None else tuple(ptr(c) for c in (chunk.obs, chunk.act, chunk.rew, chunk.done, chunk.obs2)),
+                    None if ring is None else (ptr(ring.cursor), ptr(ring.env_id), ptr(ring.length), ptr(ring.ret), ring.capacity),
+                    model.precision, tuple(ptr(w) for w in model.W), tuple(ptr(b) for b in model.b),
+                    bytes(model.norm),   # the fp32 path takes the statistics by value: baked into the capture
+                    ptr(model._image), ptr(model._ws),
+                    tuple(ptr(x) for x in (pr.wp, pr.left, pr.wp_off, pr.radii, pr.cur_idx)), pr.theta, pr.gamma, pr.hpf, pr.per_row,
+                    tuple(ptr(x) for x in (nav._S, nav.actions_done, nav.at_goal, nav.start_idx)),
+                    tuple(ptr(fb[k]) for k in sorted(fb)), nav.noise_amount, nav.seed, nav.problem_id0, nav.give_up,
+                    nav.final_steps, tuple(nav.low.tolist()), tuple(nav.high.tolist()))
+        key = make_key()
         if key not in cache:
             # warm-up outside the capture (lazy allocations, the weight image, LDS opt-ins) on a side stream, then
             # restore the state it advanced
@@ -380,11 +397,11 @@ class VecEnv:
                 dst.copy_(src)
             if ring is not None:
                 ring.cursor.copy_(ring_snap)
+            key = make_key()          # the warm-up may have allocated the model's weight image / workspace
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 nav.fused_step(self, chunk, ring)
-            stale = [k for k in cache if k[0] != "chunk"]
-            for k in stale[:max(0, len(stale) - 7)]:     # plans come and go (one per episode): keep the newest graphs
+            for k in list(cache)[:max(0, len(cache) - 7)]:     # weights / chunks come and go: keep the newest graphs
                 del cache[k]
             cache[key] = g
         g = cache[key]

@@ -194,7 +194,7 @@ def test_pendulum_step_kernel(ssc):
         assert d[: n // 2].all() and not d[n // 2:].any()       # TimeLimit(200) only
 
 
-@pytest.mark.parametrize("policy", ["random", "actor_f32", "actor_mfma"])
+@pytest.mark.parametrize("policy", ["random", "actor_f32", "actor_mfma", "actor_f32_clip", "actor_mfma_clip"])
 def test_rollout_pendulum_teacher_forced(ssc, policy):
     n, K, seed, id0 = 777, 40, 4321, 5
     env = ssc.VecEnv("Pendulum-v0", n, seed=seed, env_id0=id0)
@@ -208,9 +208,15 @@ def test_rollout_pendulum_teacher_forced(ssc, policy):
         pol, oracle_pol, tol = ssc.RandomPolicy(), O.OracleRandomPolicy(seed, id0, n, -2.0, 2.0), 0.0
     else:
         w = actor_weights(3, 64, 32, seed=21, w3_scale=0.5)
-        prec = "f32" if policy == "actor_f32" else "bf16_mfma"
-        pol = ssc.ActorPolicy({k: torch.as_tensor(v) for k, v in w.items()}, precision=prec)
-        oracle_pol = O.OracleDDPGPolicy(w, seed, id0, n, low=-2.0, high=2.0)
+        prec = "f32" if policy.startswith("actor_f32") else "bf16_mfma"
+        # "_clip": what DDPG_Baselines_agent.as_policy() builds -- the actor sees clip(obs, -5, 5) (ddpg_editted.py:106-109);
+        # a quarter of the envs start with |theta-dot| > 5 so that the clip is active
+        clip = 5.0 if policy.endswith("_clip") else 0.0
+        if clip:
+            env.s1[: n // 4] = torch.where(env.s1[: n // 4] >= 0, 7.0, -7.0)
+            obs0 = env.observe().cpu().numpy().copy()
+        pol = ssc.ActorPolicy({k: torch.as_tensor(v) for k, v in w.items()}, precision=prec, obs_clip=clip)
+        oracle_pol = O.OracleDDPGPolicy(w, seed, id0, n, low=-2.0, high=2.0, obs_clip=clip or None)
         tol = 4e-5 if prec == "f32" else 2 * TOL_ACT_BF16
     chunk = env.rollout(K, pol)
     torch.cuda.synchronize()

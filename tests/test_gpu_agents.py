@@ -277,6 +277,16 @@ def test_critic_kde_ucb_kernels(ssc):
         ref_v = O.critic_forward(obs, O.actor_forward(obs, **aw, last_layer_tanh=llt), **cw, last_layer_tanh=llt)
         assert v.shape == (777, 1) and np.max(np.abs(v - ref_v)) <= 2e-5 * max(1.0, np.abs(ref_v).max())
         assert agent.get_state_value(obs[0]).shape == (1,)
+        # DDPG_editted clips network inputs to observation_range = (-5, 5) (ddpg_editted.py:106-109)
+        big = (obs * 9.0).astype(np.float32)
+        assert np.abs(big).max() > 5.0
+        qb = agent.critic(big, act).cpu().numpy()
+        ref_b = O.critic_forward(big, act, **cw, last_layer_tanh=llt, obs_clip=5.0)[:, 0]
+        assert np.max(np.abs(qb - ref_b)) <= 1e-5 * max(1.0, np.abs(ref_b).max())
+        assert np.max(np.abs(qb - O.critic_forward(big, act, **cw, last_layer_tanh=llt)[:, 0])) > 1e-3   # the clip matters
+        ab = agent.actor(big).cpu().numpy()
+        ref_ab = O.actor_forward(big, **aw, last_layer_tanh=llt, obs_clip=5.0)
+        assert np.max(np.abs(ab - ref_ab)) <= 2e-5
     # KDE (Scott) + UCB against the oracle (itself pinned to scipy.stats.gaussian_kde on the CPU)
     for n, d, m in [(5000, 2, 2000), (100000, 2, 2000), (3000, 3, 77)]:
         data = (np.cumsum(rng.normal(size=(n, d)) * 0.01, axis=0) % 1.0).astype(np.float32)
@@ -364,6 +374,8 @@ def test_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2):
         agent.target_critic_flat -= 0.01
         cap, n_iters, B = 1000, 6, 64
         s = rng.uniform(-1.2, 0.6, (cap, obs_dim)).astype(np.float32)
+        if obs_dim == 3:
+            s[:, 2] = rng.uniform(-8, 8, cap)            # Pendulum's theta-dot: observation_range (-5, 5) clips it
         a = rng.uniform(-1, 1, (cap, 1)).astype(np.float32)
         r = (rng.normal(size=cap) * 0.5).astype(np.float32)
         t = (rng.random(cap) < 0.1)
@@ -381,7 +393,7 @@ def test_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2):
             bi = idx[it]
             o_a, o_c, o_ta, o_tc, adam, cl, al = O.ddpg_train_step(
                 o_a, o_c, o_ta, o_tc, adam, (s[bi], a[bi], r[bi], t[bi], s2[bi]), gamma=0.99, tau=0.001,
-                actor_lr=1e-3, critic_lr=1e-3, last_layer_tanh=llt)
+                actor_lr=1e-3, critic_lr=1e-3, last_layer_tanh=llt, obs_clip=5.0)
             ref_losses.append((cl, al))
         dev = lambda x, dt: torch.as_tensor(x, dtype=dt, device="cuda").contiguous()
         losses = agent.train_on(dev(s, torch.float32), dev(a, torch.float32), dev(r, torch.float32), dev(t, torch.uint8),

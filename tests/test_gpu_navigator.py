@@ -615,3 +615,43 @@ def test_mpc_rollout_graph_follows_weight_updates(nav):
     for i in range(3):
         assert torch.equal(g[i], e[i]), i
     assert not torch.equal(g[0], g[1]) and not torch.equal(g[1], g[2])
+
+
+def test_mpc_rollout_graphs_live_on_the_navigator(nav):
+    """a HIP graph bakes the navigator's N / H and buffer addresses in.  A NEW NavigatorBatch over the same
+    problems, model, env and chunk -- other num_control_samples, other horizon, possibly at a recycled id() -- must not
+    replay its predecessor's graph: every variant equals its own step-by-step path."""
+    import gc
+    import smartstartcontinuous_amd as ssc
+    rng = np.random.default_rng(3)
+    P, K, d = 24, 4, 2
+    Ws, bs = make_mlp(rng, (3, 32, 2))
+    norm = make_norm(rng, d, 1)
+    paths = [np.cumsum(rng.normal(scale=[0.02, 0.004], size=(10, d)), axis=0) + [-0.5, 0.0] for _ in range(P)]
+    wps, lefts, radii = [], [], []
+    for pth in paths:
+        stds, means = O.path_deltas_stds_and_means_per_dim(pth)
+        r = O.radii_calc(means, stds, 1, 1, 1) + 1e-3
+        wps.append(pth); radii.append(r); lefts.append(O.distances_left(pth, O.distance_func(r)))
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=1, precision="f32")
+
+    def run(graph, shapes, env, ps, chunk):
+        acts = []
+        for (N, H) in shapes:
+            batch = nav.NavigatorBatch(model, ps, num_control_samples=N, horizon=H, seed=5)
+            env.rollout(K, ssc.MpcPolicy(batch, graph=graph), out=chunk)
+            acts.append(chunk.act.clone())
+            del batch
+            gc.collect()                      # the next NavigatorBatch may land on the same id()
+        torch.cuda.synchronize()
+        return acts
+    shapes = [(64, 3), (192, 3), (64, 5), (320, 2), (64, 3)]
+    out = []
+    for graph in (True, False):
+        env = ssc.VecEnv("MountainCarContinuous-v0", P, seed=8)
+        env.reset()
+        ps = nav.MpcProblemSet(wps, lefts, radii, [0] * P)
+        out.append(run(graph, shapes, env, ps, ssc.TransitionChunk(2, K, P, "cuda")))
+    for i in range(len(shapes)):
+        assert torch.equal(out[0][i], out[1][i]), shapes[i]
+    assert not torch.equal(out[0][0], out[0][1])

@@ -248,3 +248,23 @@ def test_oracle_episode_index_matches_reference_trace(golden_dir):
     assert (idx >= first).all() and len(set(idx.tolist())) == 20
     more = O.smart_start_indices(valid, 64, 5, 1)            # more slots than valid records: every valid index once
     assert sorted(more[more >= 0].tolist()) == np.nonzero(valid)[0].tolist()
+
+
+def test_replay_buffer_save_load_roundtrip(tmp_path):
+    """ReplayBuffer.save / load (replay_buffer.py:117-134): the pickled record list round-trips; episode markers are
+    not persisted (the reference sets next_episode_number = len(buffer) and keeps no starts)."""
+    agent = object()
+    a = ReplayBuffer(agent, 20)
+    a.start_new_episode(agent)
+    for k in range(27):
+        a.add(agent, np.array([k, -k], float), np.array([0.5 * k]), float(k), k % 5 == 4, np.array([k + 1, -k - 1], float))
+    path = str(tmp_path / "replay_buffer.obj")
+    a.save(path)
+    b = ReplayBuffer(agent, 20)
+    assert b.load(str(tmp_path / "missing.obj")) is False and len(b) == 0
+    assert b.load(path) is True and len(b) == 20 and b.next_episode_number == 20 and len(b.episode_starting_indices) == 0
+    for i in range(20):
+        for x, y in zip(a.buffer[i], b.buffer[i]):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    small = ReplayBuffer(agent, 8)          # a smaller buffer keeps the newest records
+    assert small.load(path) and len(small) == 8 and small.buffer[-1][0][0] == 26 and small.buffer[0][0][0] == 19
