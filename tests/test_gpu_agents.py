@@ -32,7 +32,8 @@ def test_rltrain_with_ddpg_agent(ssc):
     np.random.seed(0)
     summary = ssc.rlTrain(agent, env, print_results=False, print_steps=False, num_episodes=3, max_steps=1000)
     assert [e[0] for e in summary.episodes] == [60, 60, 60]          # TimeLimit(60)
-    assert len(agent.replay_buffer) == 180 and len(agent.replay_buffer.episode_starting_indices) == 3
+    # a bare DDPG agent never marks episode starts (start_new_episode is `pass`, DDPG_Baselines_agent.py:249-250)
+    assert len(agent.replay_buffer) == 180 and len(agent.replay_buffer.episode_starting_indices) == 0
     assert abs(agent.decaying_ou_action_noise.epsilon - 0.99 ** 3) < 1e-12
     s, a, r, t, s2 = agent.replay_buffer.all_batch()
     assert np.all(np.abs(a) <= 1.0) and t.sum() == 3 and np.allclose(r, -0.1 * a[:, 0] ** 2, atol=1e-6)
