@@ -147,14 +147,25 @@ def bench_config4(args, torch):
     lefts = [num.distances_left(path, dist)] * P
     ps = nav.MpcProblemSet(wps, lefts, radii, [0] * P, theta=1.0, gamma=0.75, horizontal_penalty_factor=0.5)
     s0 = torch.as_tensor(np.repeat(np.stack([w[0] for w in wps]), N, axis=0), dtype=torch.float32, device="cuda")
+    s0_p = torch.as_tensor(np.stack([w[0] for w in wps]), dtype=torch.float32, device="cuda")     # one start state per problem
+
+    def _ws_bytes(P_, N_, H_):
+        from smartstartcontinuous_amd import _ffi
+        return _ffi.lib().ssc_mpc_score_workspace_bytes(P_, N_, H_)
     S = torch.empty((H + 1, M, d), device="cuda")
     rng = np.random.default_rng(0)
 
+    sel_out = dict(scores=torch.empty(M, device="cuda"), best=torch.empty(P, dtype=torch.int32, device="cuda"),
+                   best_score=torch.empty(P, device="cuda"), action=torch.empty((P, a), device="cuda"),
+                   ws=torch.empty(_ws_bytes(P, N, H), dtype=torch.uint8, device="cuda"))
+
     def step(t):
-        A = nav.mpc_sample_actions(P, N, H, [-2.0], [2.0], 1234, 0, t)
-        model.do_forward_sim(s0, A, out=S)
-        scores, best, _ = nav.mpc_score(ps, S)
-        return nav.mpc_select_action(A, S, best, P, 0.005, 1234, 0, t, want_path=False)
+        # THREE launches per MPC step: the forward simulation draws its own candidate sequences (no sample launch, no
+        # [M][H][a] matrix), scoring pass A, scoring pass B whose last block also selects the action
+        sp = nav.mpc_sampling(N, [-2.0], [2.0], 1234, 0, t)
+        model.do_forward_sim_sampled(s0_p, sp, M, H, out=S)
+        return nav.mpc_score_select(ps, S, sampling=sp, act_dim=a, noise_amount=0.005, seed=1234, problem_id0=0, t=t,
+                                    want_path=False, out=sel_out)[2]
 
     def sim_only(A):
         model.do_forward_sim(s0, A, out=S)
@@ -194,7 +205,7 @@ def bench_config4(args, torch):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (all layers on bf16 MFMA, fp32 accumulate; layer 1 split into bf16 head + residual)",
            "data": "synthetic", "config": {"workload": "BASELINE configs[3]: Pendulum dims (in 4, out 3), num_fc_layers 2, depth 500, "
                                           "%d MPC problems x %d samples = %d rows, horizon %d; z-score stats from 25x333 Pendulum random rollouts, "
-                                          "200-state recorded path as waypoints; sample + forward sim + score + select" % (P, N, M, H)},
+                                          "200-state recorded path as waypoints; forward sim (in-kernel sampling) + score + select = 3 launches per MPC step" % (P, N, M, H)},
            "roofline": {"bound": "mfma", "achieved": flop_row * M * H / (kms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": flop_row * M * H / (kms * 1e-3) / 1e12 / 2500.0, "traffic": None, "kernel_ms": kms,
                         "kernel": "ssc::dyn_mfma_sim_kernel<16,2,true,4> (weight image prepared once; HIP-graph replay of 10 launches)", "algorithmic_flop_per_launch": flop_row * M * H}}

@@ -262,12 +262,45 @@ int ssc_mpc_sample_actions(int32_t n_problems, int32_t n_samples, int32_t horizo
                            const float *low, const float *high, uint64_t seed, uint64_t problem_id0,
                            uint64_t t, const uint64_t *d_t_base, float *d_A, ssc_stream_t stream);
 
+/* The candidate action sequences of an MPC step as a SPECIFICATION instead of a matrix: all_samples =
+ * npr.uniform(low, high, (N, H, act)) (NND_MB_agent.py:500-501) is a pure function of (seed, problem, sample, t) --
+ * the Philox stream of ssc_mpc_sample_actions -- so the consumers can draw the numbers where they use them and the
+ * [P*N][H][act] matrix need not exist. */
+typedef struct ssc_mpc_sampling {
+    int32_t n_samples;                       /* N: row r of an [P*N] array is sample r % N of problem r / N */
+    float low[SSC_MAX_ACT], high[SSC_MAX_ACT];
+    uint64_t seed, problem_id0, t;
+    const uint64_t *d_t_base;                /* device step counter added to t (HIP-graph replay); may be NULL */
+} ssc_mpc_sampling;
+
+/* ssc_mpc_sample_actions + ssc_dyn_forward_sim in ONE launch (Dyn_Model.do_forward_sim fed by get_best_sim_actions,
+ * NND_MB_agent.py:498-512): the forward-simulation kernel draws every row's action sequence itself (bit-identical to
+ * ssc_mpc_sample_actions with the same specification), so the sample launch and the [m][H][act] read disappear.
+ * d_A_out [m][H][act] (may be NULL) receives the sequences for callers that index them later (ssc_mpc_rollout_step);
+ * ssc_mpc_score_select regenerates the winner's first action from the specification and does not need it.
+ * precision SSC_PREC_F32 runs the two-launch equivalent and needs d_A_out. */
+int ssc_mpc_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, const ssc_mpc_sampling *sampling, int64_t m,
+                        int32_t H, int32_t state_dim, int32_t act_dim, const float *d_s0, int64_t s0_rows,
+                        float *d_A_out, float *d_S, int precision, void *d_workspace, size_t workspace_bytes,
+                        ssc_stream_t stream);
+
 /* generate_scores_add_delta (NND_MB_agent.py:566-628) + argmax (:625-626) per problem.
  * d_S [H+1][P*N][state_dim] (output of ssc_dyn_forward_sim); d_scores [P*N]; d_best_idx [P]
  * (index within the problem, lowest index on ties like np.argmax); d_best_score [P]. */
 size_t ssc_mpc_score_workspace_bytes(int32_t n_problems, int32_t n_samples, int32_t horizon);
 int ssc_mpc_score(const ssc_mpc_problems *prob, const float *d_S, float *d_scores, int32_t *d_best_idx,
                   float *d_best_score, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream);
+
+/* ssc_mpc_score + ssc_mpc_select_action in the same two launches: the block that finishes a problem's argmax also
+ * writes action[p] = best_sequence[0] + noise_amount * N(0,1) (no clip, NND_MB_agent.py:353-356; the draws of
+ * ssc_mpc_select_action) and the predicted path S[:, best] -> d_best_path [P][H+1][state_dim] (may be NULL).  The
+ * first action of the winner comes from d_A [P*N][H][act] when given, otherwise it is regenerated from `sampling`
+ * (exactly one of the two must be non-NULL).  noise_seed / problem_id0 / t (+ *d_t_base of `sampling` when given)
+ * key the noise like ssc_mpc_select_action. */
+int ssc_mpc_score_select(const ssc_mpc_problems *prob, const float *d_S, float *d_scores, int32_t *d_best_idx,
+                         float *d_best_score, const float *d_A, const ssc_mpc_sampling *sampling, int32_t act_dim,
+                         float noise_amount, uint64_t noise_seed, uint64_t problem_id0, uint64_t t, float *d_action,
+                         float *d_best_path, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream);
 
 /* NND_MB_agent.observe (NND_MB_agent.py:360-373) + close_enough_to_goal (:425-432) for P navigators at
  * once: given the state each env reached, advance its waypoint index when the waypoint was reached /

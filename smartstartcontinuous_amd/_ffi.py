@@ -89,6 +89,11 @@ class MpcProblems(Structure):
                 ("horizontal_penalty_factor", c_float), ("per_row_projection", c_int32)]
 
 
+class MpcSampling(Structure):
+    _fields_ = [("n_samples", c_int32), ("low", c_float * SSC_MAX_ACT), ("high", c_float * SSC_MAX_ACT),
+                ("seed", c_uint64), ("problem_id0", c_uint64), ("t", c_uint64), ("d_t_base", c_void_p)]
+
+
 class CriticDesc(Structure):
     _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("h1", c_int32), ("h2", c_int32),
                 ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
@@ -178,6 +183,11 @@ _SIGNATURES = {
     "ssc_dyn_prepare": (c_int, [POINTER(MlpDesc), POINTER(Norm), c_void_p, c_size_t, c_void_p]),
     "ssc_dyn_forward_sim": (c_int, [POINTER(MlpDesc), POINTER(Norm), c_int64, c_int32, c_int32, c_int32, c_void_p,
                                     c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "ssc_mpc_forward_sim": (c_int, [POINTER(MlpDesc), POINTER(Norm), POINTER(MpcSampling), c_int64, c_int32, c_int32, c_int32,
+                                    c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "ssc_mpc_score_select": (c_int, [POINTER(MpcProblems), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     POINTER(MpcSampling), c_int32, c_float, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
     "ssc_mpc_sample_actions": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float),
                                        c_uint64, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "ssc_mpc_rollout_step": (c_int, [POINTER(EnvParams), POINTER(MpcProblems), POINTER(MpcNavState), c_void_p, c_void_p,

@@ -196,6 +196,13 @@ struct DynSimArgs {
     float *S;               // sim: [H+1][m][d]; fwd: y [m][out]
     const unsigned char *a1, *a2, *a3;  // packed weight image (workspace)
     const float *b2, *b3, *nm;
+    // candidate action sequences drawn INSIDE the kernel (ssc_mpc_forward_sim): A == nullptr, row r is sample r % N of
+    // problem r / N, Philox stream of ssc_mpc_sample_actions (oracle: mpc_action_samples); A_out (may be null) receives them
+    int32_t sample, N;
+    uint64_t seed, pid0, t;
+    const uint64_t *t_base;
+    float low[SSC_MAX_ACT], span[SSC_MAX_ACT];
+    float *A_out;
 };
 
 // np.nan_to_num((x - mean) / std) (dynamics_model.py:228-229) with inv = 1/std: 0/0 = 0 * inf = NaN -> 0;
@@ -270,26 +277,37 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     const int group = wave >> 2;
 
     // ---- stage the resident weights ------------------------------------------------------------
+    // Everything goes out before anything is waited for: the layer-1 and output-layer fragments and the first W2^T
+    // tiles by LDS-DMA (1 KiB pieces dealt round-robin to the 8 waves, no VGPR staging), the small bias arrays through
+    // registers, then -- below -- this lane's start state, first actions and the normalisation constants; ONE wait +
+    // barrier in front of layer 1 covers all of it.
+    const __amdgpu_buffer_rsrc_t a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(g.a2), 0, NFC == 2 ? UT * A2_TILE : 0, 0x00020000);   // reads past the end return 0
     {
-        const f32x4 *s3 = reinterpret_cast<const f32x4 *>(g.a3);
-        f32x4 *d3 = reinterpret_cast<f32x4 *>(l_a3);
-        for (int e = tid; e < UT * 512 / 16; e += kDynThreads) d3[e] = s3[e];
-        const f32x4 *s1 = reinterpret_cast<const f32x4 *>(g.a1);
-        f32x4 *d1 = reinterpret_cast<f32x4 *>(l_a1);
-        for (int e = tid; e < KS1 * MT * 1024 / 16; e += kDynThreads) d1[e] = s1[e];
+        constexpr int A1_PIECES = KS1 * MT;              // 1 KiB each
+        constexpr int A3_BYTES = UT * 512;
+        const __amdgpu_buffer_rsrc_t a1_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char *>(g.a1), 0, A1_PIECES * 1024, 0x00020000);
+#pragma unroll
+        for (int ch = wave; ch < A1_PIECES; ch += kNW) lds_dma_1k(a1_rsrc, lane * 16, ch * 1024, l_a1 + ch * 1024);
+        if constexpr (A3_BYTES % 1024 == 0) {
+            const __amdgpu_buffer_rsrc_t a3_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned char *>(g.a3), 0, A3_BYTES, 0x00020000);
+#pragma unroll
+            for (int ch = wave; ch < A3_BYTES / 1024; ch += kNW) lds_dma_1k(a3_rsrc, lane * 16, ch * 1024, l_a3 + ch * 1024);
+        } else {   // a piece is 1 KiB: a smaller image goes through registers
+            const f32x4 *s3 = reinterpret_cast<const f32x4 *>(g.a3);
+            f32x4 *d3 = reinterpret_cast<f32x4 *>(l_a3);
+            for (int e = tid; e < A3_BYTES / 16; e += kDynThreads) d3[e] = s3[e];
+        }
+        if (NFC == 2) {  // first W2^T tiles: everything when resident, tiles 0 and 1 of the ring otherwise
+            constexpr int PRE = STREAM ? 2 : NBUF;
+#pragma unroll
+            for (int ch = wave; ch < PRE * A2_CHUNKS; ch += kNW) lds_dma_1k(a2_rsrc, lane * 16, ch * 1024, l_a2 + ch * 1024);
+        }
         for (int e = tid; e < UT * 32; e += kDynThreads) l_b2[e] = g.b2[e];
         if (tid < 16) l_b3[tid] = g.b3[tid];
     }
-    // raw buffer over the W2^T fragment image (reads past the end return 0)
-    const __amdgpu_buffer_rsrc_t a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char *>(g.a2), 0, NFC == 2 ? UT * A2_TILE : 0, 0x00020000);
-    if (NFC == 2) {  // first W2^T tiles by LDS-DMA: everything when resident, tiles 0 and 1 of the ring otherwise
-        constexpr int PRE = STREAM ? 2 : NBUF;
-#pragma unroll
-        for (int ch = wave; ch < PRE * A2_CHUNKS; ch += kNW) lds_dma_1k(a2_rsrc, lane * 16, ch * 1024, l_a2 + ch * 1024);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA pieces above
-    __syncthreads();
 
     // output-layer A fragments: MFMA row (lane & 15) reads entry (lane & 7) of its k group
     const unsigned char *a3_lane = l_a3 + (kg * 8 + (c & 7)) * 16;
@@ -311,14 +329,55 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         }
     }
 
-    // the actions of step t+1 are fetched during step t (a global load costs ~1-2 k cycles even from L2)
+    // the actions of step t+1 are fetched during step t (a global load costs ~1-2 k cycles even from L2) -- or, in
+    // sampling mode, drawn from Philox here: candidate sequence of sample n of problem p = words of
+    // Philox(seed; (problem_id0 + p) << 32 | n, t * ceil(H a / 4) + c, TAG_MPC), flat index h * a + ai = 4 c + word
+    // (NND_MB_agent.py:500-501; bit-exact with ssc_mpc_sample_actions / oracle mpc_action_samples), so the [m][H][a]
+    // matrix never has to exist in memory
     constexpr int AMAX = KIN < 4 ? KIN : 4;
     float act[2][AMAX];
+    uint64_t sid[2] = {0, 0};
+    u32x4 wcache[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+    int wc = -1;  // Philox call the cached words belong to (block-uniform)
+    uint64_t tt = 0;
+    if (g.sample) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            sid[nt] = ((g.pid0 + (uint64_t)(rowc[nt] / g.N)) << 32) + (uint64_t)(rowc[nt] % g.N);
+        tt = (g.t + (g.t_base != nullptr ? *g.t_base : 0)) * (uint64_t)((g.H * g.a + 3) / 4);
+    }
+    auto fetch_actions = [&](int ts) {
+        if (g.sample) {
+#pragma unroll
+            for (int ai = 0; ai < AMAX; ++ai)
+                if (ai < g.a) {
+                    const int f = ts * g.a + ai, c4 = f >> 2;
+                    if (c4 != wc) {  // block-uniform
+                        wc = c4;
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) wcache[nt] = rng_words(g.seed, sid[nt], tt + (uint64_t)c4, TAG_MPC);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        act[nt][ai] = uniform_f32(pick(wcache[nt], (uint32_t)(f & 3)), g.low[ai], g.span[ai]);
+                        if (g.A_out != nullptr && valid[nt] && kg == 0) g.A_out[(rowc[nt] * g.H + ts) * g.a + ai] = act[nt][ai];
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float *ap = g.A + (rowc[nt] * g.H + ts) * g.a;
+#pragma unroll
+                for (int ai = 0; ai < AMAX; ++ai)
+                    if (ai < g.a) act[nt][ai] = ap[ai];
+            }
+        }
+    };
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int ai = 0; ai < AMAX; ++ai)
-            act[nt][ai] = (!g.fwd_mode && ai < g.a) ? g.A[rowc[nt] * g.H * g.a + ai] : 0.0f;
+        for (int ai = 0; ai < AMAX; ++ai) act[nt][ai] = 0.0f;
+    if (!g.fwd_mode && g.H > 0) fetch_actions(0);
 
     // Normalisation constants per network input (input k = state k for k < d, else action k-d) and per state
     // delta, read once through scalar loads: block-uniform, so they live in SGPRs and the per-step input code
@@ -336,6 +395,9 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         z_mean[k] = (k < g.d) ? uniform_f32(g.nm[4 * 8 + k]) : 0.0f;
         z_std[k] = (k < g.d) ? uniform_f32(g.nm[5 * 8 + k]) : 0.0f;
     }
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA pieces (and every load above)
+    __syncthreads();
 
     int bsel = 0;  // LDS slot of the current W2 tile (STREAM)
     constexpr int NF = 2 * UT;                // W2^T fragments (ring entries) per hidden tile: k-step p = f>>1, half f&1
@@ -436,15 +498,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         }
         // the actions of the next step: issued here, behind layer 1's scheduling fences, so that the loads fly
         // under the hidden tiles (hoisted to the top of the step they were waited for at once)
-        if (!g.fwd_mode && t + 1 < g.H) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float *ap = g.A + (rowc[nt] * g.H + t + 1) * g.a;
-#pragma unroll
-                for (int ai = 0; ai < AMAX; ++ai)
-                    if (ai < g.a) act[nt][ai] = ap[ai];
-            }
-        }
+        if (!g.fwd_mode && t + 1 < g.H) fetch_actions(t + 1);
         // ---- hidden layer 2 (+ output layer fused per tile) -------------------------------------
         f32x4 acc3[2];
         acc3[0] = acc3[1] = *reinterpret_cast<const f32x4 *>(l_b3 + kg * 4);
@@ -670,6 +724,24 @@ int dyn_mfma_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t 
     DynSimArgs g{};
     g.m = m; g.H = H; g.d = state_dim; g.a = act_dim; g.fwd_mode = 0;
     g.s0 = d_s0; g.s0_rows = m / s0_rows; g.A = d_A; g.S = d_S;
+    return run_mfma(mlp, g, ws, s);
+}
+
+// the same simulation with the candidate actions drawn inside the kernel (ssc_mpc_forward_sim)
+int dyn_mfma_forward_sim_sampled(const ssc_mlp_desc *mlp, const ssc_norm *norm, const ssc_mpc_sampling *sp, int64_t m,
+                                 int32_t H, int32_t state_dim, int32_t act_dim, const float *d_s0, int64_t s0_rows,
+                                 float *d_A_out, float *d_S, void *ws, bool prepared, hipStream_t s) {
+    if (!prepared)
+        if (int rc = dyn_mfma_prepare(mlp, norm, ws, s)) return rc;
+    DynSimArgs g{};
+    g.m = m; g.H = H; g.d = state_dim; g.a = act_dim; g.fwd_mode = 0;
+    g.s0 = d_s0; g.s0_rows = m / s0_rows; g.A = nullptr; g.S = d_S;
+    g.sample = 1; g.N = sp->n_samples; g.seed = sp->seed; g.pid0 = sp->problem_id0; g.t = sp->t; g.t_base = sp->d_t_base;
+    for (int a = 0; a < SSC_MAX_ACT; ++a) {
+        g.low[a] = a < act_dim ? sp->low[a] : 0.0f;
+        g.span[a] = a < act_dim ? sp->high[a] - sp->low[a] : 0.0f;
+    }
+    g.A_out = d_A_out;
     return run_mfma(mlp, g, ws, s);
 }
 

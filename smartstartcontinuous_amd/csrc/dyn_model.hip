@@ -175,6 +175,9 @@ int dyn_mfma_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t 
                          void *ws, bool prepared, hipStream_t s);
 int dyn_mfma_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float *d_y, void *ws, bool prepared,
                          hipStream_t s);
+int dyn_mfma_forward_sim_sampled(const ssc_mlp_desc *mlp, const ssc_norm *norm, const ssc_mpc_sampling *sp, int64_t m,
+                                 int32_t H, int32_t state_dim, int32_t act_dim, const float *d_s0, int64_t s0_rows,
+                                 float *d_A_out, float *d_S, void *ws, bool prepared, hipStream_t s);
 
 static bool is_mfma(int precision) { return precision == SSC_PREC_BF16_MFMA || precision == SSC_PREC_BF16_MFMA_PREPARED; }
 
@@ -278,6 +281,43 @@ int ssc_dyn_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m
                            St, z, Sn);
     }
     return check_launch("ssc_dyn_forward_sim");
+}
+
+int ssc_mpc_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, const ssc_mpc_sampling *sp, int64_t m, int32_t H,
+                        int32_t state_dim, int32_t act_dim, const float *d_s0, int64_t s0_rows, float *d_A_out,
+                        float *d_S, int precision, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream) {
+    if (int rc = validate_mlp(mlp, "ssc_mpc_forward_sim")) return rc;
+    SSC_REQUIRE(norm != nullptr && sp != nullptr, "ssc_mpc_forward_sim: NULL descriptor");
+    SSC_REQUIRE(m >= 0 && H >= 1, "ssc_mpc_forward_sim: m = %lld, H = %d", (long long)m, H);
+    SSC_REQUIRE(state_dim >= 1 && state_dim <= SSC_MAX_STATE && act_dim >= 1 && act_dim <= SSC_MAX_ACT,
+                "ssc_mpc_forward_sim: state_dim %d / act_dim %d out of range", state_dim, act_dim);
+    SSC_REQUIRE(mlp->dims[0] == state_dim + act_dim && mlp->dims[mlp->n_layers] == state_dim,
+                "ssc_mpc_forward_sim: network is %d -> %d, expected %d -> %d", mlp->dims[0],
+                mlp->dims[mlp->n_layers], state_dim + act_dim, state_dim);
+    SSC_REQUIRE(sp->n_samples >= 1 && m % sp->n_samples == 0, "ssc_mpc_forward_sim: n_samples %d must divide m = %lld",
+                sp->n_samples, (long long)m);
+    SSC_REQUIRE(s0_rows >= 1 && (m == 0 || m % s0_rows == 0), "ssc_mpc_forward_sim: s0_rows must divide m");
+    for (int a = 0; a < act_dim; ++a)
+        SSC_REQUIRE(sp->low[a] <= sp->high[a], "ssc_mpc_forward_sim: low > high for action component %d", a);
+    if (m == 0) return SSC_OK;
+    SSC_REQUIRE(d_s0 && d_S, "ssc_mpc_forward_sim: NULL device pointer");
+    const size_t need = ssc_dyn_workspace_bytes(mlp, m, precision);
+    SSC_REQUIRE(d_workspace != nullptr && workspace_bytes >= need,
+                "ssc_mpc_forward_sim: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (is_mfma(precision)) {
+        if (!dyn_mfma_supported(mlp, state_dim, act_dim))
+            return set_error(SSC_EUNSUPPORTED, "ssc_mpc_forward_sim: MFMA path needs 1-2 hidden layers of equal "
+                                               "depth <= 512 (inputs <= 10 when 2 layers deeper than 128)");
+        return dyn_mfma_forward_sim_sampled(mlp, norm, sp, m, H, state_dim, act_dim, d_s0, s0_rows, d_A_out, d_S,
+                                            d_workspace, precision == SSC_PREC_BF16_MFMA_PREPARED, as_stream(stream));
+    }
+    // fp32: the two-launch equivalent
+    SSC_REQUIRE(d_A_out != nullptr, "ssc_mpc_forward_sim: the fp32 path materialises the action matrix: d_A_out NULL");
+    if (int rc = ssc_mpc_sample_actions((int32_t)(m / sp->n_samples), sp->n_samples, H, act_dim, sp->low, sp->high, sp->seed,
+                                        sp->problem_id0, sp->t, sp->d_t_base, d_A_out, stream))
+        return rc;
+    return ssc_dyn_forward_sim(mlp, norm, m, H, state_dim, act_dim, d_s0, s0_rows, d_A_out, d_S, precision, d_workspace,
+                               workspace_bytes, stream);
 }
 
 }  // extern "C"

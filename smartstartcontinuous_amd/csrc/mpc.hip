@@ -107,16 +107,24 @@ __device__ __forceinline__ float mpc_walk(const MpcArgs &a, const float *__restr
 // The same walk with the whole trajectory of the sample fetched up front (H + 1 <= kPreT, d <= kPreD): all
 // loads are in flight together, one memory latency per sample instead of one per horizon step.
 constexpr int kPreT = 8, kPreD = 4;
-template <int PASS>
-__device__ __forceinline__ float mpc_walk_pre(const MpcArgs &a, const float *__restrict__ S, int64_t row, int64_t M,
-                                              const float *wps, const float *lefts, int W, int idx0,
-                                              const float *inv_r, bool live, double *wave_sums, const float *cproj) {
-    float pts[kPreT][SSC_MAX_STATE];
+struct PrePts {
+    float v[kPreT][SSC_MAX_STATE];
+};
+// Issued FIRST in both passes, before the problem's waypoints are staged and (pass B) the partial sums are reduced: the
+// three are independent round trips to L2 / HBM, and these small launches are nothing but a chain of such round trips.
+__device__ __forceinline__ void mpc_fetch_pts(const MpcArgs &a, const float *__restrict__ S, int64_t row, int64_t M, bool live,
+                                              PrePts &pts) {
 #pragma unroll
     for (int t = 0; t < kPreT; ++t)
 #pragma unroll
         for (int k = 0; k < SSC_MAX_STATE; ++k)
-            pts[t][k] = (live && k < kPreD && t <= a.H && k < a.d) ? S[((int64_t)t * M + row) * a.d + k] : 0.0f;
+            pts.v[t][k] = (live && k < kPreD && t <= a.H && k < a.d) ? S[((int64_t)t * M + row) * a.d + k] : 0.0f;
+}
+
+template <int PASS>
+__device__ __forceinline__ float mpc_walk_pre(const MpcArgs &a, const PrePts &pp, const float *wps, const float *lefts, int W,
+                                              int idx0, const float *inv_r, bool live, double *wave_sums, const float *cproj) {
+    const float (&pts)[kPreT][SSC_MAX_STATE] = pp.v;
     WalkState w{idx0, 0.0f, 0.0f, 1.0f, live};
 #pragma unroll
     for (int t = 0; t < kPreT; ++t)
@@ -124,12 +132,13 @@ __device__ __forceinline__ float mpc_walk_pre(const MpcArgs &a, const float *__r
     return w.score;
 }
 
+__device__ __forceinline__ bool mpc_can_prefetch(const MpcArgs &a) { return a.H + 1 <= kPreT && a.d <= kPreD; }  // block-uniform
+
 template <int PASS>
-__device__ __forceinline__ float mpc_walk_any(const MpcArgs &a, const float *__restrict__ S, int64_t row, int64_t M,
-                                              const float *wps, const float *lefts, int W, int idx0,
+__device__ __forceinline__ float mpc_walk_any(const MpcArgs &a, const PrePts &pp, const float *__restrict__ S, int64_t row,
+                                              int64_t M, const float *wps, const float *lefts, int W, int idx0,
                                               const float *inv_r, bool live, double *wave_sums, const float *cproj) {
-    if (a.H + 1 <= kPreT && a.d <= kPreD)  // block-uniform
-        return mpc_walk_pre<PASS>(a, S, row, M, wps, lefts, W, idx0, inv_r, live, wave_sums, cproj);
+    if (mpc_can_prefetch(a)) return mpc_walk_pre<PASS>(a, pp, wps, lefts, W, idx0, inv_r, live, wave_sums, cproj);
     return mpc_walk<PASS>(a, S, row, M, wps, lefts, W, idx0, inv_r, live, wave_sums, cproj);
 }
 
@@ -138,8 +147,24 @@ __device__ __forceinline__ void load_problem(const MpcArgs &a, int p, float *wps
     const int off = a.wp_off[p];
     W = a.wp_off[p + 1] - off;
     idx0 = a.cur_idx[p];
-    for (int e = threadIdx.x; e < W * a.d; e += blockDim.x) wps[e] = a.wp[(int64_t)off * a.d + e];
-    for (int e = threadIdx.x; e < W; e += blockDim.x) lefts[e] = a.left[off + e];
+    // up to 4 + 2 loads per thread in flight before the first LDS store (a plain copy loop waits for every load in
+    // turn: W * d / 256 dependent round trips)
+    const float *wsrc = a.wp + (int64_t)off * a.d;
+    const int nw = W * a.d;
+    for (int e0 = threadIdx.x; e0 < nw; e0 += 4 * (int)blockDim.x) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (e0 + q * (int)blockDim.x < nw) ? wsrc[e0 + q * (int)blockDim.x] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (e0 + q * (int)blockDim.x < nw) wps[e0 + q * (int)blockDim.x] = v[q];
+    }
+    for (int e0 = threadIdx.x; e0 < W; e0 += 2 * (int)blockDim.x) {
+        const float v0 = a.left[off + e0];
+        const float v1 = (e0 + (int)blockDim.x < W) ? a.left[off + e0 + blockDim.x] : 0.0f;
+        lefts[e0] = v0;
+        if (e0 + (int)blockDim.x < W) lefts[e0 + blockDim.x] = v1;
+    }
     if ((int)threadIdx.x < a.d) inv_r[threadIdx.x] = 1.0f / a.radii[p * a.d + threadIdx.x];
     __syncthreads();
 }
@@ -171,12 +196,14 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_pass_a_kernel(MpcArgs a, int Wm
     float *inv_r = lefts + Wmax;
     const int p = blockIdx.y;
     if (blockIdx.x == 0 && threadIdx.x == 0) ticket[p] = 0;  // pass B elects its last block with it
-    int W, idx0;
-    load_problem(a, p, wps, lefts, inv_r, W, idx0);
     const int n = blockIdx.x * kMpcBlock + threadIdx.x;
     const bool live = n < a.N;
-    mpc_walk_any<0>(a, S, (int64_t)p * a.N + (live ? n : 0), (int64_t)a.P * a.N, wps, lefts, W, idx0, inv_r, live,
-                    red + (threadIdx.x >> 6) * kMaxH1 * 2, nullptr);
+    const int64_t row = (int64_t)p * a.N + (live ? n : 0), M = (int64_t)a.P * a.N;
+    PrePts pp;
+    if (mpc_can_prefetch(a)) mpc_fetch_pts(a, S, row, M, live, pp);
+    int W, idx0;
+    load_problem(a, p, wps, lefts, inv_r, W, idx0);
+    mpc_walk_any<0>(a, pp, S, row, M, wps, lefts, W, idx0, inv_r, live, red + (threadIdx.x >> 6) * kMaxH1 * 2, nullptr);
     __syncthreads();
     for (int e = threadIdx.x; e < (a.H + 1) * 2; e += kMpcBlock) {
         double v = 0.0;
@@ -185,7 +212,20 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_pass_a_kernel(MpcArgs a, int Wm
     }
 }
 
-__global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wmax, const float *__restrict__ S,
+// What ssc_mpc_select_action does, folded into pass B's last block (ssc_mpc_score_select)
+struct SelectArgs {
+    float *action;       // [P][act]; nullptr: no selection epilogue
+    float *best_path;    // [P][H+1][d] or nullptr
+    const float *A;      // [P*N][H][act] or nullptr -> regenerate the winner's first action from the sampling spec
+    int32_t act;
+    float noise;
+    uint64_t seed, pid0, t;          // noise key (ssc_mpc_select_action)
+    uint64_t s_seed, s_pid0, s_t;    // sampling spec (ssc_mpc_sample_actions)
+    const uint64_t *t_base;          // device step counter added to t and s_t
+    float low[SSC_MAX_ACT], span[SSC_MAX_ACT];
+};
+
+__global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wmax, int stage_partials, SelectArgs sel, const float *__restrict__ S,
                                                                const double *__restrict__ partial,
                                                                float *__restrict__ scores,
                                                                float *blk_best_score, int32_t *blk_best_idx,
@@ -200,24 +240,38 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wm
     float *wps = reinterpret_cast<float *>(last + 2);
     float *lefts = wps + Wmax * a.d;
     float *inv_r = lefts + Wmax;
+    // [nblk][H+1][2] doubles behind the floats, rounded up to an 8-byte boundary (the carve above ends on a multiple of 4)
+    double *pstage = stage_partials
+        ? reinterpret_cast<double *>(smem + ((reinterpret_cast<unsigned char *>(inv_r + 8) - smem + 7) & ~(ptrdiff_t)7))
+        : nullptr;
     const int p = blockIdx.y;
-    // fixed-order reduction of the per-block partials of this problem
+    const int n = blockIdx.x * kMpcBlock + threadIdx.x;
+    const int64_t M = (int64_t)a.P * a.N;
+    PrePts pp;
+    if (mpc_can_prefetch(a)) mpc_fetch_pts(a, S, (int64_t)p * a.N + (n < a.N ? n : 0), M, n < a.N, pp);
+    // fixed-order reduction of the per-block partials of this problem.  The partials come in with ONE round trip (every
+    // thread fetches its share into LDS) and are then summed in block order by thread t -- H + 1 threads walking nblk
+    // dependent global loads each was most of this kernel's run time.
+    const int n_part = a.nblk * (a.H + 1) * 2;
+    if (pstage != nullptr) {
+        for (int e = threadIdx.x; e < n_part; e += kMpcBlock) pstage[e] = partial[(int64_t)p * n_part + e];
+        __syncthreads();
+    }
     for (int t = threadIdx.x; t <= a.H; t += kMpcBlock) {
         double g0 = 0.0, g1 = 0.0;
         for (int b = 0; b < a.nblk; ++b) {
-            g0 += partial[(((int64_t)p * a.nblk + b) * (a.H + 1) + t) * 2 + 0];
-            g1 += partial[(((int64_t)p * a.nblk + b) * (a.H + 1) + t) * 2 + 1];
+            const int e = (b * (a.H + 1) + t) * 2;
+            g0 += pstage != nullptr ? pstage[e + 0] : partial[(int64_t)p * n_part + e + 0];
+            g1 += pstage != nullptr ? pstage[e + 1] : partial[(int64_t)p * n_part + e + 1];
         }
         cproj[t] = (float)(g0 / g1);
     }
     int W, idx0;
     load_problem(a, p, wps, lefts, inv_r, W, idx0);  // ends with __syncthreads()
-    const int n = blockIdx.x * kMpcBlock + threadIdx.x;
     float score = -INFINITY;
     int best = 0x7fffffff;
     if (n < a.N) {
-        score = mpc_walk_any<1>(a, S, (int64_t)p * a.N + n, (int64_t)a.P * a.N, wps, lefts, W, idx0, inv_r, true,
-                                nullptr, cproj);
+        score = mpc_walk_any<1>(a, pp, S, (int64_t)p * a.N + n, M, wps, lefts, W, idx0, inv_r, true, nullptr, cproj);
         scores[(int64_t)p * a.N + n] = score;
         best = n;
         if (isnan(score)) score = -INFINITY;  // np.argmax would return the first NaN; we skip NaNs
@@ -225,9 +279,13 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wm
     block_argmax(score, best, rs, ri);
     // the block that finishes last reduces the per-block winners of its problem (no third launch)
     if (threadIdx.x == 0) {
+        // write-through (sc1) stores, drained by THIS lane, then a relaxed agent-scope ticket: the last block reads the
+        // winners back with sc1 loads after its own add returned (MI355X_MICROARCH.md "Valid forms", first table row).
+        // An acq_rel ticket would add an L2 write-back + invalidate (~3.5 us) to every block's critical path.
         __hip_atomic_store(&blk_best_score[p * a.nblk + blockIdx.x], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&blk_best_idx[p * a.nblk + blockIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int tk = __hip_atomic_fetch_add(&ticket[p], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int tk = __hip_atomic_fetch_add(&ticket[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last[0] = (tk == a.nblk - 1);
     }
     __syncthreads();
@@ -242,8 +300,42 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wm
     __syncthreads();  // rs/ri are reused
     block_argmax(score, best, rs, ri);
     if (threadIdx.x == 0) {
-        best_idx[p] = (best == 0x7fffffff) ? 0 : best;
+        best = (best == 0x7fffffff) ? 0 : best;
+        best_idx[p] = best;
         if (best_score) best_score[p] = score;
+        ri[0] = best;
+    }
+    if (sel.action == nullptr) return;
+    // ---- get_action_with_predicted_states tail (NND_MB_agent.py:339-358), same draws as mpc_select_kernel ----
+    __syncthreads();
+    best = ri[0];
+    const uint64_t tb = sel.t_base != nullptr ? *sel.t_base : 0;
+    if ((int)threadIdx.x < sel.act) {
+        const int ai = threadIdx.x;
+        float first;
+        if (sel.A != nullptr) {
+            first = sel.A[((int64_t)p * a.N + best) * a.H * sel.act + ai];
+        } else {   // flat index h * act + ai = ai < 4: word ai of the sample's first Philox call
+            const int per = (a.H * sel.act + 3) / 4;
+            const u32x4 w = rng_words(sel.s_seed, ((sel.s_pid0 + (uint64_t)p) << 32) + (uint64_t)best,
+                                      (sel.s_t + tb) * (uint64_t)per, TAG_MPC);
+            first = uniform_f32(pick(w, (uint32_t)ai), sel.low[ai], sel.span[ai]);
+        }
+        float g = 0.0f;
+        if (sel.noise != 0.0f) {
+            const u32x4 w = rng_words(sel.seed, sel.pid0 + (uint64_t)p, sel.t + tb, TAG_MPC_NOISE);
+            const u32x4 w2 = rng_words(sel.seed, sel.pid0 + (uint64_t)p, sel.t + tb + ((uint64_t)1 << 40), TAG_MPC_NOISE);
+            g = (ai == 0) ? gaussian_f32(w.x, w.y) : (ai == 1) ? gaussian_f32(w.z, w.w)
+                : (ai == 2) ? gaussian_f32(w2.x, w2.y) : gaussian_f32(w2.z, w2.w);
+        }
+        sel.action[p * sel.act + ai] = first + sel.noise * g;
+    }
+    if (sel.best_path != nullptr) {
+        const int64_t row = (int64_t)p * a.N + best, M = (int64_t)a.P * a.N;
+        for (int e = threadIdx.x; e < (a.H + 1) * a.d; e += kMpcBlock) {
+            const int tt = e / a.d, k = e % a.d;
+            sel.best_path[(int64_t)p * (a.H + 1) * a.d + e] = S[((int64_t)tt * M + row) * a.d + k];
+        }
     }
 }
 
@@ -350,18 +442,19 @@ size_t ssc_mpc_score_workspace_bytes(int32_t P, int32_t N, int32_t H) {
            align256((size_t)P * nblk * 4) + align256((size_t)P * 4);
 }
 
-int ssc_mpc_score(const ssc_mpc_problems *pr, const float *d_S, float *d_scores, int32_t *d_best_idx,
-                  float *d_best_score, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream) {
-    SSC_REQUIRE(pr != nullptr, "ssc_mpc_score: problems NULL");
-    SSC_REQUIRE(pr->n_problems >= 0 && pr->n_samples >= 0, "ssc_mpc_score: negative size");
-    SSC_REQUIRE(pr->horizon >= 0 && pr->horizon + 1 <= kMaxH1, "ssc_mpc_score: horizon %d > %d", pr->horizon,
+static int mpc_score_common(const char *who, const ssc_mpc_problems *pr, const float *d_S, float *d_scores, int32_t *d_best_idx,
+                            float *d_best_score, const SelectArgs &sel, void *d_workspace, size_t workspace_bytes,
+                            ssc_stream_t stream) {
+    SSC_REQUIRE(pr != nullptr, "%s: problems NULL", who);
+    SSC_REQUIRE(pr->n_problems >= 0 && pr->n_samples >= 0, "%s: negative size", who);
+    SSC_REQUIRE(pr->horizon >= 0 && pr->horizon + 1 <= kMaxH1, "%s: horizon %d > %d", who, pr->horizon,
                 kMaxH1 - 1);
-    SSC_REQUIRE(pr->state_dim >= 1 && pr->state_dim <= SSC_MAX_STATE, "ssc_mpc_score: state_dim out of range");
+    SSC_REQUIRE(pr->state_dim >= 1 && pr->state_dim <= SSC_MAX_STATE, "%s: state_dim out of range", who);
     if (pr->n_problems == 0 || pr->n_samples == 0) return SSC_OK;
     SSC_REQUIRE(pr->wp && pr->left && pr->wp_off && pr->cur_idx && pr->radii && d_S && d_scores && d_best_idx,
-                "ssc_mpc_score: NULL device pointer");
+                "%s: NULL device pointer", who);
     const size_t need = ssc_mpc_score_workspace_bytes(pr->n_problems, pr->n_samples, pr->horizon);
-    SSC_REQUIRE(d_workspace && workspace_bytes >= need, "ssc_mpc_score: workspace %zu < %zu", workspace_bytes, need);
+    SSC_REQUIRE(d_workspace && workspace_bytes >= need, "%s: workspace %zu < %zu", who, workspace_bytes, need);
     hipStream_t s = as_stream(stream);
     // the largest waypoint count decides the LDS carve: read wp_off back?  No host sync is allowed,
     // so the caller passes packed arrays and we size LDS for the maximum the kernel supports.
@@ -382,13 +475,49 @@ int ssc_mpc_score(const ssc_mpc_problems *pr, const float *d_S, float *d_scores,
     int32_t *ticket = reinterpret_cast<int32_t *>(w);
     const size_t lds_common = (size_t)Wmax * (a.d + 1) * 4 + 8 * 4;
     const size_t lds_a = 4 * kMaxH1 * 2 * sizeof(double) + lds_common;
-    const size_t lds_b = (kMaxH1 + 1 + 4 + 4 + 2) * 4 + lds_common;
+    const size_t part_bytes = (size_t)a.nblk * (a.H + 1) * 2 * sizeof(double);
+    const int stage_partials = part_bytes <= 32 * 1024;
+    const size_t lds_b = (kMaxH1 + 1 + 4 + 4 + 2) * 4 + lds_common + (stage_partials ? part_bytes + 8 : 0);
     const dim3 grid(a.nblk, a.P);
     hipLaunchKernelGGL(mpc_pass_a_kernel, grid, dim3(kMpcBlock), lds_a, s, a, Wmax, d_S, partial, ticket);
-    hipLaunchKernelGGL(mpc_pass_b_kernel, grid, dim3(kMpcBlock), lds_b, s, a, Wmax, d_S, partial, d_scores, bbs, bbi,
+    hipLaunchKernelGGL(mpc_pass_b_kernel, grid, dim3(kMpcBlock), lds_b, s, a, Wmax, stage_partials, sel, d_S, partial, d_scores, bbs, bbi,
                        ticket, d_best_idx, d_best_score);
-    return check_launch("ssc_mpc_score");
+    return check_launch(who);
 }
+
+int ssc_mpc_score(const ssc_mpc_problems *pr, const float *d_S, float *d_scores, int32_t *d_best_idx,
+                  float *d_best_score, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream) {
+    SelectArgs sel{};
+    return mpc_score_common("ssc_mpc_score", pr, d_S, d_scores, d_best_idx, d_best_score, sel, d_workspace, workspace_bytes,
+                            stream);
+}
+
+int ssc_mpc_score_select(const ssc_mpc_problems *pr, const float *d_S, float *d_scores, int32_t *d_best_idx,
+                         float *d_best_score, const float *d_A, const ssc_mpc_sampling *sp, int32_t act_dim,
+                         float noise_amount, uint64_t noise_seed, uint64_t problem_id0, uint64_t t, float *d_action,
+                         float *d_best_path, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream) {
+    SSC_REQUIRE(pr != nullptr, "ssc_mpc_score_select: problems NULL");
+    SSC_REQUIRE(act_dim >= 1 && act_dim <= SSC_MAX_ACT, "ssc_mpc_score_select: act_dim %d out of range", act_dim);
+    SSC_REQUIRE((d_A != nullptr) != (sp != nullptr), "ssc_mpc_score_select: exactly one of d_A and sampling must be given");
+    SSC_REQUIRE(pr->horizon >= 1, "ssc_mpc_score_select: horizon < 1");
+    if (pr->n_problems == 0 || pr->n_samples == 0) return SSC_OK;
+    SSC_REQUIRE(d_action != nullptr, "ssc_mpc_score_select: d_action NULL");
+    SelectArgs sel{};
+    sel.action = d_action; sel.best_path = d_best_path; sel.A = d_A; sel.act = act_dim; sel.noise = noise_amount;
+    sel.seed = noise_seed; sel.pid0 = problem_id0; sel.t = t;
+    if (sp != nullptr) {
+        SSC_REQUIRE(sp->n_samples == pr->n_samples, "ssc_mpc_score_select: sampling.n_samples %d != problems.n_samples %d",
+                    sp->n_samples, pr->n_samples);
+        sel.s_seed = sp->seed; sel.s_pid0 = sp->problem_id0; sel.s_t = sp->t; sel.t_base = sp->d_t_base;
+        for (int a = 0; a < act_dim; ++a) {
+            sel.low[a] = sp->low[a];
+            sel.span[a] = sp->high[a] - sp->low[a];
+        }
+    }
+    return mpc_score_common("ssc_mpc_score_select", pr, d_S, d_scores, d_best_idx, d_best_score, sel, d_workspace,
+                            workspace_bytes, stream);
+}
+
 
 int ssc_mpc_observe(const ssc_mpc_problems *pr, const float *d_new_state, int32_t *d_cur_idx,
                     int32_t *d_actions_done, int32_t give_up_after, int32_t final_steps, uint8_t *d_at_goal,

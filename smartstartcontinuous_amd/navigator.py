@@ -240,6 +240,26 @@ class DynamicsModel:
                                                 _ffi.ptr(ws), ws.numel(), _stream()))
         return y
 
+    def do_forward_sim_sampled(self, state0, sampling, m, H, precision=None, out=None, A_out=None):
+        """``do_forward_sim`` with the candidate action sequences drawn INSIDE the kernel from ``sampling``
+        (``mpc_sampling(...)``; bit-identical to ``mpc_sample_actions`` + ``do_forward_sim``): one launch instead of two
+        and no [m, H, act] matrix unless ``A_out`` asks for it (the fp32 path needs it)."""
+        prec = self._resolve(precision)
+        s0 = torch.as_tensor(state0, dtype=torch.float32, device=self.device).contiguous()
+        s0_rows = 1 if s0.dim() == 1 else s0.shape[0]
+        S = out if out is not None else torch.empty((H + 1, m, self.state_dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            if prec == _ffi.SSC_PREC_BF16_MFMA:
+                ws, prec = self._mfma_image(), _ffi.SSC_PREC_BF16_MFMA_PREPARED
+            else:
+                ws = self._workspace(self.lib.ssc_dyn_workspace_bytes(ctypes.byref(self.desc), m, prec))
+                if A_out is None:
+                    A_out = torch.empty((m, H, self.act_dim), dtype=torch.float32, device=self.device)
+            _ffi.check(self.lib.ssc_mpc_forward_sim(ctypes.byref(self.desc), ctypes.byref(self.norm), ctypes.byref(sampling),
+                                                    m, H, self.state_dim, self.act_dim, _ffi.ptr(s0), s0_rows,
+                                                    _ffi.ptr(A_out), _ffi.ptr(S), prec, _ffi.ptr(ws), ws.numel(), _stream()))
+        return S
+
     def do_forward_sim(self, state0, actions, precision=None, out=None):
         """``Dyn_Model.do_forward_sim(..., many_in_parallel=True)``: state0 [d] (tiled, :215-217) or
         [m, d]; actions [m, H, act] -> states [H+1, m, d]."""
@@ -260,6 +280,20 @@ class DynamicsModel:
                                                     _ffi.ptr(A), _ffi.ptr(S), prec, _ffi.ptr(ws), ws.numel(),
                                                     _stream()))
         return S
+
+
+def mpc_sampling(N, low, high, seed, problem_id0=0, t=0, t_base=None):
+    """``ssc_mpc_sampling``: the candidate action sequences of an MPC step as a specification (NND_MB_agent.py:500-501)."""
+    sp = _ffi.MpcSampling()
+    low = np.asarray(low, np.float32).reshape(-1)
+    high = np.asarray(high, np.float32).reshape(-1)
+    sp.n_samples = int(N)
+    for i in range(low.size):
+        sp.low[i], sp.high[i] = float(low[i]), float(high[i])
+    sp.seed, sp.problem_id0, sp.t = int(seed), int(problem_id0), int(t)
+    sp.d_t_base = None if t_base is None else t_base.data_ptr()
+    sp._keep = t_base
+    return sp
 
 
 class MpcProblemSet:
@@ -334,6 +368,38 @@ def mpc_score(problems, S):
     return scores.view(P, N), best_idx, best_score
 
 
+def mpc_score_select(problems, S, sampling=None, A=None, act_dim=1, noise_amount=0.005, seed=0, problem_id0=0, t=0,
+                     want_path=True, out=None):
+    """``mpc_score`` + ``mpc_select_action`` in the same two launches (``ssc_mpc_score_select``): the block that finishes a
+    problem's argmax also writes its action and predicted path.  The winner's first action comes from ``A`` or is
+    regenerated from ``sampling`` (give exactly one).  Returns (scores [P, N], best_idx [P], action [P, act], path or None).
+    ``out``: dict of preallocated scores / best / best_score / action / path / ws tensors (HIP-graph capture)."""
+    S = S.contiguous()
+    H1, M, d = S.shape
+    P = problems.P
+    N = M // P
+    if N * P != M or d != problems.d:
+        raise ValueError("S has the wrong shape for this problem set")
+    lib = _ffi.lib()
+    o = out if out is not None else {}
+    dev = S.device
+    scores = o.get("scores") if o.get("scores") is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    best_idx = o.get("best") if o.get("best") is not None else torch.empty(P, dtype=torch.int32, device=dev)
+    best_score = o.get("best_score") if o.get("best_score") is not None else torch.empty(P, dtype=torch.float32, device=dev)
+    action = o.get("action") if o.get("action") is not None else torch.empty((P, act_dim), dtype=torch.float32, device=dev)
+    path = o.get("path") if o.get("path") is not None else \
+        (torch.empty((P, H1, d), dtype=torch.float32, device=dev) if want_path else None)
+    st = problems.as_struct(N, H1 - 1)
+    with torch.cuda.device(dev):
+        nbytes = lib.ssc_mpc_score_workspace_bytes(P, N, H1 - 1)
+        ws = o.get("ws") if o.get("ws") is not None else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _ffi.check(lib.ssc_mpc_score_select(ctypes.byref(st), _ffi.ptr(S), _ffi.ptr(scores), _ffi.ptr(best_idx),
+                                            _ffi.ptr(best_score), _ffi.ptr(A), ctypes.byref(sampling) if sampling is not None else None,
+                                            int(act_dim), float(noise_amount), int(seed), int(problem_id0), int(t),
+                                            _ffi.ptr(action), _ffi.ptr(path), _ffi.ptr(ws), ws.numel(), _stream()))
+    return scores.view(P, N), best_idx, action, path
+
+
 def mpc_select_action(A, S, best_idx, P, noise_amount, seed, problem_id0=0, t=0, want_path=True):
     """``get_action_with_predicted_states`` tail (NND_MB_agent.py:339-358): first action of the best
     sequence + ``noise_amount * N(0,1)`` (no clip) and the predicted path [P, H+1, d]."""
@@ -373,13 +439,13 @@ class NavigatorBatch:
     def get_action(self, states, t):
         """states [P, d] (device) -> (action [P, act], best_idx [P]) for global step ``t``."""
         self.actions_done += 1                                                            # :340
-        A = mpc_sample_actions(self.P, self.N, self.H, self.low, self.high, self.seed, self.problem_id0, t,
-                               device=states.device)
-        # every problem's state is the start of its N candidate rows (np.tile, :215-217): s0_rows = P
-        S = self.model.do_forward_sim(states.float().contiguous(), A, out=self._S)
-        _, best, _ = mpc_score(self.problems, S)
-        action, _ = mpc_select_action(A, S, best, self.P, self.noise_amount, self.seed, self.problem_id0, t,
-                                      want_path=False)
+        # three launches: forward simulation (drawing its own candidate sequences), scoring pass A, scoring pass B +
+        # selection; every problem's state is the start of its N candidate rows (np.tile, :215-217): s0_rows = P
+        sp = mpc_sampling(self.N, self.low, self.high, self.seed, self.problem_id0, t)
+        S = self.model.do_forward_sim_sampled(states.float().contiguous(), sp, self.P * self.N, self.H, out=self._S)
+        _, best, action, _ = mpc_score_select(self.problems, S, sampling=sp, act_dim=len(self.low),
+                                              noise_amount=self.noise_amount, seed=self.seed, problem_id0=self.problem_id0,
+                                              t=t, want_path=False)
         return action, best
 
     def observe(self, new_states):
@@ -423,9 +489,9 @@ class NavigatorBatch:
         lib = _ffi.lib()
         if len(self.low) != 1:
             raise ValueError("the envs of this engine take one action component")
-        mpc_sample_actions(self.P, self.N, self.H, self.low, self.high, self.seed, self.problem_id0, 0,
-                           out=fb["A"], t_base=fb["t"])
-        S = self.model.do_forward_sim(fb["plan"], fb["A"], out=self._S)
+        # (the forward simulation draws the candidate sequences itself and leaves them in fb["A"] for the step kernel)
+        sp = mpc_sampling(self.N, self.low, self.high, self.seed, self.problem_id0, 0, t_base=fb["t"])
+        S = self.model.do_forward_sim_sampled(fb["plan"], sp, self.P * self.N, self.H, out=self._S, A_out=fb["A"])
         st = self.problems.as_struct(self.N, self.H)
         nav = _ffi.MpcNavState(self.problems.cur_idx.data_ptr(), self.start_idx.data_ptr(), self.actions_done.data_ptr(),
                                self.at_goal.data_ptr(), self.give_up, self.final_steps)

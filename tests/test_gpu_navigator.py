@@ -655,3 +655,62 @@ def test_mpc_rollout_graphs_live_on_the_navigator(nav):
     for i in range(len(shapes)):
         assert torch.equal(out[0][i], out[1][i]), shapes[i]
     assert not torch.equal(out[0][0], out[0][1])
+
+
+@pytest.mark.parametrize("dims,prec,P,N,H,act", [((4, 500, 500, 3), "bf16_mfma", 3, 1000, 4, 1), ((3, 32, 2), "bf16_mfma", 2, 333, 5, 1),
+                                                 ((5, 64, 64, 3), "bf16_mfma", 2, 700, 7, 2), ((3, 32, 2), "f32", 2, 100, 6, 1),
+                                                 ((12, 64, 8), "bf16_mfma", 1, 515, 3, 4)])
+def test_forward_sim_with_in_kernel_sampling_equals_sample_then_sim(nav, dims, prec, P, N, H, act):
+    """ssc_mpc_forward_sim (the forward simulation draws its candidate action sequences itself) == ssc_mpc_sample_actions
+    followed by ssc_dyn_forward_sim, bit for bit: the trajectories, and the action matrix when it is asked for -- for
+    horizons x action widths that need 1, 2 and 3 Philox calls per row, ragged row counts, and through a device step
+    counter (d_t_base)."""
+    rng = np.random.default_rng(5)
+    d = dims[-1]
+    assert dims[0] == d + act
+    Ws, bs = make_mlp(rng, dims)
+    model = nav.DynamicsModel(Ws, bs, make_norm(rng, d, act), state_dim=d, act_dim=act, precision=prec)
+    low, high = [-1.0, -0.5, 0.0, -2.0][:act], [1.0, 0.5, 3.0, 2.0][:act]
+    M = P * N
+    s0 = torch.as_tensor((rng.normal(size=(P, d)) * 0.2).astype(np.float32), device="cuda")
+    t_base = torch.full((1,), 40, dtype=torch.int64, device="cuda")
+    for (t, tb) in ((7, None), (3, t_base)):
+        A = nav.mpc_sample_actions(P, N, H, low, high, seed=77, problem_id0=9, t=t, t_base=tb)
+        S_ref = model.do_forward_sim(s0, A).clone()
+        sp = nav.mpc_sampling(N, low, high, 77, 9, t, t_base=tb)
+        A_out = torch.full((M, H, act), -7.0, device="cuda")
+        S = model.do_forward_sim_sampled(s0, sp, M, H, A_out=A_out)
+        assert torch.equal(S, S_ref) and torch.equal(A_out, A)
+        if prec != "f32":
+            S2 = model.do_forward_sim_sampled(s0, sp, M, H)          # no action matrix at all
+            assert torch.equal(S2, S_ref)
+
+
+def test_score_select_equals_score_then_select(nav):
+    """ssc_mpc_score_select (pass B's last block also selects) == ssc_mpc_score + ssc_mpc_select_action: same scores, winner,
+    action (with the 0.005 N(0,1) noise) and predicted path -- with the action matrix given, and with the winner's first
+    action regenerated from the sampling specification."""
+    rng = np.random.default_rng(31)
+    P, N, H, d = 5, 600, 4, 3
+    Ws, bs = make_mlp(rng, (d + 1, 32, d))
+    model = nav.DynamicsModel(Ws, bs, make_norm(rng, d, 1), state_dim=d, act_dim=1)
+    states = (rng.normal(size=(P, d)) * 0.1).astype(np.float32)
+    wps = [np.cumsum(rng.normal(scale=0.02, size=(15, d)), axis=0) + states[p] for p in range(P)]
+    radii = [np.array([0.03, 0.03, 0.03])] * P
+    lefts = [O.distances_left(w, O.distance_func(radii[0])) for w in wps]
+    ps = nav.MpcProblemSet(wps, lefts, radii, [0] * P)
+    t_base = torch.full((1,), 5, dtype=torch.int64, device="cuda")
+    for (t, tb) in ((11, None), (2, t_base)):
+        t_eff = t + (0 if tb is None else 5)
+        A = nav.mpc_sample_actions(P, N, H, [-2.0], [2.0], seed=8, problem_id0=50, t=t, t_base=tb)
+        S = model.do_forward_sim(torch.as_tensor(states, device="cuda"), A)
+        scores, best, _ = nav.mpc_score(ps, S)
+        action, path = nav.mpc_select_action(A, S, best, P, 0.005, 8, 50, t_eff)
+        sp = nav.mpc_sampling(N, [-2.0], [2.0], 8, 50, t, t_base=tb)
+        if tb is None:
+            sc1, b1, a1, p1 = nav.mpc_score_select(ps, S, A=A, noise_amount=0.005, seed=8, problem_id0=50, t=t_eff)
+            assert torch.equal(sc1, scores) and torch.equal(b1, best) and torch.equal(a1, action) and torch.equal(p1, path)
+        sc2, b2, a2, p2 = nav.mpc_score_select(ps, S, sampling=sp, noise_amount=0.005, seed=8, problem_id0=50, t=t)
+        assert torch.equal(sc2, scores) and torch.equal(b2, best) and torch.equal(a2, action) and torch.equal(p2, path)
+    with pytest.raises(nav._ffi.SscError):
+        nav.mpc_score_select(ps, S, noise_amount=0.0)                # neither A nor a sampling spec
