@@ -54,6 +54,7 @@ struct Step {
     int16_t i0, i1, tail_from, pad;
     int32_t w, b, x, z, xtail;
     float c;
+    int32_t m_lds;   // ST_WGRAD: LDS offset of this layer's Adam moments ([W | b] first moments, then the second ones), or -1: global
 };
 
 struct TrainArgs {   // passed by value: must stay below the 4 KB kernel-argument limit
@@ -80,9 +81,11 @@ __device__ __forceinline__ f4 weights4(const float *w, int j, int out) {
     return r;
 }
 
+// (tanh on the transcendental pipe, |err| ~ 1e-7: ocml's tanhf is ~150 instructions per inlined call site, and the whole
+// kernel has to stay well inside the 64 KB instruction cache: it was 70 KB, it is 27 KB now)
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
-    if (act == ACT_TANH) return tanhf(v);
+    if (act == ACT_TANH) return tanh_fast(v);
     return v;
 }
 
@@ -96,7 +99,7 @@ __device__ __forceinline__ void dense_fwd_groups(const float *W, const float *bi
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = weights4<AL4>(bias, 4 * (wave + kNW * q), out);
     const int n_head = in < tail_from ? in : tail_from;
-#pragma unroll 8
+#pragma unroll 2
     for (int i = 0; i < n_head; ++i) {
         const float x = X[i * kP + b];
 #pragma unroll
@@ -138,10 +141,10 @@ __device__ __forceinline__ void dense_fwd(const float *W, const float *bias, int
                                           int act, const float *Xtail, int tail_from) {
     const int wave = threadIdx.x >> 6;
     const int groups = (out + 3) >> 2;
-    const int nq = (groups - wave + kNW - 1) / kNW;   // groups wave, wave + kNW, ... < groups  (out <= 64: nq <= 4)
-    if (nq >= 4) dense_fwd_groups<4, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
-    else if (nq == 3) dense_fwd_groups<3, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
-    else if (nq == 2) dense_fwd_groups<2, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
+    const int nq = (groups - wave + kNW - 1) / kNW;   // groups wave, wave + kNW, ... < groups  (out <= 64: nq <= 2)
+    // (the wide layers run on the MFMA: what is left here are layer 1 with its 2..8 inputs and ragged sizes, so ONE small
+    // instance per alignment beats four unrolled ones -- code size)
+    if (nq >= 2) dense_fwd_groups<2, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
     else if (nq == 1) dense_fwd_groups<1, AL4>(W, bias, in, out, X, Z, act, Xtail, tail_from);
 }
 
@@ -177,20 +180,94 @@ __device__ __forceinline__ void dense_bwd_rows(const float *W, int out, int i0, 
     }
 }
 
+// out == 1 (the layer above is the critic's Q or a 1-d action): dX[i - i0][b] = W[i] dZ[0][b] act'(A[i - i0][b]),
+// elementwise over (i1 - i0) x 64 values -- the generic routine spent 2.7 k cycles on its per-element bounds checks.
+__device__ __forceinline__ void dense_bwd_out1(const float *W, int i0, int i1, const float *dZ, float *dX, const float *A, int act) {
+    for (int e = threadIdx.x; e < (i1 - i0) * kB; e += kTrainThreads) {
+        const int r = e >> 6, b = e & 63, o = r * kP + b;
+        dX[o] = W[i0 + r] * dZ[b] * act_deriv(A[o], act);
+    }
+}
+
 template <bool AL4>
 __device__ __forceinline__ void dense_bwd_in(const float *W, int out, int i0, int i1, const float *dZ, float *dX,
                                              const float *A, int act) {
     const int wave = threadIdx.x >> 6;
     const int nr = (i1 - i0 - wave + kNW - 1) / kNW;   // rows i0 + wave, i0 + wave + kNW, ... of this wave
     int q = 0;
-    for (; q + 4 <= nr; q += 4) dense_bwd_rows<4, AL4>(W, out, i0, q, dZ, dX, A, act);
-    if (nr - q == 3) dense_bwd_rows<3, AL4>(W, out, i0, q, dZ, dX, A, act);
-    else if (nr - q == 2) dense_bwd_rows<2, AL4>(W, out, i0, q, dZ, dX, A, act);
-    else if (nr - q == 1) dense_bwd_rows<1, AL4>(W, out, i0, q, dZ, dX, A, act);
+    for (; q + 2 <= nr; q += 2) dense_bwd_rows<2, AL4>(W, out, i0, q, dZ, dX, A, act);
+    if (nr - q == 1) dense_bwd_rows<1, AL4>(W, out, i0, q, dZ, dX, A, act);
+}
+
+// ---- the wide contractions on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) ------------------------------------------
+// Lane = sample with one broadcast weight per FMA makes EVERY wave re-read the whole activation block from LDS for its
+// 4 output units: a 64 -> 32 layer moved 139 KB through the LDS and took ~6 k cycles, the pass through W2 11 k, its
+// gradient 13 k -- together 60 % of an iteration.  As 16 x 16 tiles of D = A B (A [16 x 4], B [4 x 16] per k-step, one
+// register per lane each, D four) the same contractions read every operand element once per tile: one or two tiles per
+// wave.  Products and sums are exact fp32 (the instruction is an fp32 FMA chain), so the fp64-oracle tolerance does not
+// move.  The 32x32x2 shape was measured in round 1 (no gain: a 64 -> 32 layer is only TWO 32 x 32 tiles, six of eight
+// waves idle); 16 x 16 tiles give every wave one.  Only layers whose sizes are multiples of 16 come here: a version
+// with operand guards for every size (layer 1, the 1-unit outputs, ragged nets) was built and measured SLOWER on those
+// (41.8 vs 32.8 us per iteration) -- the small layers stay on the VALU routines above.
+// Lane l of a wave: A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15], D[row 4 (l >> 4) + r][col l & 15].
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4m mfma4(float a, float b, const f32x4m &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// forward: Z[j][b] = act(bias[j] + sum_i W[i][j] X[i][b]);  rows = units j, cols = samples b, k = inputs i.
+// Needs out % 16 == 0; input rows beyond the last multiple of 4 (the critic's 65th row: the action) and the rows held
+// in Xtail are added on the VALU to the accumulators.
+__device__ __forceinline__ void dense_fwd_mfma(const float *W, const float *bias, int in, int out, const float *X, float *Z,
+                                               int act, const float *Xtail, int tail_from) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int n_head = in < tail_from ? in : tail_from;
+    const int n_tiles = (out >> 4) * (kB / 16);
+    for (int tile = wave; tile < n_tiles; tile += kNW) {
+        const int j0 = (tile >> 2) * 16, b0 = (tile & 3) * 16;
+        f32x4m acc = *reinterpret_cast<const f32x4m *>(bias + j0 + 4 * kg);
+        const float *wp = W + kg * out + j0 + c, *xp = X + kg * kP + b0 + c;
+        const int n4 = n_head & ~3;
+#pragma unroll 4
+        for (int i0 = 0; i0 < n4; i0 += 4) acc = mfma4(wp[i0 * out], xp[i0 * kP], acc);
+        for (int i = n4; i < in; ++i) {
+            const float x = (i < tail_from) ? X[i * kP + b0 + c] : Xtail[(i - tail_from) * kP + b0 + c];
+            acc += *reinterpret_cast<const f32x4m *>(W + i * out + j0 + 4 * kg) * x;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[(j0 + 4 * kg + r) * kP + b0 + c] = apply_act(acc[r], act);
+    }
+}
+
+// backward: dX[i - i0][b] = act'(A[i - i0][b]) sum_j W[i][j] dZ[j][b];  rows = input rows i, cols = samples, k = units j.
+// Needs (i1 - i0) % 16 == 0 and out % 4 == 0.  A wave takes one 16-row block and TWO sample tiles, so the A fragments
+// (a column slice of row-major W: a strided, bank-conflicted read) are fetched once per pair.
+__device__ __forceinline__ void dense_bwd_mfma(const float *W, int out, int i0, int i1, const float *dZ, float *dX,
+                                               const float *A, int act) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, kg = lane >> 4;
+    const int n_items = ((i1 - i0) >> 4) * 2;     // (row block, pair of sample tiles)
+    for (int item = wave; item < n_items; item += kNW) {
+        const int ib = item >> 1, sb = (item & 1) * 2;
+        f32x4m acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+        const float *wp = W + (i0 + ib * 16 + c) * out + kg;
+        const float *z0 = dZ + kg * kP + sb * 16 + c, *z1 = z0 + 16;
+#pragma unroll 4
+        for (int j0 = 0; j0 < out; j0 += 4) {
+            const float a = wp[j0];
+            acc0 = mfma4(a, z0[j0 * kP], acc0);
+            acc1 = mfma4(a, z1[j0 * kP], acc1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (ib * 16 + 4 * kg + r) * kP + sb * 16 + c;
+            dX[o] = acc0[r] * act_deriv(A[o], act);
+            dX[o + 16] = acc1[r] * act_deriv(A[o + 16], act);
+        }
+    }
 }
 
 // beta^n for an integer step count, by squaring in f64 (ocml's pow() alone is several thousand instructions)
-__device__ __forceinline__ double ipow(double base, int n) {
+__device__ __noinline__ double ipow(double base, int n) {
     double r = 1.0;
     while (n > 0) {
         if (n & 1) r *= base;
@@ -211,8 +288,8 @@ __device__ __forceinline__ void adam_apply(float *theta, float *m, float *v, int
     const float vi = c.beta2 * v[idx] + (1.0f - c.beta2) * (g * g);
     m[idx] = mi;
     v[idx] = vi;
-    theta[idx] += (-c.a) * mi / (sqrtf(vi) + c.eps);
-}
+    theta[idx] += (-c.a) * mi * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vi) + c.eps);   // 1-ulp sqrt / rcp: a 1e-7 relative
+}                                                                                            // wobble of a 1e-3-sized step
 
 // dW[i][j] = sum_b X[i][b] dZ[j][b]; db[j] = sum_b dZ[j][b]; applied straight into Adam.
 // (Fetching the moments of 4 elements ahead of their dot products was measured 2x SLOWER: the pass is bound by
@@ -220,7 +297,39 @@ __device__ __forceinline__ void adam_apply(float *theta, float *m, float *v, int
 __device__ __forceinline__ void weight_grad_adam(const float *X, const float *dZ, int in, int out, float *theta,
                                                  float *m, float *v, int offW, int offb, const AdamCfg &c,
                                                  const float *Xtail, int tail_from) {
-    for (int idx = threadIdx.x; idx < in * out; idx += kTrainThreads) {
+    int first = 0;   // rows [0, first) of dW are done on the MFMA below
+    const int n_head = in < tail_from ? in : tail_from;
+    if ((out & 15) == 0 && n_head >= 16) {
+        // dW[i][j] = sum_b X[i][b] dZ[j][b]: rows = input rows i, cols = units j, k = samples b (64 = 16 k-steps); the
+        // accumulator goes straight into Adam (4 elements per lane, 16 consecutive j per k group: coalesced moments)
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cc = lane & 15, kg = lane >> 4;
+        first = n_head & ~15;
+        const int jt = out >> 4, n_tiles = (first >> 4) * jt;
+        for (int tile = wave; tile < n_tiles; tile += kNW) {
+            const int ib = tile / jt, jb = tile - ib * jt;
+            const float *xp = X + (ib * 16 + cc) * kP + kg, *zp = dZ + (jb * 16 + cc) * kP + kg;
+            f32x4m acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            float m0[4], v0[4];   // the moments are requested BEFORE the contraction: their global round trip runs under it
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int idx = offW + (ib * 16 + 4 * kg + r) * out + jb * 16 + cc;
+                m0[r] = m[idx];
+                v0[r] = v[idx];
+            }
+#pragma unroll 4
+            for (int b0 = 0; b0 < kB; b0 += 4) acc = mfma4(xp[b0], zp[b0], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int idx = offW + (ib * 16 + 4 * kg + r) * out + jb * 16 + cc;
+                const float mi = c.beta1 * m0[r] + (1.0f - c.beta1) * acc[r];
+                const float vi = c.beta2 * v0[r] + (1.0f - c.beta2) * (acc[r] * acc[r]);
+                m[idx] = mi;
+                v[idx] = vi;
+                theta[idx] += (-c.a) * mi * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vi) + c.eps);
+            }
+        }
+    }
+    for (int idx = first * out + threadIdx.x; idx < in * out; idx += kTrainThreads) {
         const int i = idx / out, j = idx - i * out;
         const float *xr = (i >= tail_from) ? Xtail + (i - tail_from) * kP : X + i * kP;
         f4 g4 = (f4)(0.0f);
@@ -248,9 +357,40 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
     float *th_ta = lds + g.off_theta[2], *th_tc = lds + g.off_theta[3];
     for (int e = tid; e < g.n_actor; e += kTrainThreads) { th_a[e] = d.actor[e]; th_ta[e] = d.target_actor[e]; }
     for (int e = tid; e < g.n_critic; e += kTrainThreads) { th_c[e] = d.critic[e]; th_tc[e] = d.target_critic[e]; }
+    // Adam moments of the SMALL layers live in LDS for the whole launch (their update steps are a few hundred elements
+    // each: with the moments in global memory every one of them was two dependent memory round trips)
+    for (int si = 0; si < g.n_steps; ++si) {
+        const Step &st = g.steps[si];
+        if (st.kind != ST_WGRAD || st.m_lds < 0) continue;
+        const int cnt = st.in * st.out + st.out;
+        const float *gm = st.net == 0 ? d.adam_m_actor : d.adam_m_critic, *gv = st.net == 0 ? d.adam_v_actor : d.adam_v_critic;
+        for (int e = tid; e < cnt; e += kTrainThreads) {
+            lds[st.m_lds + e] = gm[st.w + e];
+            lds[st.m_lds + cnt + e] = gv[st.w + e];
+        }
+    }
     __syncthreads();
     int tA = d.adam_t[0], tC = d.adam_t[1];
     float closs = 0.0f, aloss = 0.0f;
+    // running beta powers for MpiAdam's bias correction, in f64 (1 - 0.999^t loses 5 digits in fp32): one ipow per
+    // launch, then one multiplication per iteration -- the per-iteration ipow + sqrt + divisions sat on the critical
+    // path (3.6 k cycles with every other thread waiting at the barrier)
+    double b1a = ipow((double)d.beta1, tA), b2a = ipow((double)d.beta2, tA);
+    double b1c = ipow((double)d.beta1, tC), b2c = ipow((double)d.beta2, tC);
+    // (requesting the batch rows of iteration it + 1 in the middle of iteration it and parking them in registers was
+    // tried: hipcc drains every outstanding load in front of the next __syncthreads(), so the round trips only moved)
+    float pf_s[SSC_MAX_STATE], pf_s2[SSC_MAX_STATE], pf_a[SSC_MAX_ACT], pf_r = 0.0f, pf_t = 0.0f;
+    auto fetch_rows = [&](int it_) {
+        const int64_t rec = g.batch_idx[(int64_t)it_ * kB + tid];
+#pragma unroll
+        for (int c = 0; c < SSC_MAX_STATE; ++c)
+            if (c < d.obs_dim) { pf_s[c] = g.rp.s[rec * d.obs_dim + c]; pf_s2[c] = g.rp.s2[rec * d.obs_dim + c]; }
+#pragma unroll
+        for (int c = 0; c < SSC_MAX_ACT; ++c)
+            if (c < d.act_dim) pf_a[c] = g.rp.a[rec * d.act_dim + c];
+        pf_r = g.rp.r[rec];
+        pf_t = g.rp.t[rec] ? 1.0f : 0.0f;
+    };
 
     for (int it = 0; it < g.n_iters; ++it) {
 #ifdef SSC_DDPG_DIAG
@@ -262,22 +402,50 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
             float *Z = lds + st.z;
             switch (st.kind) {
             case ST_GATHER:   // ReplayBuffer.sample_batch rows
+                ++tA; ++tC;
+                b1a *= (double)d.beta1; b2a *= (double)d.beta2; b1c *= (double)d.beta1; b2c *= (double)d.beta2;
+                if (tid == kB) {   // a lane that has nothing to gather: the MpiAdam step sizes of this iteration
+                    cfg_s[0] = AdamCfg{(float)((double)d.actor_lr * sqrt(1.0 - b2a) / (1.0 - b1a)), d.beta1, d.beta2, d.epsilon};
+                    cfg_s[1] = AdamCfg{(float)((double)d.critic_lr * sqrt(1.0 - b2c) / (1.0 - b1c)), d.beta1, d.beta2, d.epsilon};
+                }
                 if (tid < kB) {
-                    const int64_t rec = g.batch_idx[(int64_t)it * kB + tid];
+                    fetch_rows(it);
                     float *S = lds + g.off_S, *S2 = lds + g.off_S2, *RT = lds + g.off_RT, *XA = lds + g.off_X2act;
-                    for (int c = 0; c < d.obs_dim; ++c) {   // obs0 / obs1 enter every network clipped (ddpg_editted.py:106-109)
-                        const float v0 = g.rp.s[rec * d.obs_dim + c], v1 = g.rp.s2[rec * d.obs_dim + c];
-                        S[c * kP + tid] = d.obs_clip > 0.0f ? fminf(fmaxf(v0, -d.obs_clip), d.obs_clip) : v0;
-                        S2[c * kP + tid] = d.obs_clip > 0.0f ? fminf(fmaxf(v1, -d.obs_clip), d.obs_clip) : v1;
-                    }
-                    for (int c = 0; c < d.act_dim; ++c) XA[c * kP + tid] = g.rp.a[rec * d.act_dim + c];
-                    RT[0 * kP + tid] = g.rp.r[rec];
-                    RT[1 * kP + tid] = g.rp.t[rec] ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < SSC_MAX_STATE; ++c)
+                        if (c < d.obs_dim) {   // obs0 / obs1 enter every network clipped (ddpg_editted.py:106-109)
+                            S[c * kP + tid] = d.obs_clip > 0.0f ? fminf(fmaxf(pf_s[c], -d.obs_clip), d.obs_clip) : pf_s[c];
+                            S2[c * kP + tid] = d.obs_clip > 0.0f ? fminf(fmaxf(pf_s2[c], -d.obs_clip), d.obs_clip) : pf_s2[c];
+                        }
+#pragma unroll
+                    for (int c = 0; c < SSC_MAX_ACT; ++c)
+                        if (c < d.act_dim) XA[c * kP + tid] = pf_a[c];
+                    RT[0 * kP + tid] = pf_r;
+                    RT[1 * kP + tid] = pf_t;
                 }
                 break;
             case ST_FWD:
-                if (st.out == 1 && st.tail_from >= st.in)
+                if (st.out == 1 && st.tail_from >= st.in) {
                     dense_fwd_out1(lds + st.w, lds + st.b, st.in, X, Z, st.act);
+                    // what used to be three interpreter steps of their own (each ~600 cycles of step overhead and, for two
+                    // of them, a block barrier): the lane that just wrote q[b] finishes the per-sample arithmetic on it
+                    if (st.i0 != 0 && tid < kB) {
+                        const float q = Z[tid];
+                        float *RT = lds + g.off_RT;
+                        if (st.i0 == 1) {          // target_Q = r + (1 - terminal) * gamma * Q'(s2, pi'(s2))   (ddpg_editted.py:132-133)
+                            RT[2 * kP + tid] = RT[tid] + (1.0f - RT[kP + tid]) * d.gamma * q;
+                        } else if (st.i0 == 2) {   // critic loss = mean((Q - y)^2)  (:181); the row becomes d loss / d q
+                            const float e = q - RT[2 * kP + tid];
+                            closs = e * e;
+                            Z[tid] = 2.0f * e / (float)kB;
+                        } else {                   // actor loss = -mean Q(s, pi(s))  (:168); the row becomes its dq = -1/B
+                            RT[3 * kP + tid] = -q;   // parked in LDS until ST_LOSSES
+                            Z[tid] = -1.0f / (float)kB;
+                        }
+                    }
+                }
+                else if ((st.out & 15) == 0 && (st.in < st.tail_from ? st.in : st.tail_from) >= 16)
+                    dense_fwd_mfma(lds + st.w, lds + st.b, st.in, st.out, X, Z, st.act, lds + st.xtail, st.tail_from);
                 else if ((st.out & 3) == 0)
                     dense_fwd<true>(lds + st.w, lds + st.b, st.in, st.out, X, Z, st.act, lds + st.xtail, st.tail_from);
                 else
@@ -300,7 +468,11 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
                 for (int e = tid; e < st.out * kB; e += kTrainThreads) Z[(e >> 6) * kP + (e & 63)] = st.c;
                 break;
             case ST_BWD:
-                if ((st.out & 3) == 0) dense_bwd_in<true>(lds + st.w, st.out, st.i0, st.i1, X, Z, lds + st.xtail, st.act);
+                if (st.out == 1)
+                    dense_bwd_out1(lds + st.w, st.i0, st.i1, X, Z, lds + st.xtail, st.act);
+                else if (((st.i1 - st.i0) & 15) == 0 && st.i1 > st.i0 && (st.out & 3) == 0 && st.out >= 16)
+                    dense_bwd_mfma(lds + st.w, st.out, st.i0, st.i1, X, Z, lds + st.xtail, st.act);
+                else if ((st.out & 3) == 0) dense_bwd_in<true>(lds + st.w, st.out, st.i0, st.i1, X, Z, lds + st.xtail, st.act);
                 else dense_bwd_in<false>(lds + st.w, st.out, st.i0, st.i1, X, Z, lds + st.xtail, st.act);
                 break;
             case ST_DERIV:    // delta *= act'(activation): tanh -> 1 - a^2, relu -> a > 0
@@ -314,28 +486,22 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
                 if (tid < kB) aloss = -X[tid];
                 break;
             case ST_LOSSES: {
-                float v0 = (tid < kB) ? closs : 0.0f, v1 = (tid < kB) ? aloss : 0.0f;
+                float v0 = (tid < kB) ? closs : 0.0f, v1 = (tid < kB) ? (lds + g.off_RT)[3 * kP + tid] : 0.0f;
 #pragma unroll
                 for (int msk = 32; msk >= 1; msk >>= 1) { v0 += __shfl_xor(v0, msk); v1 += __shfl_xor(v1, msk); }
                 if (b == 0) { red[0][tid >> 6] = v0; red[1][tid >> 6] = v1; }
-                ++tA; ++tC;
-                if (tid == 0) {
-                    // MpiAdam step sizes of this iteration; bias correction in f64 (1 - 0.999^t loses 5 digits in fp32)
-                    cfg_s[0] = AdamCfg{(float)((double)d.actor_lr * sqrt(1.0 - ipow((double)d.beta2, tA)) /
-                                               (1.0 - ipow((double)d.beta1, tA))), d.beta1, d.beta2, d.epsilon};
-                    cfg_s[1] = AdamCfg{(float)((double)d.critic_lr * sqrt(1.0 - ipow((double)d.beta2, tC)) /
-                                               (1.0 - ipow((double)d.beta1, tC))), d.beta1, d.beta2, d.epsilon};
-                }
                 break;
             }
-            case ST_WGRAD:    // gradients + MpiAdam, all from the OLD parameters' deltas         (:326-327)
-                if (st.net == 0)
-                    weight_grad_adam(X, Z, st.in, st.out, th_a, d.adam_m_actor, d.adam_v_actor, st.w, st.b, cfg_s[0],
-                                     lds + st.xtail, st.tail_from);
-                else
-                    weight_grad_adam(X, Z, st.in, st.out, th_c, d.adam_m_critic, d.adam_v_critic, st.w, st.b, cfg_s[1],
-                                     lds + st.xtail, st.tail_from);
+            case ST_WGRAD: {  // gradients + MpiAdam, all from the OLD parameters' deltas         (:326-327)
+                float *mm = st.net == 0 ? d.adam_m_actor : d.adam_m_critic, *vv = st.net == 0 ? d.adam_v_actor : d.adam_v_critic;
+                if (st.m_lds >= 0) {   // flat index st.w + k of the layer maps to LDS word m_lds + k
+                    mm = lds + st.m_lds - st.w;
+                    vv = mm + (st.in * st.out + st.out);
+                }
+                weight_grad_adam(X, Z, st.in, st.out, st.net == 0 ? th_a : th_c, mm, vv, st.w, st.b, cfg_s[st.net == 0 ? 0 : 1],
+                                 lds + st.xtail, st.tail_from);
                 break;
+            }
             case ST_TUPDATE:  // update_target_net: theta' <- (1 - tau) theta' + tau theta       (:338-339)
                 for (int e = tid; e < g.n_actor; e += kTrainThreads) th_ta[e] = (1.0f - d.tau) * th_ta[e] + d.tau * th_a[e];
                 for (int e = tid; e < g.n_critic; e += kTrainThreads) th_tc[e] = (1.0f - d.tau) * th_tc[e] + d.tau * th_c[e];
@@ -364,6 +530,16 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
     // the forward kernels outside (ssc_actor_forward, ssc_critic_forward, rollouts) read the global arrays
     for (int e = tid; e < g.n_actor; e += kTrainThreads) { d.actor[e] = th_a[e]; d.target_actor[e] = th_ta[e]; }
     for (int e = tid; e < g.n_critic; e += kTrainThreads) { d.critic[e] = th_c[e]; d.target_critic[e] = th_tc[e]; }
+    for (int si = 0; si < g.n_steps; ++si) {
+        const Step &st = g.steps[si];
+        if (st.kind != ST_WGRAD || st.m_lds < 0) continue;
+        const int cnt = st.in * st.out + st.out;
+        float *gm = st.net == 0 ? d.adam_m_actor : d.adam_m_critic, *gv = st.net == 0 ? d.adam_v_actor : d.adam_v_critic;
+        for (int e = tid; e < cnt; e += kTrainThreads) {
+            gm[st.w + e] = lds[st.m_lds + e];
+            gv[st.w + e] = lds[st.m_lds + cnt + e];
+        }
+    }
     if (tid == 0) { d.adam_t[0] = tA; d.adam_t[1] = tC; }
 }
 
@@ -388,7 +564,7 @@ struct StepList {
         if (g.n_steps >= kMaxSteps) { overflow = true; g.n_steps = kMaxSteps - 1; }
         Step &s = g.steps[g.n_steps++];
         s = Step{};
-        s.kind = (int16_t)kind; s.barrier = barrier ? 1 : 0; s.tail_from = 0x7fff;
+        s.kind = (int16_t)kind; s.barrier = barrier ? 1 : 0; s.tail_from = 0x7fff; s.m_lds = -1;
         return s;
     }
     void fwd(int theta, const NetDims &n, int layer, int x, int z, int act, bool barrier, int xtail = -1, int tail_from = 0x7fff) {
@@ -450,7 +626,7 @@ extern "C" int ssc_ddpg_train(const ssc_ddpg_desc *d, const ssc_replay_view *rp,
     // ---- LDS carve (rows of kP floats), then the parameters --------------------------------------------------
     int p = 0;
     auto take = [&](int rows) { const int q = p; p += rows * kP; return q; };
-    const int S = take(d->obs_dim), RT = take(3);                             // RT: r, terminal, y (target Q)
+    const int S = take(d->obs_dim), RT = take(4);                             // RT: r, terminal, y (target Q), -Q(s, pi(s))
     const int X2 = take(C.h1 + d->act_dim);                                   // critic: relu(layer 1) rows, then the action rows
     const int CA2 = take(C.h2 > d->obs_dim ? C.h2 : d->obs_dim);              // critic layer 2; before that the next-state rows
     const int S2 = CA2;                                                       // (read by the target pass's first two steps only)
@@ -470,9 +646,8 @@ extern "C" int ssc_ddpg_train(const ssc_ddpg_desc *d, const ssc_replay_view *rp,
     const int TA = al4(p), TC = al4(TA + A.total()), TTA = al4(TC + C.total()), TTC = al4(TTA + A.total());
     g.off_theta[0] = TA; g.off_theta[1] = TC; g.off_theta[2] = TTA; g.off_theta[3] = TTC;
     p = TTC + C.total();
-    const size_t lds = (size_t)p * sizeof(float);
-    if (lds > 160 * 1024 - 128)   // 64 B of static LDS (loss partials, Adam step sizes)
-        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: these layer sizes need %zu B of LDS", lds);
+    if ((size_t)p * sizeof(float) > 160 * 1024 - 128)   // 64 B of static LDS (loss partials, Adam step sizes)
+        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: these layer sizes need %zu B of LDS", (size_t)p * sizeof(float));
     // ---- the steps of one iteration ----------------------------------------------------------------------------
     StepList L(g);
     L.add(ST_GATHER, true);
@@ -483,23 +658,22 @@ extern "C" int ssc_ddpg_train(const ssc_ddpg_desc *d, const ssc_replay_view *rp,
     L.fwd(TTA, A, 3, DZ2A, X2B + C.h1 * kP, ACT_TANH, true);
     L.fwd(TTC, C, 2, X2B, CB2, act2, true);
     L.fwd(TTC, C, 3, CB2, DZB2, ACT_NONE, true);
-    { Step &s = L.add(ST_YTARGET, false); s.x = DZB2; }
+    g.steps[g.n_steps - 1].i0 = 1;                              // ... + the target_Q arithmetic on the row (post-op 1)
     // critic on (s, a) and actor on s                                (:181, :127)
     L.fwd(TC, C, 1, S, X2, ACT_RELU, false);
     L.fwd(TA, A, 1, S, U1, ACT_RELU, true);
     L.fwd(TC, C, 2, X2, CA2, act2, false);
     L.fwd(TA, A, 2, U1, U2, act2, true);
     L.fwd(TC, C, 3, CA2, DQ, ACT_NONE, false);
+    g.steps[g.n_steps - 1].i0 = 2;                              // ... + critic loss, DQ becomes d loss / d q (post-op 2)
     L.fwd(TA, A, 3, U2, PI, ACT_TANH, true);
-    { Step &s = L.add(ST_CLOSS, true); s.x = DQ; s.z = DQ; }
     // critic backward: dz2 = (W3 dq) * act'(z2)
     L.bwd(TC + C.oW3(), 1, 0, C.h2, DQ, DZ2, CA2, act2, false);
     // critic forward on (s, pi(s)) for the actor loss: the same relu(layer 1) rows, the action rows are pi(s)
     L.fwd(TC, C, 2, X2, CB2, act2, true, PI, C.h1);
     L.bwd(TC + C.oW2(), C.h2, 0, C.h1, DZ2, DZ1, X2, ACT_RELU, false);   // ... * relu'(layer 1)
-    L.fwd(TC, C, 3, CB2, DZ3A, ACT_NONE, true);             // q(s, pi) -> DZ3A row 0 (temporarily)
-    { Step &s = L.add(ST_ALOSS, false); s.x = DZ3A; }
-    { Step &s = L.add(ST_FILL, true); s.z = DZ3A; s.out = 1; s.c = -1.0f / (float)kB; }   // dq of -mean Q
+    L.fwd(TC, C, 3, CB2, DZ3A, ACT_NONE, true);             // q(s, pi) -> DZ3A row 0, then
+    g.steps[g.n_steps - 1].i0 = 3;                          // actor loss, the row becomes dq of -mean Q (post-op 3)
     L.bwd(TC + C.oW3(), 1, 0, C.h2, DZ3A, DZB2, CB2, act2, true);
     // d(-mean Q)/d(action) = rows h1.. of W2 dzb2 (through the output tanh), then back through the actor
     L.bwd(TC + C.oW2(), C.h2, C.h1, C.h1 + d->act_dim, DZB2, DZ3A, PI, ACT_TANH, true);
@@ -514,7 +688,22 @@ extern "C" int ssc_ddpg_train(const ssc_ddpg_desc *d, const ssc_replay_view *rp,
     L.wgrad(0, A.oW3(), A.ob3(), A.h2, A.out, U2, DZ3A, true);
     L.add(ST_TUPDATE, true);
     if (L.overflow) return set_error(SSC_EINVAL, "ssc_ddpg_train: step list overflow");
+    // Adam moments of the small layers move into what is left of the LDS (smallest layers first)
+    {
+        int free_floats = (160 * 1024 - 128) / 4 - p;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int si = 0; si < g.n_steps; ++si) {
+                Step &st = g.steps[si];
+                if (st.kind != ST_WGRAD || st.m_lds >= 0) continue;
+                const int cnt = st.in * st.out + st.out;
+                if ((pass == 0 && cnt > 256) || cnt > 640 || 2 * cnt > free_floats) continue;
+                st.m_lds = p;
+                p += 2 * cnt;
+                free_floats -= 2 * cnt;
+            }
+    }
 
+    const size_t lds = (size_t)p * sizeof(float);
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(ddpg_train_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),

@@ -14,8 +14,10 @@ pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.ex
 
 
 def test_abi_argument_validation_under_asan_ubsan():
-    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "sanitizer"))
-    import build as sb
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ssc_sanitizer_build", os.path.join(os.path.dirname(__file__), "sanitizer", "build.py"))
+    sb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sb)
     exe = sb.build()
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")

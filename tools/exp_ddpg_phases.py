@@ -24,9 +24,9 @@ for _ in range(2):
                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 torch.cuda.synchronize()
 m = np.median(out.cpu().numpy()[20:], axis=0)
-names = (["gather"] + ["tgt fwd a1", "tgt fwd c1", "tgt fwd a2", "tgt fwd a3", "tgt fwd c2", "tgt fwd c3", "y target"]
-         + ["fwd c1", "fwd a1", "fwd c2", "fwd a2", "fwd c3", "fwd a3", "closs", "bwd c3 (+deriv)", "fwd c2(s,pi)", "bwd c2->dz1 (+relu)",
-            "fwd c3(s,pi)", "aloss", "fill dq", "bwd c3 (pi)", "bwd c2->da", "bwd a3", "bwd a2",
+names = (["gather"] + ["tgt fwd a1", "tgt fwd c1", "tgt fwd a2", "tgt fwd a3", "tgt fwd c2", "tgt fwd c3 + y target"]
+         + ["fwd c1", "fwd a1", "fwd c2", "fwd a2", "fwd c3 + closs", "fwd a3", "bwd c3 (+deriv)", "fwd c2(s,pi)", "bwd c2->dz1 (+relu)",
+            "fwd c3(s,pi) + aloss + dq", "bwd c3 (pi)", "bwd c2->da", "bwd a3", "bwd a2",
             "losses+adam cfg", "wgrad c1", "wgrad c2", "wgrad c3", "wgrad a1", "wgrad a2", "wgrad a3", "target update"])
 for k, nme in enumerate(names):
     print("%2d %-20s %7.0f cycles" % (k, nme, m[k]))
