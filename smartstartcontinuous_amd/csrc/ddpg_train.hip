@@ -48,7 +48,7 @@ enum {
 
 // One step.  x, z, xtail (and w, b of the dense steps) are offsets in floats from the start of the dynamic LDS
 // array; for ST_WGRAD w, b index the flat parameter / moment arrays of the net.
-struct Step {
+struct alignas(16) Step {
     int16_t kind, barrier;          // barrier: __syncthreads() after the step
     int16_t in, out, act, net;      // net: 0 actor / 1 critic (ST_WGRAD)
     int16_t i0, i1, tail_from, pad;
@@ -56,6 +56,8 @@ struct Step {
     float c;
     int32_t m_lds;   // ST_WGRAD: LDS offset of this layer's Adam moments ([W | b] first moments, then the second ones), or -1: global
 };
+
+static_assert(sizeof(Step) == 48, "a step is three 16-byte scalar loads");
 
 struct TrainArgs {   // passed by value: must stay below the 4 KB kernel-argument limit
     ssc_ddpg_desc d;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
     }
     __syncthreads();
     int tA = d.adam_t[0], tC = d.adam_t[1];
-    float closs = 0.0f, aloss = 0.0f;
+    float closs = 0.0f;
     // running beta powers for MpiAdam's bias correction, in f64 (1 - 0.999^t loses 5 digits in fp32): one ipow per
     // launch, then one multiplication per iteration -- the per-iteration ipow + sqrt + divisions sat on the critical
     // path (3.6 k cycles with every other thread waiting at the barrier)
@@ -392,12 +394,24 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
         pf_t = g.rp.t[rec] ? 1.0f : 0.0f;
     };
 
+    // A step descriptor is fetched WHOLE (three s_load_dwordx4 from the kernel-argument segment) one step ahead of its
+    // use.  Read field by field where needed, every step paid 4-5 DEPENDENT scalar-cache round trips (kind -> branch ->
+    // sizes -> branch -> offsets ...), ~800 of the ~2000 cycles even the smallest step took.
+    auto load_step = [&](int si_) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 *q = reinterpret_cast<const i32x4 *>(&g.steps[si_]);
+        union { i32x4 v[3]; Step s; } u;
+        u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2];
+        return u.s;
+    };
+    Step nxt = load_step(0);
     for (int it = 0; it < g.n_iters; ++it) {
 #ifdef SSC_DDPG_DIAG
         uint64_t cp_prev = __builtin_amdgcn_s_memtime();
 #endif
         for (int si = 0; si < g.n_steps; ++si) {
-            const Step &st = g.steps[si];   // kernel-argument segment: scalar loads, the whole block follows one step
+            const Step st = nxt;
+            nxt = load_step(si + 1 < g.n_steps ? si + 1 : 0);
             const float *X = lds + st.x;
             float *Z = lds + st.z;
             switch (st.kind) {
@@ -483,7 +497,7 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
                 }
                 break;
             case ST_ALOSS:    // actor loss = -mean Q(s, pi(s))                                  (:168)
-                if (tid < kB) aloss = -X[tid];
+                if (tid < kB) (lds + g.off_RT)[3 * kP + tid] = -X[tid];
                 break;
             case ST_LOSSES: {
                 float v0 = (tid < kB) ? closs : 0.0f, v1 = (tid < kB) ? (lds + g.off_RT)[3 * kP + tid] : 0.0f;
