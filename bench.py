@@ -71,10 +71,10 @@ def bench_config3(args, torch):
     env.reset()
     chunk = TransitionChunk(2, K, n, env.device)
     pd = env.policy_desc(ActorPolicy(w, precision="bf16_mfma", ou_mu=0.4, ou_sigma=0.6, ou_theta=0.15))
-    for _ in range(args.warmup):
+    for _ in range(args.warmup + args.settle_launches):     # settling: see main()
         env.rollout(K, out=chunk, policy_desc=pd)
-    torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for a, b in evs:
         a.record(); env.rollout(K, out=chunk, policy_desc=pd); b.record()
@@ -85,7 +85,8 @@ def bench_config3(args, torch):
     rate = n * K * args.steps / el
     mfma_flops = 2.0 * 64 * 32 + 2.0 * 2 * 64          # hidden GEMM (bf16 MFMA) + layer 1 (fp32 MFMA) per env-step
     res = {"metric": "env-steps/sec, 65 536 MountainCar envs + DDPG actor 64-32 fwd (bf16 MFMA) + OU noise", "value": rate,
-           "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+           "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "settle_launches": args.settle_launches,
+           "ms_per_step": el / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (hidden GEMM), f32 elsewhere",
            "data": "synthetic", "config": {"workload": "BASELINE configs[2]: MountainCarContinuous-v0, %d envs, actor 64-32 "
                                           "lastLayerTanh, OU mu0.4 sigma0.6 theta0.15, %d env-steps per launch, full log" % (n, K)},
@@ -169,7 +170,7 @@ def bench_config4(args, torch):
 
     def sim_only(A):
         model.do_forward_sim(s0, A, out=S)
-    for t in range(args.warmup):
+    for t in range(args.warmup + args.settle_launches):     # settling: see main()
         step(t)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -201,7 +202,8 @@ def bench_config4(args, torch):
     flop_row = 2.0 * ((d + a) * 500 + 500 * 500 + 500 * d)         # 507 000, SURVEY 8d
     res = {"metric": "row-steps/sec, NND_MB dynamics MLP 2x500 forward sim + MPC scoring, 65 536 rows", "value": M * H * args.steps / el,
            "unit": "row-steps/s", "env_steps_per_s": P * args.steps / el,
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "settle_launches": args.settle_launches,
+           "ms_per_step": el / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (all layers on bf16 MFMA, fp32 accumulate; layer 1 split into bf16 head + residual)",
            "data": "synthetic", "config": {"workload": "BASELINE configs[3]: Pendulum dims (in 4, out 3), num_fc_layers 2, depth 500, "
                                           "%d MPC problems x %d samples = %d rows, horizon %d; z-score stats from 25x333 Pendulum random rollouts, "
@@ -310,9 +312,11 @@ def main():
     ap.add_argument("--steady-launches", type=int, default=400,
                     help="extra untimed-for-`value` launches after the timed region whose per-launch distribution is "
                          "reported as roofline.steady (N = 1 only; 0 disables)")
-    ap.add_argument("--settle-launches", type=int, default=300,
+    ap.add_argument("--settle-launches", type=int, default=1500,
                     help="untimed launches of the step between the W warm-up steps and the timed region, so that the "
                          "timed K steps run past the post-idle power/clock transient (0 disables)")
+    ap.add_argument("--series-out", default=None,
+                    help="diagnostic: write (phase, start, duration) of every launch of the run to this CSV")
     ap.add_argument("--no-single-step", action="store_true", help="skip the single-step-API (ssc_mc_step) line")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
                     help="BASELINE.json config (1-based): 2 = headline random-policy rollout (default), "
@@ -385,17 +389,27 @@ def main():
         if gather is not None:
             gather.submit(chunk, i & 1, env.stats)
 
+    series = [] if args.series_out else None     # diagnostic: (phase, event pair) of EVERY launch
+
+    def ev_pair(phase):
+        if series is None:
+            return None
+        series.append((phase, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+        return series[-1][1:]
+
     for i in range(args.warmup):
-        one_step(i)
-    # Settling: the first ~10 ms of sustained load after an idle GPU are a power/clock transient (the same launch
-    # takes 260 -> 340 -> 287 us over its first 25 repetitions, profiles/r02/drift).  W = 5
-    # warm-up launches end in the middle of it, so W is followed by --settle-launches further untimed launches of
-    # the same step: the timed K steps then measure the state a rollout engine actually runs in.
+        one_step(i, ev_pair("warmup"))
+    # Settling: the first ~10 ms of sustained load after an idle GPU are a power/clock transient (the shader clock dips
+    # to ~1.7 GHz: the same launch takes 260 -> 340 -> 287 us over its first 25 repetitions, profiles/r02/drift), and
+    # the launch time keeps creeping down for ~0.3 s of sustained load after that (262 -> 252 -> 243 us,
+    # profiles/r02/drift/window.txt).  W = 5 warm-up launches end in the middle of the first, so
+    # W is followed by --settle-launches further untimed launches of the same step (1500 = 0.4 s): the timed K steps
+    # then measure the state a rollout engine actually runs in.  The count is reported in the JSON line.
     for i in range(args.settle_launches):
-        one_step(args.warmup + i)
+        one_step(args.warmup + i, ev_pair("settle"))
     warm_total = args.warmup + args.settle_launches
-    barrier()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(warm_total + i, evs[i])
@@ -416,6 +430,15 @@ def main():
             one_step(warm_total + args.steps + i, ev)
         torch.cuda.synchronize()
         sl = [a.elapsed_time(b) for a, b in sev]
+        if series is not None and rank == 0:
+            t_first = series[0][1]
+            rows = [(ph, t_first.elapsed_time(a), a.elapsed_time(b)) for ph, a, b in series]
+            rows += [("timed", t_first.elapsed_time(a), a.elapsed_time(b)) for a, b in evs]
+            rows += [("steady", t_first.elapsed_time(a), a.elapsed_time(b)) for a, b in sev]
+            with open(args.series_out, "w") as f:
+                f.write("phase,start_ms,kernel_ms\n")
+                for r in rows:
+                    f.write("%s,%.4f,%.5f\n" % r)
         steady = dist_stats(sl[len(sl) // 4:])            # the settled three quarters
         steady["first_quarter_mean"] = sum(sl[:len(sl) // 4]) / max(1, len(sl) // 4)
         steady["launches"] = args.steady_launches
