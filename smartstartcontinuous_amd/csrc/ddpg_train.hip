@@ -16,14 +16,12 @@
 //     (forward) or input rows (backward) are dealt to the 4 waves in groups of 4, and a weight is one
 //     broadcast LDS read -- a float4 of 4 consecutive units where the row length allows.
 // fp32, plain FMA chains in k order; MpiAdam's bias-corrected step size is computed in f64.
-#include "ssc_device.h"
+#include "ddpg_device.h"
 #include "ssc_host.h"
+#include <cstdlib>
 
 namespace ssc {
 
-constexpr int kB = 64;       // batch size = lanes of a wave
-constexpr int kP = kB + 4;   // padded LDS row: 16-B aligned rows (float4 access over 4 samples); a stride of
-                             // 68 dwords keeps both ds_read_b128 column gathers and ds_write_b128 conflict-free
 #ifndef SSC_DDPG_THREADS
 #define SSC_DDPG_THREADS 512
 #endif
@@ -72,7 +70,17 @@ struct TrainArgs {   // passed by value: must stay below the 4 KB kernel-argumen
 };
 static_assert(sizeof(TrainArgs) <= 4000, "TrainArgs must fit the kernel-argument segment");
 
-typedef float f4 __attribute__((ext_vector_type(4)));
+#ifdef SSC_DDPG_DIAG
+// intra-step marks of thread 0 (cycles since the step began), copied out for step SSC_DDPG_DIAG_STEP
+#ifndef SSC_DDPG_DIAG_STEP
+#define SSC_DDPG_DIAG_STEP 10
+#endif
+__shared__ uint64_t diag_t0;
+__shared__ float diag_marks[12];
+#define DIAG_MARK(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) diag_marks[k] = (float)(__builtin_amdgcn_s_memtime() - diag_t0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DIAG_MARK(k) do { } while (0)
+#endif
 
 template <bool AL4>
 __device__ __forceinline__ f4 weights4(const float *w, int j, int out) {
@@ -212,9 +220,22 @@ __device__ __forceinline__ void dense_bwd_in(const float *W, int out, int i0, in
 // with operand guards for every size (layer 1, the 1-unit outputs, ragged nets) was built and measured SLOWER on those
 // (41.8 vs 32.8 us per iteration) -- the small layers stay on the VALU routines above.
 // Lane l of a wave: A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15], D[row 4 (l >> 4) + r][col l & 15].
-typedef float f32x4m __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4m mfma4(float a, float b, const f32x4m &c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+
+// acc += sum over `nsteps` k-steps of A-fragment x B-fragment (operand element of step s at ap[s * astride], bp[s * bstride]).
+// The operands of U steps are requested together and the U MFMAs issued behind them: hipcc does not unroll the plain
+// loop (runtime trip count), which left every MFMA waiting on its own LDS round trip -- 16 serial round trips for a
+// 64-deep contraction, ~2 k of the ~3.3 k cycles such a step took.
+template <int U>
+__device__ __forceinline__ void mfma_chain(f32x4m &acc, const float *ap, int astride, const float *bp, int bstride, int nsteps) {
+    int s = 0;
+    for (; s + U <= nsteps; s += U) {
+        float a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = ap[(s + u) * astride]; b[u] = bp[(s + u) * bstride]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = mfma4(a[u], b[u], acc);
+    }
+    for (; s < nsteps; ++s) acc = mfma4(ap[s * astride], bp[s * bstride], acc);
 }
 
 // forward: Z[j][b] = act(bias[j] + sum_i W[i][j] X[i][b]);  rows = units j, cols = samples b, k = inputs i.
@@ -227,17 +248,27 @@ __device__ __forceinline__ void dense_fwd_mfma(const float *W, const float *bias
     const int n_tiles = (out >> 4) * (kB / 16);
     for (int tile = wave; tile < n_tiles; tile += kNW) {
         const int j0 = (tile >> 2) * 16, b0 = (tile & 3) * 16;
+        DIAG_MARK(1);
         f32x4m acc = *reinterpret_cast<const f32x4m *>(bias + j0 + 4 * kg);
         const float *wp = W + kg * out + j0 + c, *xp = X + kg * kP + b0 + c;
         const int n4 = n_head & ~3;
-#pragma unroll 4
-        for (int i0 = 0; i0 < n4; i0 += 4) acc = mfma4(wp[i0 * out], xp[i0 * kP], acc);
+        mfma_chain<8>(acc, wp, 4 * out, xp, 4 * kP, n4 >> 2);
+        DIAG_MARK(2);
         for (int i = n4; i < in; ++i) {
             const float x = (i < tail_from) ? X[i * kP + b0 + c] : Xtail[(i - tail_from) * kP + b0 + c];
             acc += *reinterpret_cast<const f32x4m *>(W + i * out + j0 + 4 * kg) * x;
         }
+        DIAG_MARK(3);
+        if (act == ACT_RELU) {          // (one wave-uniform branch per tile, not one per element)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Z[(j0 + 4 * kg + r) * kP + b0 + c] = apply_act(acc[r], act);
+            for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+        } else if (act == ACT_TANH) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = tanh_fast(acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[(j0 + 4 * kg + r) * kP + b0 + c] = acc[r];
+        DIAG_MARK(4);
     }
 }
 
@@ -253,11 +284,19 @@ __device__ __forceinline__ void dense_bwd_mfma(const float *W, int out, int i0, 
         f32x4m acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
         const float *wp = W + (i0 + ib * 16 + c) * out + kg;
         const float *z0 = dZ + kg * kP + sb * 16 + c, *z1 = z0 + 16;
-#pragma unroll 4
-        for (int j0 = 0; j0 < out; j0 += 4) {
-            const float a = wp[j0];
-            acc0 = mfma4(a, z0[j0 * kP], acc0);
-            acc1 = mfma4(a, z1[j0 * kP], acc1);
+        int s4 = 0;
+        const int nsteps = out >> 2;
+        for (; s4 + 4 <= nsteps; s4 += 4) {   // 4 k-steps: 12 operand reads in flight, then 8 MFMAs on two accumulators
+            float a[4], u0[4], u1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = wp[4 * (s4 + u)]; u0[u] = z0[4 * (s4 + u) * kP]; u1[u] = z1[4 * (s4 + u) * kP]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc0 = mfma4(a[u], u0[u], acc0); acc1 = mfma4(a[u], u1[u], acc1); }
+        }
+        for (; s4 < nsteps; ++s4) {
+            const float a = wp[4 * s4];
+            acc0 = mfma4(a, z0[4 * s4 * kP], acc0);
+            acc1 = mfma4(a, z1[4 * s4 * kP], acc1);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -268,20 +307,6 @@ __device__ __forceinline__ void dense_bwd_mfma(const float *W, int out, int i0, 
     }
 }
 
-// beta^n for an integer step count, by squaring in f64 (ocml's pow() alone is several thousand instructions)
-__device__ __noinline__ double ipow(double base, int n) {
-    double r = 1.0;
-    while (n > 0) {
-        if (n & 1) r *= base;
-        base *= base;
-        n >>= 1;
-    }
-    return r;
-}
-
-struct AdamCfg {
-    float a, beta1, beta2, eps;   // a = stepsize * sqrt(1 - b2^t) / (1 - b1^t) with t already incremented
-};
 
 // MpiAdam.update (baselines common/mpi_adam.py [third-party], ddpg_editted.py:326-327): theta in LDS, moments in
 // global memory, same index.
@@ -318,8 +343,7 @@ __device__ __forceinline__ void weight_grad_adam(const float *X, const float *dZ
                 m0[r] = m[idx];
                 v0[r] = v[idx];
             }
-#pragma unroll 4
-            for (int b0 = 0; b0 < kB; b0 += 4) acc = mfma4(xp[b0], zp[b0], acc);
+            mfma_chain<8>(acc, xp, 4, zp, 4, kB / 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int idx = offW + (ib * 16 + 4 * kg + r) * out + jb * 16 + cc;
@@ -412,6 +436,10 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
         for (int si = 0; si < g.n_steps; ++si) {
             const Step st = nxt;
             nxt = load_step(si + 1 < g.n_steps ? si + 1 : 0);
+#ifdef SSC_DDPG_DIAG
+            if (tid == 0) diag_t0 = cp_prev;
+            DIAG_MARK(0);
+#endif
             const float *X = lds + st.x;
             float *Z = lds + st.z;
             switch (st.kind) {
@@ -507,13 +535,19 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
                 break;
             }
             case ST_WGRAD: {  // gradients + MpiAdam, all from the OLD parameters' deltas         (:326-327)
-                float *mm = st.net == 0 ? d.adam_m_actor : d.adam_m_critic, *vv = st.net == 0 ? d.adam_v_actor : d.adam_v_critic;
+                // two instances, so that each knows its address space: with one generic pointer the moment accesses were
+                // flat_load / flat_store, which count on lgkmcnt as well -- every wait for an LDS operand of the contraction
+                // then also waited for the global round trip of the prefetched moments
+                float *theta = st.net == 0 ? th_a : th_c;
+                const AdamCfg &cfg = cfg_s[st.net == 0 ? 0 : 1];
                 if (st.m_lds >= 0) {   // flat index st.w + k of the layer maps to LDS word m_lds + k
-                    mm = lds + st.m_lds - st.w;
-                    vv = mm + (st.in * st.out + st.out);
+                    float *mm = lds + (st.m_lds - st.w);
+                    weight_grad_adam(X, Z, st.in, st.out, theta, mm, mm + (st.in * st.out + st.out), st.w, st.b, cfg,
+                                     lds + st.xtail, st.tail_from);
+                } else {
+                    weight_grad_adam(X, Z, st.in, st.out, theta, st.net == 0 ? d.adam_m_actor : d.adam_m_critic,
+                                     st.net == 0 ? d.adam_v_actor : d.adam_v_critic, st.w, st.b, cfg, lds + st.xtail, st.tail_from);
                 }
-                weight_grad_adam(X, Z, st.in, st.out, st.net == 0 ? th_a : th_c, mm, vv, st.w, st.b, cfg_s[st.net == 0 ? 0 : 1],
-                                 lds + st.xtail, st.tail_from);
                 break;
             }
             case ST_TUPDATE:  // update_target_net: theta' <- (1 - tau) theta' + tau theta       (:338-339)
@@ -529,8 +563,12 @@ __global__ __launch_bounds__(kTrainThreads) void ddpg_train_kernel(TrainArgs g) 
 #endif
                 break;
             }
+            DIAG_MARK(5);
             if (st.barrier) __syncthreads();
 #ifdef SSC_DDPG_DIAG
+            DIAG_MARK(6);
+            if (si == SSC_DDPG_DIAG_STEP && tid == 0)
+                for (int k = 0; k < 8; ++k) g.losses[(int64_t)kMaxSteps * it + 32 + k] = diag_marks[k];
             {
                 __builtin_amdgcn_sched_barrier(0);
                 const uint64_t now = __builtin_amdgcn_s_memtime();
@@ -631,6 +669,14 @@ extern "C" int ssc_ddpg_train(const ssc_ddpg_desc *d, const ssc_replay_view *rp,
                 "ssc_ddpg_train: NULL parameter / optimiser pointer");
     SSC_REQUIRE(rp->s && rp->a && rp->r && rp->t && rp->s2 && rp->capacity > 0 && d_batch_idx,
                 "ssc_ddpg_train: NULL replay pointer");
+    // the shipped shape has a kernel of its own (ddpg_train_fixed.hip); SSC_DDPG_INTERPRETER=1 keeps it on the step
+    // interpreter below (A/B measurements, and the tests that check both against the oracle)
+#ifndef SSC_DDPG_DIAG
+    if (ddpg_fixed_shape(d)) {
+        const char *force = getenv("SSC_DDPG_INTERPRETER");
+        if (!(force && force[0] == '1')) return ddpg_train_fixed(d, rp, d_batch_idx, n_iters, d_losses, as_stream(stream));
+    }
+#endif
 
     const NetDims A{d->obs_dim, d->actor_h1, d->actor_h2, d->act_dim, 0};
     const NetDims C{d->obs_dim, d->critic_h1, d->critic_h2, 1, d->act_dim};

@@ -354,12 +354,19 @@ class _BoxEnv:
         self.action_space = spaces.Box(low=np.array([-1.0], np.float32), high=np.array([1.0], np.float32))
 
 
-@pytest.mark.parametrize("obs_dim,h1,h2", [(2, 64, 32), (3, 64, 32), (8, 64, 32), (2, 24, 20)])
-def test_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2):
+@pytest.mark.parametrize("obs_dim,h1,h2,interpreter", [(2, 64, 32, False), (3, 64, 32, False), (2, 64, 32, True), (3, 64, 32, True),
+                                                       (8, 64, 32, False), (2, 24, 20, False)])
+def test_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2, interpreter, monkeypatch):
     """ssc_ddpg_train (train + update_target_net, n iterations in one launch) against the fp64 restatement
     of ddpg_editted.py:287-339 (itself cross-checked against torch autograd on the CPU).  obs_dim 3 is the
-    Pendulum layout, 8 the widest the ABI admits (the LDS carve must hold), 24-20 exercises ragged unit groups."""
+    Pendulum layout, 8 the widest the ABI admits (the LDS carve must hold), 24-20 exercises ragged unit groups.
+    The shipped 64-32 shape with a 2-d / 3-d observation runs the shape-specialised kernel (ddpg_train_fixed.hip),
+    everything else -- and 64-32 again with SSC_DDPG_INTERPRETER=1 -- the step interpreter (ddpg_train.hip)."""
     from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    if interpreter:
+        monkeypatch.setenv("SSC_DDPG_INTERPRETER", "1")
+    else:
+        monkeypatch.delenv("SSC_DDPG_INTERPRETER", raising=False)
     rng = np.random.default_rng(11)
     env = ssc.make("MountainCarContinuous-v0") if obs_dim == 2 else _BoxEnv(obs_dim)
     for llt in (True, False):

@@ -31,3 +31,4 @@ names = (["gather"] + ["tgt fwd a1", "tgt fwd c1", "tgt fwd a2", "tgt fwd a3", "
 for k, nme in enumerate(names):
     print("%2d %-20s %7.0f cycles" % (k, nme, m[k]))
 print("total %.0f cycles per iteration" % m[:len(names)].sum())
+print("marks of step %s (cycles since step start): %s" % (os.environ.get("SSC_DIAG_STEP_NAME", "10"), " ".join("%.0f" % x for x in m[32:40])))
