@@ -671,12 +671,10 @@ extern "C" int ssc_ddpg_train(const ssc_ddpg_desc *d, const ssc_replay_view *rp,
                 "ssc_ddpg_train: NULL replay pointer");
     // the shipped shape has a kernel of its own (ddpg_train_fixed.hip); SSC_DDPG_INTERPRETER=1 keeps it on the step
     // interpreter below (A/B measurements, and the tests that check both against the oracle)
-#ifndef SSC_DDPG_DIAG
     if (ddpg_fixed_shape(d)) {
         const char *force = getenv("SSC_DDPG_INTERPRETER");
         if (!(force && force[0] == '1')) return ddpg_train_fixed(d, rp, d_batch_idx, n_iters, d_losses, as_stream(stream));
     }
-#endif
 
     const NetDims A{d->obs_dim, d->actor_h1, d->actor_h2, d->act_dim, 0};
     const NetDims C{d->obs_dim, d->critic_h1, d->critic_h2, 1, d->act_dim};

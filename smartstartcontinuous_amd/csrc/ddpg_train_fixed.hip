@@ -17,15 +17,15 @@
 //     (__syncthreads() drains vmcnt every time).
 // The wide contractions (64 -> 32 forward, its transpose, its weight gradient) run on v_mfma_f32_16x16x4_f32: exact
 // fp32 products and sums.  One CU sustains 256 fp32 MFMA flop/cycle, so each 64 x 64 x 32 contraction is >= 1024
-// cycles; an iteration holds nine of them (three forward passes of the targets / online nets + two critic layers on
-// (s, pi(s)), two backward, two weight gradients): ~9.2 k cycles of matrix work, the floor of this design.
+// cycles; an iteration holds eight of them (layer 2 of the four nets -- critic(s, pi(s)) reuses the head of
+// critic(s, a) --, two backward, two weight gradients): ~8.2 k cycles of matrix work, the floor of this design.
 //
 // Levels of one iteration (B = barrier):
 //   L0  batch rows (prefetched) -> S, S2, action row; MpiAdam step sizes                                          B
 //   L1  layer 1 of all four nets (target actor / critic on s2, critic / actor on s)                               B
-//   L2  layer 2: target actor, actor, critic(s, a)                      [3 MFMA tiles per wave]                  B
+//   L2  layer 2: target actor, actor, critic(s, a) + the head of target critic layer 2  [4 MFMA tiles per wave]  B
 //   L3  output layers: target action, pi(s), Q(s, a)                    [one wave each]                           B
-//   L4  layer 2: target critic(s2, pi'(s2)), critic(s, pi(s))          [2 MFMA tiles per wave]                  B
+//   L4  layer 2: target critic(s2, pi'(s2)), critic(s, pi(s)): action rows onto the heads kept from L2          B
 //   L5  Q' -> y -> critic loss, dQ; Q(s, pi) -> actor loss; delta of critic layer 2 on the (s, pi) path           B
 //   L6  delta of critic layer 2 (TD path); d(-Q)/d(action) -> delta of the actor output                           B
 //   L7  critic layer-1 delta [MFMA]; actor layer-2 delta                                                           B
@@ -39,8 +39,9 @@ namespace {
 
 constexpr int kT = 512, kNW = kT / 64;
 constexpr int H1 = 64, H2 = 32;
-constexpr int W2S = H2 + 1;   // LDS row stride of a W2 matrix: the backward pass reads COLUMN slices of it (lane = input
-                              // row), which at stride 32 put all 16 lanes of a k group on one bank; 33 leaves 2-way
+constexpr int W2S = H2 + 4;   // LDS row stride of a W2 matrix.  The backward pass reads COLUMN slices of it (lane = input row): at
+                              // stride 32 all 16 lanes of a k group sit on one bank, at 36 they spread over 8 (2-way).  The forward
+                              // pass wants rows 4 apart to sit 16 banks apart (see fwd_item): 36 = 4 mod 32 does that too, like kP
 constexpr int al4(int x) { return (x + 3) & ~3; }
 
 // LDS image / flat layout of one net.  IN2 = rows of W2 (H1 for the actor, H1 + 1 for the critic: the action row).
@@ -69,7 +70,8 @@ struct Rows {
     static constexpr int TB2 = CA2 + H2;        // target critic layer 2;  later the critic layer-2 delta (L6)
     static constexpr int CB2 = TB2 + H2;        // critic layer 2 on (s, pi(s))
     static constexpr int PI = CB2 + H2, Q = PI + 1, DQ = Q + 1, DZ3A = DQ + 1;
-    static constexpr int total = DZ3A + 1;
+    static constexpr int LC = DZ3A + 1, LA = LC + 1;   // per-sample loss terms (summed one level later, off the critical path)
+    static constexpr int total = LA + 1;
     static constexpr int DZB2 = T1, DZ1A = T1, DZ1 = X2B, DZ2A = T2, DZ2 = TB2;
 };
 
@@ -81,28 +83,60 @@ struct FixedArgs {
     int32_t n_iters;
 };
 
+// Diagnostic build (-DSSC_DDPG_DIAG, tools/exp_ddpg_phases.py): d_losses is [n_iters][16] and receives the cycles
+// thread 0 spent in each level instead of the losses.
+#ifdef SSC_DDPG_DIAG
+#define LEVEL_MARK(k) do { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); \
+        if (tid == 0) g.losses[16 * it + (k)] = (float)(now_ - cp_prev); cp_prev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LEVEL_MARK(k) do { } while (0)
+#endif
+
 // only LDS data crosses waves: no vmcnt drain (see the header)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <bool TANH2> __device__ __forceinline__ float act2(float v) { return TANH2 ? tanh_fast(v) : fmaxf(v, 0.0f); }
 template <bool TANH2> __device__ __forceinline__ float act2_deriv(float a) { return TANH2 ? 1.0f - a * a : (a > 0.0f ? 1.0f : 0.0f); }
 
-// one 16 x 16 tile of Z = bias + W2^T X over the 64 head rows;  rows = units j0.., cols = samples b0..
-__device__ __forceinline__ f32x4m fwd_tile(const float *W2, const float *b2, const float *X, int j0, int b0, int c, int kg) {
-    f32x4m acc = *reinterpret_cast<const f32x4m *>(b2 + j0 + 4 * kg);
-    const float *wp = W2 + kg * W2S + j0 + c, *xp = X + kg * kP + b0 + c;
-    float a[H1 / 4], b[H1 / 4];
+// Two 16 x 16 tiles of Z = bias + W2^T X over the 64 head rows: units 16 jb.., samples 32 sp.. and 32 sp + 16..; the W
+// fragment is fetched once for both.  k-step s of lane group kg contracts input row k(s, kg) = 16 (s >> 2) + (s & 3)
+// + 4 kg instead of the usual 4 s + kg: a ds_read_b32 is banked (address / 4) % 32 over each 32-lane half, i.e. over the
+// lane groups kg and kg + 1 together; both operands have row strides = 4 mod 32 (kP = 68, W2S = 36), so rows FOUR apart
+// land 16 banks apart and every read is conflict-free (rows one apart overlap in 12 of 16 banks: 2-way).  The LDS, not
+// the matrix pipe, bounded these levels: 32 operand reads per 16 MFMAs at ~4 cycles each vs 32 cycles per MFMA / 4 SIMDs.
+struct TilePair { f32x4m t0, t1; };
+__device__ __forceinline__ TilePair fwd_item(const float *W2, const float *b2, const float *X, int jb, int sp, int c, int kg) {
+    TilePair acc;
+    acc.t0 = acc.t1 = *reinterpret_cast<const f32x4m *>(b2 + 16 * jb + 4 * kg);
+    const float *wp = W2 + 4 * kg * W2S + 16 * jb + c, *xp = X + 4 * kg * kP + 32 * sp + c;
 #pragma unroll
-    for (int s = 0; s < H1 / 4; ++s) { a[s] = wp[4 * s * W2S]; b[s] = xp[4 * s * kP]; }
+    for (int h = 0; h < 2; ++h) {   // two batches of 8 k-steps: 24 operand registers in flight, not 48
+        float a[H1 / 8], u0[H1 / 8], u1[H1 / 8];
 #pragma unroll
-    for (int s = 0; s < H1 / 4; ++s) acc = mfma4(a[s], b[s], acc);
+        for (int s = 0; s < H1 / 8; ++s) {
+            const int k = 32 * h + 16 * (s >> 2) + (s & 3);
+            a[s] = wp[k * W2S]; u0[s] = xp[k * kP]; u1[s] = xp[k * kP + 16];
+        }
+#pragma unroll
+        for (int s = 0; s < H1 / 8; ++s) { acc.t0 = mfma4(a[s], u0[s], acc.t0); acc.t1 = mfma4(a[s], u1[s], acc.t1); }
+    }
     return acc;
 }
 
+// + the 65th input row (critic: the action), activation, store
 template <bool TANH2>
-__device__ __forceinline__ void store_tile(float *Z, const f32x4m &acc, int j0, int b0, int c, int kg) {
+__device__ __forceinline__ void store_item(float *Z, TilePair acc, const float *w_tail, const float *x_tail, int jb, int sp, int c, int kg) {
+    if (w_tail != nullptr) {
+        const f32x4m w = *reinterpret_cast<const f32x4m *>(w_tail + 16 * jb + 4 * kg);
+        acc.t0 += w * x_tail[32 * sp + c];
+        acc.t1 += w * x_tail[32 * sp + 16 + c];
+    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Z[(j0 + 4 * kg + r) * kP + b0 + c] = act2<TANH2>(acc[r]);
+    for (int r = 0; r < 4; ++r) {
+        float *z = Z + (16 * jb + 4 * kg + r) * kP + 32 * sp + c;
+        z[0] = act2<TANH2>(acc.t0[r]);
+        z[16] = act2<TANH2>(acc.t1[r]);
+    }
 }
 
 // dX[i][b] = relu'(A[i][b]) sum_j W2[i][j] dZ[j][b] for input rows 16 ib.. and the sample tiles 2 sp, 2 sp + 1
@@ -124,15 +158,19 @@ __device__ __forceinline__ void bwd_item(const float *W2, const float *dZ, const
     }
 }
 
-// dW[i][j] = sum_b X[i][b] dZ[j][b] for rows 16 ib.., units 16 jb..;  lane holds (i = 16 ib + 4 kg + r, j = 16 jb + c)
+// dW[i][j] = sum_b X[i][b] dZ[j][b] for rows 16 ib.., units 16 jb..;  lane holds (i = 16 ib + 4 kg + r, j = 16 jb + c).
+// The contraction index (the sample) is the contiguous one in both operands: lane group kg takes samples 16 q + 4 kg ..
+// + 3 as FOUR k-steps from one ds_read_b128 per operand -- 8 reads per tile instead of 32.
 __device__ __forceinline__ f32x4m wgrad_tile(const float *X, const float *dZ, int ib, int jb, int c, int kg) {
-    const float *xp = X + (16 * ib + c) * kP + kg, *zp = dZ + (16 * jb + c) * kP + kg;
-    float a[kB / 4], b[kB / 4];
+    const float *xp = X + (16 * ib + c) * kP + 4 * kg, *zp = dZ + (16 * jb + c) * kP + 4 * kg;
+    f4 a[kB / 16], b[kB / 16];
 #pragma unroll
-    for (int s = 0; s < kB / 4; ++s) { a[s] = xp[4 * s]; b[s] = zp[4 * s]; }
+    for (int q = 0; q < kB / 16; ++q) { a[q] = *reinterpret_cast<const f4 *>(xp + 16 * q); b[q] = *reinterpret_cast<const f4 *>(zp + 16 * q); }
     f32x4m acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int s = 0; s < kB / 4; ++s) acc = mfma4(a[s], b[s], acc);
+    for (int q = 0; q < kB / 16; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma4(a[q][e], b[q][e], acc);
     return acc;
 }
 
@@ -157,13 +195,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // MpiAdam.update on one element (baselines common/mpi_adam.py [third-party], ddpg_editted.py:326-327), then
-// update_target_net on the same element (:338-339).  theta / target in LDS, moments in registers.
-__device__ __forceinline__ void adam_target(float *theta, float *target, int idx, float &m, float &v, float g, const AdamCfg &c, float tau) {
+// update_target_net on the same element (:338-339).  th / tg: the old values of theta and target (read by the caller,
+// all of a lane's elements at once: one LDS round trip, not one per element); moments in registers.
+__device__ __forceinline__ void adam_target(float &th, float &tg, float &m, float &v, float g, const AdamCfg &c, float tau) {
     m = c.beta1 * m + (1.0f - c.beta1) * g;
     v = c.beta2 * v + (1.0f - c.beta2) * (g * g);
-    const float th = theta[idx] + (-c.a) * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + c.eps);
-    theta[idx] = th;
-    target[idx] = (1.0f - tau) * target[idx] + tau * th;
+    th += (-c.a) * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + c.eps);   // 1-ulp sqrt / rcp: a 1e-7 relative wobble
+    tg = (1.0f - tau) * tg + tau * th;                                              // of a 1e-3-sized step
+}
+
+// the four elements (i = 16 ib + 4 kg + r, j = 16 jb + c) of a weight-gradient tile
+__device__ __forceinline__ void adam_tile(float *theta, float *target, int base, const f32x4m &g, float (&m)[4], float (&v)[4],
+                                          const AdamCfg &c, float tau) {
+    float th[4], tg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { th[r] = theta[base + r * W2S]; tg[r] = target[base + r * W2S]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) adam_target(th[r], tg[r], m[r], v[r], g[r], c, tau);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { theta[base + r * W2S] = th[r]; target[base + r * W2S] = tg[r]; }
 }
 
 // One "small" parameter element: its gradient is a 64-sample dot product of two LDS rows (or the sum of one).
@@ -195,7 +245,7 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
     __shared__ float red[2];
     __shared__ AdamCfg cfg_s[2];
     const ssc_ddpg_desc &d = g.d;
-    const int tid = threadIdx.x, wave = tid >> 6, b = tid & 63, c = tid & 15, kg = (tid >> 4) & 3;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), b = tid & 63, c = tid & 15, kg = (tid >> 4) & 3;
     float *const act = lds;                                   // activation rows
     float *const th_a = lds + R::total * kP;                  // parameter images
     float *const th_c = th_a + NA::size;
@@ -268,6 +318,9 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
 
     float r_cur = 0.0f, t_cur = 0.0f;
     for (int it = 0; it < g.n_iters; ++it) {
+#ifdef SSC_DDPG_DIAG
+        uint64_t cp_prev = __builtin_amdgcn_s_memtime();
+#endif
         // ---- L0: ReplayBuffer.sample_batch rows; MpiAdam step sizes --------------------------------------------------
         ++tA; ++tC;
         b1a *= (double)d.beta1; b2a *= (double)d.beta2; b1c *= (double)d.beta1; b2c *= (double)d.beta2;
@@ -288,62 +341,72 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
             rec_next = idx_of(it + 2);
         }
         lds_barrier();
+        LEVEL_MARK(0);
 
         // ---- L1: layer 1 of the four nets; wave -> units 8 wave .., lane = sample ----------------------------------
         {
             float xs[O], x2[O];
 #pragma unroll
             for (int k = 0; k < O; ++k) { xs[k] = row(R::S + k)[b]; x2[k] = row(R::S2 + k)[b]; }
-            auto layer1 = [&](const float *img, const float *x, float *Z) {   // W1 / b1 sit at the same offsets in both nets
-                f4 a0 = *reinterpret_cast<const f4 *>(img + NA::b1 + 8 * wave), a1 = *reinterpret_cast<const f4 *>(img + NA::b1 + 8 * wave + 4);
+            // every weight of the four layers is requested before the first FMA: written net by net, each net waited for
+            // its own LDS round trip (4 x ~300 cycles for ~100 FMAs)
+            const float *const img[4] = {th_ta, th_tc, th_c, th_a};   // W1 / b1 sit at the same offsets in both kinds of net
+            float *const Z[4] = {row(R::T1), row(R::X2B), row(R::X2), row(R::U1)};
+            f4 w[4][O + 1][2];
 #pragma unroll
-                for (int k = 0; k < O; ++k) {
-                    a0 += *reinterpret_cast<const f4 *>(img + NA::W1 + k * H1 + 8 * wave) * x[k];
-                    a1 += *reinterpret_cast<const f4 *>(img + NA::W1 + k * H1 + 8 * wave + 4) * x[k];
-                }
+            for (int n = 0; n < 4; ++n) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    Z[(8 * wave + e) * kP + b] = fmaxf(a0[e], 0.0f);
-                    Z[(8 * wave + 4 + e) * kP + b] = fmaxf(a1[e], 0.0f);
+                for (int h = 0; h < 2; ++h) {
+                    w[n][O][h] = *reinterpret_cast<const f4 *>(img[n] + NA::b1 + 8 * wave + 4 * h);
+#pragma unroll
+                    for (int k = 0; k < O; ++k) w[n][k][h] = *reinterpret_cast<const f4 *>(img[n] + NA::W1 + k * H1 + 8 * wave + 4 * h);
                 }
-            };
-            layer1(th_ta, x2, row(R::T1));
-            layer1(th_tc, x2, row(R::X2B));
-            layer1(th_c, xs, row(R::X2));
-            layer1(th_a, xs, row(R::U1));
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const float *x = n < 2 ? x2 : xs;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f4 a = w[n][O][h];
+#pragma unroll
+                    for (int k = 0; k < O; ++k) a += w[n][k][h] * x[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Z[n][(8 * wave + 4 * h + e) * kP + b] = fmaxf(a[e], 0.0f);
+                }
+            }
         }
         lds_barrier();
+        LEVEL_MARK(1);
 
-        // ---- L2: layer 2 of target actor, actor, critic(s, a); wave -> tile (units 16 (wave >> 2).., samples 16 (wave & 3)..)
+        // ---- L2: layer 2 of target actor, actor, critic(s, a) -- and the 64 head rows of target critic layer 2, whose
+        //      65th input (the target action) is the only part that has to wait for L3.  critic(s, pi(s)) in L4 shares
+        //      its head with critic(s, a): same weights, same relu(layer 1) rows.
+        //      wave -> (units 16 jb.., samples 32 sp..) of TWO nets: waves 0-3 target actor + the shared critic head,
+        //      waves 4-7 actor + target critic head; the critic accumulators stay in registers until L4.
+        const int jb = (wave >> 1) & 1, sp = wave & 1;
+        const bool lo = wave < 4;
+        const float *const img1 = lo ? th_ta : th_a, *const img2 = lo ? th_c : th_tc;
+        TilePair keep;
         {
-            const int j0 = 16 * (wave >> 2), b0 = 16 * (wave & 3);
-            f32x4m t2 = fwd_tile(th_ta + NA::W2, th_ta + NA::b2, row(R::T1), j0, b0, c, kg);
-            f32x4m u2 = fwd_tile(th_a + NA::W2, th_a + NA::b2, row(R::U1), j0, b0, c, kg);
-            f32x4m c2 = fwd_tile(th_c + NC::W2, th_c + NC::b2, row(R::X2), j0, b0, c, kg);
-            c2 += *reinterpret_cast<const f32x4m *>(th_c + NC::W2 + H1 * W2S + j0 + 4 * kg) * row(R::X2 + H1)[b0 + c];   // the action row
-            store_tile<TANH2>(row(R::T2), t2, j0, b0, c, kg);
-            store_tile<TANH2>(row(R::U2), u2, j0, b0, c, kg);
-            store_tile<TANH2>(row(R::CA2), c2, j0, b0, c, kg);
+            const TilePair first = fwd_item(img1 + NA::W2, img1 + NA::b2, lo ? row(R::T1) : row(R::U1), jb, sp, c, kg);
+            keep = fwd_item(img2 + NC::W2, img2 + NC::b2, lo ? row(R::X2) : row(R::X2B), jb, sp, c, kg);
+            store_item<TANH2>(lo ? row(R::T2) : row(R::U2), first, nullptr, nullptr, jb, sp, c, kg);
+            if (lo) store_item<TANH2>(row(R::CA2), keep, th_c + NC::W2 + H1 * W2S, row(R::X2 + H1), jb, sp, c, kg);   // + the action row
         }
         lds_barrier();
+        LEVEL_MARK(2);
 
         // ---- L3: the three output layers, one wave each ------------------------------------------------------------
         if (wave == 0) row(R::X2B + H1)[b] = tanh_fast(dot32(th_ta + NA::W3, th_ta + NA::b3, row(R::T2), b));   // pi'(s2)  (:132)
         else if (wave == 1) row(R::PI)[b] = tanh_fast(dot32(th_a + NA::W3, th_a + NA::b3, row(R::U2), b));       // pi(s)    (:127)
         else if (wave == 2) row(R::Q)[b] = dot32(th_c + NC::W3, th_c + NC::b3, row(R::CA2), b);                  // Q(s, a)  (:181)
         lds_barrier();
+        LEVEL_MARK(3);
 
-        // ---- L4: layer 2 of target critic(s2, pi'(s2)) and critic(s, pi(s)) ----------------------------------------
-        {
-            const int j0 = 16 * (wave >> 2), b0 = 16 * (wave & 3);
-            f32x4m tb = fwd_tile(th_tc + NC::W2, th_tc + NC::b2, row(R::X2B), j0, b0, c, kg);
-            f32x4m cb = fwd_tile(th_c + NC::W2, th_c + NC::b2, row(R::X2), j0, b0, c, kg);
-            tb += *reinterpret_cast<const f32x4m *>(th_tc + NC::W2 + H1 * W2S + j0 + 4 * kg) * row(R::X2B + H1)[b0 + c];
-            cb += *reinterpret_cast<const f32x4m *>(th_c + NC::W2 + H1 * W2S + j0 + 4 * kg) * row(R::PI)[b0 + c];
-            store_tile<TANH2>(row(R::TB2), tb, j0, b0, c, kg);
-            store_tile<TANH2>(row(R::CB2), cb, j0, b0, c, kg);
-        }
+        // ---- L4: layer 2 of target critic(s2, pi'(s2)) and critic(s, pi(s)): the action rows onto the heads of L2 ----
+        store_item<TANH2>(lo ? row(R::CB2) : row(R::TB2), keep, img2 + NC::W2 + H1 * W2S, lo ? row(R::PI) : row(R::X2B + H1), jb, sp, c, kg);
         lds_barrier();
+        LEVEL_MARK(4);
 
         // ---- L5 -------------------------------------------------------------------------------------------------------
         if (wave == 0) {          // target_Q = r + (1 - terminal) gamma Q'(s2, pi'(s2))  (:132-133); critic loss = mean((Q - y)^2)  (:181)
@@ -351,11 +414,9 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
             const float y = r_cur + (1.0f - t_cur) * d.gamma * qt;
             const float e = row(R::Q)[b] - y;
             row(R::DQ)[b] = 2.0f * e / (float)kB;
-            const float s = wave_sum(e * e);
-            if (b == 0) red[0] = s;
+            row(R::LC)[b] = e * e;
         } else if (wave == 1) {   // actor loss = -mean Q(s, pi(s))  (:168)
-            const float s = wave_sum(-dot32(th_c + NC::W3, th_c + NC::b3, row(R::CB2), b));
-            if (b == 0) red[1] = s;
+            row(R::LA)[b] = -dot32(th_c + NC::W3, th_c + NC::b3, row(R::CB2), b);
         } else {                  // (s, pi) path: dq = -1/B, delta of critic layer 2 = W3 dq act2'(.)
             for (int e = tid - 2 * 64; e < H2 * kB; e += kT - 2 * 64) {
                 const int o = (e >> 6) * kP + (e & 63);
@@ -363,12 +424,17 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
             }
         }
         lds_barrier();
+        LEVEL_MARK(5);
 
         // ---- L6: TD path delta of critic layer 2; d(-Q)/d(action) through the output tanh ---------------------------
 #pragma unroll
         for (int q = 0; q < H2 * kB / kT; ++q) {
             const int e = tid + kT * q, o = (e >> 6) * kP + (e & 63);
             row(R::DZ2)[o] = th_c[NC::W3 + (e >> 6)] * row(R::DQ)[e & 63] * act2_deriv<TANH2>(row(R::CA2)[o]);
+        }
+        if (wave == 1 || wave == 2) {   // the loss sums: six dependent cross-lane steps each, on waves with nothing else to do here
+            const float sum = wave_sum(row(wave == 1 ? R::LC : R::LA)[b]);
+            if (b == 0) red[wave - 1] = sum;
         }
         if (wave == kNW - 1) {
             float da0 = 0.0f, da1 = 0.0f;
@@ -381,6 +447,7 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
             row(R::DZ3A)[b] = (da0 + da1) * (1.0f - p * p);
         }
         lds_barrier();
+        LEVEL_MARK(6);
 
         // ---- L7: critic layer-1 delta (MFMA: wave -> 16 input rows x 32 samples); actor layer-2 delta ------------------
         bwd_item(th_c + NC::W2, row(R::DZ2), row(R::X2), row(R::DZ1), wave >> 1, wave & 1, c, kg);
@@ -390,33 +457,46 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
             row(R::DZ2A)[o] = th_a[NA::W3 + (e >> 6)] * row(R::DZ3A)[e & 63] * act2_deriv<TANH2>(row(R::U2)[o]);
         }
         lds_barrier();
+        LEVEL_MARK(7);
 
         // ---- L8: actor layer-1 delta; critic gradients -> MpiAdam -> target critic -----------------------------------
         bwd_item(th_a + NA::W2, row(R::DZ2A), row(R::U1), row(R::DZ1A), wave >> 1, wave & 1, c, kg);
+        LEVEL_MARK(10);
         {
             const AdamCfg cc = cfg_s[1];
             const f32x4m gw = wgrad_tile(row(R::X2), row(R::DZ2), w_ib, w_jb, c, kg);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                adam_target(th_c, th_tc, NC::W2 + (16 * w_ib + 4 * kg + r) * W2S + 16 * w_jb + c, mW2c[r], vW2c[r], gw[r], cc, d.tau);
-            if (ec.on) adam_target(th_c, th_tc, ec.lidx, mc, vc, small_grad(lds, ec), cc, d.tau);
+            LEVEL_MARK(11);
+            adam_tile(th_c, th_tc, NC::W2 + (16 * w_ib + 4 * kg) * W2S + 16 * w_jb + c, gw, mW2c, vW2c, cc, d.tau);
+            LEVEL_MARK(12);
+            if (ec.on) {
+                float th = th_c[ec.lidx], tg = th_tc[ec.lidx];
+                adam_target(th, tg, mc, vc, small_grad(lds, ec), cc, d.tau);
+                th_c[ec.lidx] = th; th_tc[ec.lidx] = tg;
+            }
         }
+        LEVEL_MARK(13);
         lds_barrier();
+        LEVEL_MARK(8);
 
         // ---- L9: actor gradients -> MpiAdam -> target actor; losses ------------------------------------------------------
         {
             const AdamCfg ca = cfg_s[0];
             const f32x4m gw = wgrad_tile(row(R::U1), row(R::DZ2A), w_ib, w_jb, c, kg);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                adam_target(th_a, th_ta, NA::W2 + (16 * w_ib + 4 * kg + r) * W2S + 16 * w_jb + c, mW2a[r], vW2a[r], gw[r], ca, d.tau);
-            if (ea.on) adam_target(th_a, th_ta, ea.lidx, ma, va, small_grad(lds, ea), ca, d.tau);
+            adam_tile(th_a, th_ta, NA::W2 + (16 * w_ib + 4 * kg) * W2S + 16 * w_jb + c, gw, mW2a, vW2a, ca, d.tau);
+            if (ea.on) {
+                float th = th_a[ea.lidx], tg = th_ta[ea.lidx];
+                adam_target(th, tg, ma, va, small_grad(lds, ea), ca, d.tau);
+                th_a[ea.lidx] = th; th_ta[ea.lidx] = tg;
+            }
         }
+#ifndef SSC_DDPG_DIAG
         if (tid == 0 && g.losses != nullptr) {
             g.losses[2 * it + 0] = red[0] / (float)kB;
             g.losses[2 * it + 1] = red[1] / (float)kB;
         }
+#endif
         lds_barrier();
+        LEVEL_MARK(9);
     }
 
     // the forward kernels outside (ssc_actor_forward, ssc_critic_forward, rollouts) read the global arrays
