@@ -76,7 +76,7 @@ class ActorPolicy:
 class MpcPolicy:
     """The SmartStart navigator as a rollout policy (NND_MB_agent.get_action, NND_MB_agent.py:339-358):
     ``navigators`` is a :class:`smartstartcontinuous_amd.navigator.NavigatorBatch` with one problem per env.
-    Unlike RANDOM / ACTOR this policy is a chain of launches per step -- sample, forward sim, score (2), and one
+    Unlike RANDOM / ACTOR this policy is a chain of launches per step -- forward sim (drawing its own candidates), score (2), and one
     fused launch for action / env step / log / statistics / waypoint advance / auto-reset -- whose step index and
     log row are device counters: the chain is captured once as a HIP graph and replayed K times per chunk
     (``graph=False``: the step-by-step reference path through the single-purpose entry points)."""

@@ -33,13 +33,14 @@ if interp:
                 "fwd c3(s,pi) + aloss + dq", "bwd c3 (pi)", "bwd c2->da", "bwd a3", "bwd a2",
                 "losses+adam cfg", "wgrad c1", "wgrad c2", "wgrad c3", "wgrad a1", "wgrad a2", "wgrad a3", "target update"])
 else:
-    names = ["L0 gather + adam cfg", "L1 layer 1 x4", "L2 layer 2 x3 (MFMA)", "L3 output layers x3", "L4 layer 2 x2 (MFMA)",
-             "L5 y, losses, dzb2", "L6 dz2, d action", "L7 bwd c2 (MFMA), dz2a", "L8 bwd a2 + critic grads/Adam (MFMA)",
+    names = ["L0 gather + adam cfg", "L1 layer 1 x4", "L2 layer 2: 4 contractions (MFMA)", "L3 output layers x3", "L4 action rows onto the critic heads",
+             "L5 y, loss terms, dzb2", "L6 dz2, d action, loss sums", "L7 bwd c2 (MFMA), dz2a", "L8 bwd a2 + critic grads/Adam (MFMA)",
              "L9 actor grads/Adam (MFMA)"]
+    m[8] = m[8] + m[10] + m[11] + m[12] + m[13]     # L8 carries marks of its own (10..13) in front of its barrier mark
 for k, nme in enumerate(names):
     print("%2d %-40s %7.0f cycles" % (k, nme, m[k]))
 print("total %.0f cycles per iteration" % m[:len(names)].sum())
 if interp:
     print("marks of step %s (cycles since step start): %s" % (os.environ.get("SSC_DIAG_STEP_NAME", "10"), " ".join("%.0f" % x for x in m[32:40])))
 if not interp:
-    print("inside L8 (thread 0): bwd a2 %.0f | wgrad c2 tile %.0f | Adam x4 %.0f | small element %.0f | barrier wait %.0f" % tuple(m[[10, 11, 12, 13, 8]]))
+    print("inside L8 (thread 0): bwd a2 %.0f | wgrad c2 tile %.0f | Adam x4 %.0f | small element %.0f (each incl. ~150 cycles of mark overhead)" % tuple(m[[10, 11, 12, 13]]))

@@ -6,7 +6,7 @@ import smartstartcontinuous_amd as ssc
 from smartstartcontinuous_amd import navigator as nav
 from smartstartcontinuous_amd.agents import init_dynamics_weights
 
-def run(P, N, H, depth, K=20):
+def run(P, N, H, depth, K=400):
     rng = np.random.default_rng(0)
     Ws, bs = init_dynamics_weights(3, 2, 2 if depth >= 100 else 1, depth, torch.Generator().manual_seed(1))
     norm = dict(mean_x=[-0.5, 0.0], std_x=[0.2, 0.02], mean_y=[0.0], std_y=[0.6], mean_z=[0.0, 0.0], std_z=[0.01, 0.002])
