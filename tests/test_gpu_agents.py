@@ -440,6 +440,50 @@ def test_ddpg_training_reduces_critic_loss(ssc):
     assert losses[-50:, 0].mean() < 0.2 * losses[:20, 0].mean()
 
 
+@pytest.mark.parametrize("obs_dim", [2, 3])
+def test_ddpg_fixed_kernel_tracks_interpreter_over_launches(ssc, obs_dim, monkeypatch):
+    """The shape-specialised learner (ddpg_train_fixed.hip: Adam moments in registers, target update fused, padded LDS
+    weight image) against the step interpreter over 3 launches x 100 iterations from the same start: parameters,
+    targets, moments and step counters must survive the launch boundary through the global arrays, and the two fp32
+    summation orders may not drift apart (both are within 5e-6 of the fp64 oracle after 6 steps; here 300)."""
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    rng = np.random.default_rng(4)
+    env = ssc.make("MountainCarContinuous-v0") if obs_dim == 2 else _BoxEnv(obs_dim)
+    cap, B = 2000, 64
+    s = rng.uniform(-1.0, 1.0, (cap, obs_dim)).astype(np.float32)
+    a = rng.uniform(-1, 1, (cap, 1)).astype(np.float32)
+    r = (rng.normal(size=cap) * 0.5).astype(np.float32)
+    t = (rng.random(cap) < 0.1)
+    s2 = (s + rng.normal(size=(cap, obs_dim)) * 0.02).astype(np.float32)
+    dev = lambda x, dt: torch.as_tensor(x, dtype=dt, device="cuda").contiguous()
+    data = (dev(s, torch.float32), dev(a, torch.float32), dev(r, torch.float32), dev(t, torch.uint8), dev(s2, torch.float32))
+    idx = [dev(np.stack([rng.permutation(cap)[:B] for _ in range(100)]).astype(np.int32), torch.int32) for _ in range(3)]
+    out = {}
+    for mode in ("fixed", "interpreter"):
+        if mode == "interpreter":
+            monkeypatch.setenv("SSC_DDPG_INTERPRETER", "1")
+        else:
+            monkeypatch.delenv("SSC_DDPG_INTERPRETER", raising=False)
+        agent = DDPG_Baselines_agent(env, None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32, lastLayerTanh=True,
+                                     actor_lr=1e-3, critic_lr=1e-3, gamma=0.99, tau=0.01, batch_size=64, seed=9, training=False)
+        losses = [agent.train_on(*data, ix, 100).cpu().numpy() for ix in idx]
+        torch.cuda.synchronize()
+        out[mode] = dict(actor=agent.actor_flat.cpu().numpy(), critic=agent.critic_flat.cpu().numpy(),
+                         ta=agent.target_actor_flat.cpu().numpy(), tc=agent.target_critic_flat.cpu().numpy(),
+                         m=agent._adam_critic[0].cpu().numpy(), v=agent._adam_actor[1].cpu().numpy(),
+                         t=agent._adam_t.cpu().tolist(), losses=np.concatenate(losses))
+    f, g = out["fixed"], out["interpreter"]
+    assert f["t"] == g["t"] == [300, 300]
+    assert np.isfinite(f["losses"]).all()
+    # Adam normalises the step: an element whose gradient is rounding noise moves by +-lr per step whatever the size of
+    # the gradient, so a handful of elements may differ by a few steps' worth; everything else agrees to fp32 rounding
+    for k in ("actor", "critic", "ta", "tc"):
+        diff = np.abs(f[k] - g[k])
+        assert np.quantile(diff, 0.99) <= 2e-5 and diff.max() <= 3e-3, (k, np.quantile(diff, 0.99), diff.max())
+    assert np.allclose(f["losses"], g["losses"], rtol=2e-3, atol=1e-5)
+    assert np.allclose(f["m"], g["m"], rtol=5e-2, atol=1e-6) and np.allclose(f["v"], g["v"], rtol=5e-2, atol=1e-9)
+
+
 def test_device_replay_ring_matches_oracle(ssc):
     """ssc_replay_append / ssc_replay_sample against the restatement: ring contents bit-exact (wrap-around,
     chunk larger than the ring, last_steps), indices bit-exact."""
