@@ -13,6 +13,19 @@ src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+# settled launches of the dominant kernel from the full trace (kernel_stats.csv averages every launch of the run, the
+# post-idle transient and the settling phase included)
+for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv")):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    by = collections.defaultdict(list)
+    for r in rows:
+        by[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    name, d = max(by.items(), key=lambda kv: sum(kv[1]))
+    tail = sorted(d[len(d) * 3 // 4:])
+    json.dump({"kernel": name, "launches": len(d), "mean_us_all": sum(d) / len(d),
+               "last_quarter": {"n": len(tail), "mean_us": sum(tail) / len(tail), "median_us": tail[len(tail) // 2],
+                                "min_us": tail[0], "p90_us": tail[int(0.9 * len(tail))]}},
+              open(os.path.join(dst, "kernel_trace_settled.json"), "w"), indent=1)
 pmc = {}
 for tagdir in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(tagdir):
