@@ -245,6 +245,7 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
     ring as well, so that ``smartstart.device_smart_start_path(replay, agent, radii, n_ss)`` can pick a smart-start
     state and recover the path to it without the replay contents leaving HBM.
     Returns (Summary, losses per chunk, replay)."""
+    import torch
     from .replay_buffer import DeviceReplayBuffer
     from .vec_env import EpisodeRing, TransitionChunk
     summary = Summary("vec_ddpg_" + env.spec.id)
@@ -254,14 +255,20 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
                                 n_envs=env.n, max_path_len=(env.spec.max_episode_steps or 1000) + 1)
     losses = []
     generations = 0.0   # finished episodes / env.n: epsilon decays once per episode PER ENV (DDPG_Baselines_agent.py:255-258)
+    side = torch.cuda.Stream(env.device)                 # episode-record readback, off the learner's stream
+    rolled = torch.cuda.Event()
     for _ in range(num_chunks):
         pd = env.policy_desc(agent.as_policy())          # weights are views into the flat parameter arrays
         out = env.rollout(chunk_steps, out=chunk, ring=ring, policy_desc=pd)
+        rolled.record()
         replay.append_chunk(out, reward_scale=agent.reward_scale, last_steps=replay_last_steps)
         l = agent.train_from(replay, train_iters)
         if l is not None:
             losses.append(l)
-        (ids, lens, rets), _d = ring.drain()
+        # the host needs the finished episodes of THIS chunk before it can launch the next one (epsilon decay); it waits
+        # for the rollout only -- append + learner iterations are already queued and run while the records are read
+        (ids, lens, rets), _d, drained = ring.drain_overlapped(side, rolled)
+        torch.cuda.current_stream(env.device).wait_event(drained)
         summary.extend_records(lens, rets)
         generations += len(lens) / float(env.n)
         while generations >= 1.0:

@@ -172,9 +172,25 @@ class EpisodeRing:
         Returns also the number of dropped records."""
         n = int(self.cursor.item()) & 0xFFFFFFFF
         kept = min(n, self.capacity)
+        if kept == 0:      # (a device -> host copy call costs ~50 us of host time even for zero bytes)
+            return (np.empty(0, np.int64), np.empty(0, np.int32), np.empty(0, np.float32)), n
         out = (self.env_id[:kept].cpu().numpy(), self.length[:kept].cpu().numpy(), self.ret[:kept].cpu().numpy())
         self.cursor.zero_()
         return out, n - kept
+
+    def drain_overlapped(self, side, ready):
+        """drain() that waits for ``ready`` only (an event recorded right behind the rollout that filled the ring)
+        instead of for everything the caller has enqueued since: the readback and the cursor reset run on the stream
+        ``side``, so the learner iterations queued behind the rollout keep the GPU busy while the host reads the episode
+        records.  -> (records, dropped, done_event); the stream that launches the next rollout must wait for
+        ``done_event`` (the ring is written again by that rollout)."""
+        if getattr(self, "_drained", None) is None:
+            self._drained = torch.cuda.Event()     # reused: creating a HIP event per chunk costs tens of microseconds
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            out, dropped = self.drain()
+            self._drained.record(side)
+        return out, dropped, self._drained
 
 
 class VecEnv:

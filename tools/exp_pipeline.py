@@ -13,7 +13,7 @@ for n_envs, chunk, iters in [(65536, 256, 50), (65536, 256, 500), (4096, 64, 50)
                                  actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32, lastLayerTanh=True, seed=3)
     ssc.rl_train_vec_ddpg(env, agent, num_chunks=2, chunk_steps=chunk, replay_capacity=1 << 20, replay_last_steps=16)
     torch.cuda.synchronize()
-    n_chunks = 10
+    n_chunks = 40
     t0 = time.perf_counter()
     summary, losses, replay = ssc.rl_train_vec_ddpg(env, agent, num_chunks=n_chunks, chunk_steps=chunk,
                                                     replay_capacity=1 << 20, replay_last_steps=16)
