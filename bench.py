@@ -305,6 +305,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=N_ENVS_PER_GPU)
     ap.add_argument("--chunk", type=int, default=CHUNK)
     ap.add_argument("--gather", choices=["bounded", "full", "none"], default="bounded")
+    ap.add_argument("--gather-every", type=int, default=4,
+                    help="N > 1: exchange the newest transitions every M-th chunk (M x as many steps per message: the "
+                         "same records per second in fewer, larger RCCL messages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the gather path even at world size 1 "
@@ -374,8 +377,15 @@ def main():
     pd = env.policy_desc(RandomPolicy())
     gather = None
     if use_dist and args.gather != "none":
-        g_steps = K if args.gather == "full" else max(1, min(K, GATHER_RECORDS // (n * world)))
+        # bounded gather: the learner ingests GATHER_RECORDS records per chunk on average.  They travel as ONE message
+        # every --gather-every chunks (the last M * G steps of that chunk): an exchange costs the rollout stream ~35 us
+        # of queue time whatever its size (event packets + the side stream's launches, tools/exp_gather_timeline.py),
+        # so fewer, larger messages -- same records per second -- keep that off the per-chunk critical path
+        M = max(1, args.gather_every)
+        g_steps = K if args.gather == "full" else max(1, min(K, M * max(1, GATHER_RECORDS // (n * world))))
         gather = TransitionGather(env.obs_dim, g_steps, n, world, rank, dev)
+
+    gather_every = max(1, args.gather_every) if args.gather != "full" else 1
 
     def barrier():
         torch.cuda.synchronize()
@@ -392,7 +402,7 @@ def main():
         env.rollout(K, out=chunk, policy_desc=pd)
         if events is not None:
             events[1].record()
-        if gather is not None:
+        if gather is not None and (i + 1) % gather_every == 0:
             gather.submit(chunk, i & 1, env.stats)
 
     series = [] if args.series_out else None     # diagnostic: (phase, event pair) of EVERY launch
@@ -438,6 +448,10 @@ def main():
     barrier()
     per_launch = [a.elapsed_time(b) for a, b in evs]
     steps_done = warm_total + 2 * args.steps
+    if gather is not None:          # one last exchange (untimed), so that the statistics check below sees every step
+        gather.submit(chunks[(steps_done - 1) & 1], (steps_done - 1) & 1, env.stats)
+        gather.finish()
+        barrier()
 
     # Steady-state leg (outside the timed region, N = 1): the launches of a short timed window start from an idle
     # power state and slow down as the chip settles; `steady` is the distribution over
@@ -497,7 +511,8 @@ def main():
                 "parallelism": "env-sharded x%d" % world,
                 "gather": (args.gather if use_dist else "none"),
                 "backend": (("rccl" if args.backend == "nccl" else "gloo (host-staged rehearsal)") if use_dist else "none"),
-                "gather_steps_per_chunk": (gather.g_steps if gather is not None else 0),
+                "gather_steps_per_message": (gather.g_steps if gather is not None else 0),
+                "gather_every_chunks": (gather_every if gather is not None else 0),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
