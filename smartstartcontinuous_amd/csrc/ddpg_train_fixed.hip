@@ -22,7 +22,7 @@
 //
 // Levels of one iteration (B = barrier):
 //   L0  batch rows (prefetched) -> S, S2, action row; MpiAdam step sizes                                          B
-//   L1  layer 1 of all four nets (target actor / critic on s2, critic / actor on s)                               B
+//   L1  layer 1 of all four nets (target actor / critic on s2, critic / actor on s)  [one MFMA k-step per tile]   B
 //   L2  layer 2: target actor, actor, critic(s, a) + the head of target critic layer 2  [4 MFMA tiles per wave]  B
 //   L3  output layers: target action, pi(s), Q(s, a)                    [one wave each]                           B
 //   L4  layer 2: target critic(s2, pi'(s2)), critic(s, pi(s)): action rows onto the heads kept from L2          B
@@ -343,35 +343,38 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
         lds_barrier();
         LEVEL_MARK(0);
 
-        // ---- L1: layer 1 of the four nets; wave -> units 8 wave .., lane = sample ----------------------------------
+        // ---- L1: layer 1 of the four nets, ONE k-step of the fp32 MFMA per 16 x 16 tile: k = the O inputs, then the bias
+        //      against a constant 1 (b1 follows W1 in the image, so A[k][unit] = img[64 k + unit] for k <= O), zeros above.
+        //      Lane = sample with broadcast float4 weight reads was LDS-bound: 24 ds_read_b128 per lane -- a broadcast still
+        //      takes its four LDS cycles -- against 8 ds_read_b32 now.  wave -> units 16 (wave >> 1).., samples 32 (wave & 1)..
         {
-            float xs[O], x2[O];
+            static_assert(O + 1 <= 4, "inputs + bias fit one k-step");
+            const int j1 = 16 * (wave >> 1), s1 = 32 * (wave & 1);
+            const float one = (kg == O) ? 1.0f : 0.0f;
+            float xb[2][2];     // [s2 / s][sample tile]: B[k][sample] = input k, 1 for k = O, 0 above
 #pragma unroll
-            for (int k = 0; k < O; ++k) { xs[k] = row(R::S + k)[b]; x2[k] = row(R::S2 + k)[b]; }
-            // every weight of the four layers is requested before the first FMA: written net by net, each net waited for
-            // its own LDS round trip (4 x ~300 cycles for ~100 FMAs)
+            for (int q = 0; q < 2; ++q) {
+                const float *X = row(q == 0 ? R::S2 : R::S) + (kg < O ? kg : 0) * kP + s1 + c;
+                xb[q][0] = kg < O ? X[0] : one;
+                xb[q][1] = kg < O ? X[16] : one;
+            }
             const float *const img[4] = {th_ta, th_tc, th_c, th_a};   // W1 / b1 sit at the same offsets in both kinds of net
             float *const Z[4] = {row(R::T1), row(R::X2B), row(R::X2), row(R::U1)};
-            f4 w[4][O + 1][2];
+            float wa[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    w[n][O][h] = *reinterpret_cast<const f4 *>(img[n] + NA::b1 + 8 * wave + 4 * h);
-#pragma unroll
-                    for (int k = 0; k < O; ++k) w[n][k][h] = *reinterpret_cast<const f4 *>(img[n] + NA::W1 + k * H1 + 8 * wave + 4 * h);
-                }
+                const float v = img[n][NA::W1 + (kg <= O ? kg : 0) * H1 + j1 + c];
+                wa[n] = kg <= O ? v : 0.0f;
             }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const float *x = n < 2 ? x2 : xs;
+                const f32x4m zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                const f32x4m d0 = mfma4(wa[n], xb[n < 2 ? 0 : 1][0], zero), d1 = mfma4(wa[n], xb[n < 2 ? 0 : 1][1], zero);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    f4 a = w[n][O][h];
-#pragma unroll
-                    for (int k = 0; k < O; ++k) a += w[n][k][h] * x[k];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Z[n][(8 * wave + 4 * h + e) * kP + b] = fmaxf(a[e], 0.0f);
+                for (int r = 0; r < 4; ++r) {
+                    float *z = Z[n] + (j1 + 4 * kg + r) * kP + s1 + c;
+                    z[0] = fmaxf(d0[r], 0.0f);
+                    z[16] = fmaxf(d1[r], 0.0f);
                 }
             }
         }
