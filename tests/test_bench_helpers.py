@@ -1,0 +1,48 @@
+"""bench.py's bookkeeping (CPU): launch-time statistics, the source stamp of the PMC traffic figure and its staleness
+rule -- the parts of the measurement contract that do not need a GPU."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import bench
+
+
+def test_dist_stats():
+    s = bench.dist_stats([0.3, 0.1, 0.2, 0.5, 0.4, 0.6, 0.9, 0.7, 0.8, 1.0])
+    assert s["n"] == 10 and s["min"] == 0.1 and s["max"] == 1.0
+    assert s["median"] == 0.6 and s["p90"] == 1.0 and abs(s["mean"] - 0.55) < 1e-12
+    assert bench.dist_stats([2.0]) == {"n": 1, "min": 2.0, "median": 2.0, "p90": 2.0, "max": 2.0, "mean": 2.0}
+
+
+def test_traffic_is_reported_only_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed rocprofv3 PMC pass; it is reported only when that pass ran on the
+    rollout sources being benchmarked (sha-256 stamp), otherwise the line says which file is stale."""
+    sha = bench.source_sha()
+    assert len(sha) == 16 and int(sha, 16) >= 0
+    # the committed profile must be current for the committed kernel (a stale one is a hygiene failure of the repo)
+    got = bench.profiled_traffic()
+    assert got is not None and got[0] is not None, got
+    alg = bench.N_ENVS_PER_GPU * bench.CHUNK * bench.BYTES_PER_STEP
+    assert 0.99 * alg <= got[0] <= 1.05 * alg          # nothing re-read or written twice
+    # a fake tree: one profile stamped with another sha -> stale; add a matching one -> its value wins
+    csrc = tmp_path / "smartstartcontinuous_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    for f in ("rollout.hip", "ssc_device.h"):
+        (csrc / f).write_bytes(open(os.path.join(ROOT, "smartstartcontinuous_amd", "csrc", f), "rb").read())
+    (tmp_path / "profiles" / "old").mkdir(parents=True)
+    (tmp_path / "profiles" / "old" / "traffic.json").write_text(json.dumps(
+        {"write_bytes": 1.0, "fetch_bytes_corrected": 2.0, "source_sha": "0123456789abcdef"}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.source_sha() == sha
+    value, note = bench.profiled_traffic()
+    assert value is None and "stale" in note and "0123456789abcdef" in note
+    (tmp_path / "profiles" / "zz_new").mkdir()
+    (tmp_path / "profiles" / "zz_new" / "traffic.json").write_text(json.dumps(
+        {"write_bytes": 10.0, "fetch_bytes_corrected": 5.0, "source_sha": sha}))
+    assert bench.profiled_traffic() == (15.0, os.path.join("profiles", "zz_new", "traffic.json"))
+    (csrc / "rollout.hip").write_bytes(b"// edited\n")          # the kernel changes: every committed figure goes stale
+    value, note = bench.profiled_traffic()
+    assert value is None and "stale" in note
