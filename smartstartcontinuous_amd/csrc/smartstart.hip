@@ -51,7 +51,9 @@ __global__ __launch_bounds__(64) void critic_kernel(CriticW w, int64_t m, const 
     if (active) q[i] = out;
 }
 
-constexpr int kKdeQ = 8;  // query points per block
+constexpr int kKdeQ = 8;        // query points per block
+constexpr int kKdeThreads = 1024;
+constexpr int kKdeU = 4;        // data points per thread and loop trip, loads issued together
 
 struct KdeArgs {
     int32_t d;
@@ -60,20 +62,29 @@ struct KdeArgs {
     double norm;
 };
 
-__global__ __launch_bounds__(256) void kde_kernel(KdeArgs a, const float *__restrict__ data,
-                                                  const float *__restrict__ points, float *__restrict__ pdf) {
-    __shared__ double red[256 / 64][kKdeQ];
-    const int d = a.d;
+// One block = kKdeQ query points against the whole data set.  Round 1 ran this with 256-thread blocks, one data point
+// per loop trip and the state dimension as a run-time bound: 2000 / 8 = 250 blocks x 4 waves is ONE wave per SIMD, every
+// trip waited for its own L2 round trip, and the d x d whitening plus the per-query distance were 8 x 8 and 8 x 8
+// predicated loops for a 2-d state (0.41 ms for 2000 x 100 000, a tenth of the VALU rate).  Now: the dimension is a
+// template parameter (D = 0: any d <= SSC_MAX_STATE, guarded), 1024 threads per block (4 waves per SIMD), kKdeU
+// independent loads in flight per lane.  fp32 exp on the transcendental pipe, per-thread fp32 sums over <= ~100 terms,
+// f64 block reduction in a fixed order (deterministic).
+template <int D>
+__global__ __launch_bounds__(kKdeThreads) void kde_kernel(KdeArgs a, const float *__restrict__ data,
+                                                          const float *__restrict__ points, float *__restrict__ pdf) {
+    constexpr int DM = D > 0 ? D : SSC_MAX_STATE;
+    __shared__ double red[kKdeThreads / 64][kKdeQ];
+    const int d = D > 0 ? D : a.d;
     // whitened query points: y_q = Wh * x_q  (then || Wh (x_q - x_j) || = || y_q - Wh x_j ||)
-    float yq[kKdeQ][SSC_MAX_STATE];
+    float yq[kKdeQ][DM];
 #pragma unroll
     for (int q = 0; q < kKdeQ; ++q) {
         const int64_t qi = min((int64_t)blockIdx.x * kKdeQ + q, a.m - 1);
 #pragma unroll
-        for (int r = 0; r < SSC_MAX_STATE; ++r) {
+        for (int r = 0; r < DM; ++r) {
             float s = 0.0f;
 #pragma unroll
-            for (int c = 0; c < SSC_MAX_STATE; ++c)
+            for (int c = 0; c < DM; ++c)
                 if (r < d && c < d) s = fmaf(a.wh[r * d + c], points[qi * d + c], s);
             yq[q][r] = s;
         }
@@ -81,28 +92,38 @@ __global__ __launch_bounds__(256) void kde_kernel(KdeArgs a, const float *__rest
     float sum[kKdeQ];
 #pragma unroll
     for (int q = 0; q < kKdeQ; ++q) sum[q] = 0.0f;
-    for (int64_t j = threadIdx.x; j < a.n; j += 256) {
-        float x[SSC_MAX_STATE], y[SSC_MAX_STATE];
+    for (int64_t j0 = threadIdx.x; j0 < a.n; j0 += (int64_t)kKdeThreads * kKdeU) {
+        float x[kKdeU][DM];
 #pragma unroll
-        for (int c = 0; c < SSC_MAX_STATE; ++c) x[c] = (c < d) ? data[j * d + c] : 0.0f;
+        for (int u = 0; u < kKdeU; ++u) {
+            const int64_t j = j0 + (int64_t)u * kKdeThreads;
 #pragma unroll
-        for (int r = 0; r < SSC_MAX_STATE; ++r) {
-            float s = 0.0f;
-#pragma unroll
-            for (int c = 0; c < SSC_MAX_STATE; ++c)
-                if (r < d && c < d) s = fmaf(a.wh[r * d + c], x[c], s);
-            y[r] = s;
+            for (int c = 0; c < DM; ++c) x[u][c] = (c < d && j < a.n) ? data[j * d + c] : 0.0f;
         }
 #pragma unroll
-        for (int q = 0; q < kKdeQ; ++q) {
-            float e = 0.0f;
+        for (int u = 0; u < kKdeU; ++u) {
+            const bool live = j0 + (int64_t)u * kKdeThreads < a.n;
+            float y[DM];
 #pragma unroll
-            for (int r = 0; r < SSC_MAX_STATE; ++r)
-                if (r < d) {
-                    const float t = yq[q][r] - y[r];
-                    e = fmaf(t, t, e);
-                }
-            sum[q] += __expf(-0.5f * e);
+            for (int r = 0; r < DM; ++r) {
+                float s = 0.0f;
+#pragma unroll
+                for (int c = 0; c < DM; ++c)
+                    if (r < d && c < d) s = fmaf(a.wh[r * d + c], x[u][c], s);
+                y[r] = s;
+            }
+#pragma unroll
+            for (int q = 0; q < kKdeQ; ++q) {
+                float e = 0.0f;
+#pragma unroll
+                for (int r = 0; r < DM; ++r)
+                    if (r < d) {
+                        const float t = yq[q][r] - y[r];
+                        e = fmaf(t, t, e);
+                    }
+                const float k = __expf(-0.5f * e);
+                sum[q] += live ? k : 0.0f;
+            }
         }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(256) void kde_kernel(KdeArgs a, const float *__rest
         const int64_t qi = (int64_t)blockIdx.x * kKdeQ + threadIdx.x;
         if (qi < a.m) {
             double v = 0.0;
-            for (int w = 0; w < 256 / 64; ++w) v += red[w][threadIdx.x];
+            for (int w = 0; w < kKdeThreads / 64; ++w) v += red[w][threadIdx.x];
             pdf[qi] = (float)(v * a.norm);
         }
     }
@@ -194,8 +215,12 @@ int ssc_kde_evaluate(int32_t d, int64_t n, const float *d_data, int64_t m, const
     KdeArgs a{};
     a.d = d; a.n = n; a.m = m; a.norm = norm;
     for (int i = 0; i < d * d; ++i) a.wh[i] = whitening[i];
-    hipLaunchKernelGGL(kde_kernel, dim3(blocks_for(m, kKdeQ)), dim3(256), 0, as_stream(stream), a, d_data, d_points,
-                       d_pdf);
+    const dim3 grid(blocks_for(m, kKdeQ)), block(kKdeThreads);
+    hipStream_t s = as_stream(stream);
+    if (d == 1) hipLaunchKernelGGL(kde_kernel<1>, grid, block, 0, s, a, d_data, d_points, d_pdf);
+    else if (d == 2) hipLaunchKernelGGL(kde_kernel<2>, grid, block, 0, s, a, d_data, d_points, d_pdf);
+    else if (d == 3) hipLaunchKernelGGL(kde_kernel<3>, grid, block, 0, s, a, d_data, d_points, d_pdf);
+    else hipLaunchKernelGGL(kde_kernel<0>, grid, block, 0, s, a, d_data, d_points, d_pdf);
     return check_launch("ssc_kde_evaluate");
 }
 

@@ -27,7 +27,10 @@ def kde_scott_bandwidth(data):
     fp64; the d x d algebra is host-side.  Returns (whitening [d,d] fp32, norm)."""
     x = data.double()
     n, d = x.shape
-    cov = torch.atleast_2d(torch.cov(x.t())).cpu().numpy() * (n ** (-1.0 / (d + 4))) ** 2
+    # two-pass covariance with elementwise kernels and column sums (torch.cov goes through an f64 GEMM that takes 5.5 ms
+    # for a [2, 100 000] matrix on this stack -- 85 % of a whole smart-start selection; this is ~0.1 ms)
+    xc = x - x.mean(dim=0, keepdim=True)
+    cov = ((xc.unsqueeze(2) * xc.unsqueeze(1)).sum(dim=0) / (n - 1)).cpu().numpy() * (n ** (-1.0 / (d + 4))) ** 2
     inv = np.linalg.inv(cov)
     wh = np.linalg.cholesky(inv).T
     norm = 1.0 / (n * np.sqrt(np.linalg.det(2 * np.pi * cov)))
