@@ -266,6 +266,14 @@ class VecEnv:
 
     def step(self, actions):
         """actions [N, act_dim] (or [N]) -> (obs [N, obs_dim], rew [N], done [N] bool, {})."""
+        self._step_raw(actions)
+        obs, rew, done = self._obs.t().clone(), self._rew.clone(), self._done.bool()
+        if self.auto_reset:
+            self.reset(mask=self._done)
+        return obs, rew, done, {}
+
+    def _step_raw(self, actions):
+        """The launches of ``step``; the results stay in ``self._obs`` [obs_dim, N], ``self._rew``, ``self._done``."""
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
         if a.numel() != self.n:
             raise ValueError(f"expected {self.n} actions, got {a.numel()}")
@@ -282,10 +290,6 @@ class VecEnv:
                                                   _ffi.ptr(self._rew), _ffi.ptr(self._done), _ffi.ptr(self.steps),
                                                   _stream()))
         self.t += 1
-        obs, rew, done = self._obs.t().clone(), self._rew.clone(), self._done.bool()
-        if self.auto_reset:
-            self.reset(mask=self._done)
-        return obs, rew, done, {}
 
     def render(self, mode="human"):
         raise NotImplementedError("rendering is out of scope (SURVEY.md section 8: visualisation)")
@@ -492,8 +496,15 @@ class SingleEnvView:
 
     def step(self, action):
         a = np.asarray(action, dtype=np.float64).reshape(-1)
-        obs, rew, done, info = self.vec.step(torch.as_tensor(a, dtype=torch.float32))
-        return obs[0].double().cpu().numpy(), float(rew[0].item()), bool(done[0].item()), info
+        v = self.vec
+        if v.auto_reset:
+            obs, rew, done, info = v.step(torch.as_tensor(a, dtype=torch.float32))
+            return obs[0].double().cpu().numpy(), float(rew[0].item()), bool(done[0].item()), info
+        # one device -> host copy per step instead of three (each is a stream synchronisation)
+        v._step_raw(torch.as_tensor(a, dtype=torch.float32))
+        d = v.obs_dim
+        packed = torch.cat((v._obs.reshape(-1), v._rew, v._done.to(torch.float32))).cpu().numpy()
+        return packed[:d].astype(np.float64), float(packed[d]), bool(packed[d + 1] != 0.0), {}
 
     def render(self, mode="human"):
         return self.vec.render(mode)
