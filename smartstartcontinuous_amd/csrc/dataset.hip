@@ -18,6 +18,8 @@
 //   ssc_add_noise       x[:, c] += |mean[c] * noise_to_signal| * N(0,1) where mean[c] * noise_to_signal > 0.
 //
 // All of it is HBM-bound byte moving: (2*obs_dim + 1) * 4 B read (+1 B done) and written per data-set row.
+#include <type_traits>
+
 #include "ssc_device.h"
 #include "ssc_host.h"
 
@@ -164,12 +166,16 @@ __global__ __launch_bounds__(256) void dataset_build_kernel(DatasetArgs g) {
     }
     auto stage = [&](int c, int j, float v) { tile[c * (kTileStride + kPad) + (w + 4 * j) * 65 + lane] = v; };
     // one env per (wave, j): width*64 consecutive floats of the output starting at row off + k0
-    auto flush = [&](float *__restrict__ dst, int width) {
+    // (the output width is a compile-time constant of each call: as a run-time argument every element paid an integer
+    // division for its (row, column))
+    auto flush = [&](float *__restrict__ dst, auto width_tag) {
+        constexpr int width = decltype(width_tag)::value;
 #pragma unroll 4
         for (int j = 0; j < 16; ++j) {
             const int el = w + 4 * j;
             const int32_t r = rows_s[el] - k0;            // rows of this env inside the tile (may be <= 0 or > 64)
             const int64_t base = (off_s[el] + k0) * width;
+#pragma unroll
             for (int f = lane; f < width * kTileK; f += 64) {
                 const int kl = f / width, c = f - kl * width;
                 const int64_t row = off_s[el] + k0 + kl;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256) void dataset_build_kernel(DatasetArgs g) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) stage(c, j, o[c][j]);
     __syncthreads();
-    flush(g.X, D);
+    flush(g.X, std::integral_constant<int, D>{});
     __syncthreads();
     // ---- dataZ = s_{i+1} - s_i (data_manipulation.py:84-85) ---------------------------------------------------
 #pragma unroll
@@ -191,13 +197,13 @@ __global__ __launch_bounds__(256) void dataset_build_kernel(DatasetArgs g) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) stage(c, j, o2[c][j] - o[c][j]);
     __syncthreads();
-    flush(g.Z, D);
+    flush(g.Z, std::integral_constant<int, D>{});
     __syncthreads();
     // ---- dataY = a_i ----------------------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 16; ++j) stage(0, j, a[j]);
     __syncthreads();
-    flush(g.Y, 1);
+    flush(g.Y, std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -264,9 +270,13 @@ struct SpanIndex {
     }
 };
 
-__global__ __launch_bounds__(kBlock) void zscore_kernel(const float *__restrict__ x, int64_t total, int32_t cols,
+// COLS > 0: the column count as a compile-time constant (the (row, column) of an element is then a multiply-shift, not
+// an integer division per element); COLS == 0: any count
+template <int COLS>
+__global__ __launch_bounds__(kBlock) void zscore_kernel(const float *__restrict__ x, int64_t total, int32_t cols_rt,
                                                          const double *__restrict__ mean, const double *__restrict__ sd,
                                                          float *__restrict__ out, int32_t out_stride, int32_t out_col0) {
+    const int32_t cols = COLS > 0 ? COLS : cols_rt;
     // (x - mean) * (1 / std): one f64 division per column and block instead of one per element; 0 * inf = NaN and
     // finite * inf = +-inf reproduce what the division by a zero std gives
     __shared__ double mean_s[kBlock], inv_s[kBlock];
@@ -300,9 +310,11 @@ __global__ __launch_bounds__(kBlock) void zscore_kernel(const float *__restrict_
     }
 }
 
-__global__ __launch_bounds__(kBlock) void add_noise_kernel(float *__restrict__ x, int64_t total, int32_t cols,
+template <int COLS>
+__global__ __launch_bounds__(kBlock) void add_noise_kernel(float *__restrict__ x, int64_t total, int32_t cols_rt,
                                                             const double *__restrict__ mean, double nts, uint64_t seed,
                                                             uint64_t stream_id) {
+    const int32_t cols = COLS > 0 ? COLS : cols_rt;
     const int64_t first = (int64_t)blockIdx.x * (kBlock * kPerThread);
     const SpanIndex span(first, cols);
     float v[kPerThread];
@@ -409,8 +421,11 @@ int ssc_zscore(const float *d_x, int64_t rows, int32_t cols, const double *d_mea
     if (rows == 0) return SSC_OK;
     SSC_REQUIRE(d_x && d_mean && d_std && d_out, "ssc_zscore: NULL pointer");
     const int64_t total = rows * cols;
-    hipLaunchKernelGGL(zscore_kernel, dim3(blocks_for(total, kBlock * kPerThread)), dim3(kBlock), 0, as_stream(stream), d_x, total, cols, d_mean,
-                       d_std, d_out, out_stride, out_col0);
+    const dim3 grid(blocks_for(total, kBlock * kPerThread)), block(kBlock);
+    hipStream_t s = as_stream(stream);
+#define SSC_ZS(C) hipLaunchKernelGGL(zscore_kernel<C>, grid, block, 0, s, d_x, total, cols, d_mean, d_std, d_out, out_stride, out_col0)
+    if (cols == 1) SSC_ZS(1); else if (cols == 2) SSC_ZS(2); else if (cols == 3) SSC_ZS(3); else if (cols == 4) SSC_ZS(4); else SSC_ZS(0);
+#undef SSC_ZS
     return check_launch("ssc_zscore");
 }
 
@@ -421,8 +436,11 @@ int ssc_add_noise(float *d_x, int64_t rows, int32_t cols, const double *d_mean, 
     if (rows == 0) return SSC_OK;
     SSC_REQUIRE(d_x && d_mean, "ssc_add_noise: NULL pointer");
     const int64_t total = rows * cols;
-    hipLaunchKernelGGL(add_noise_kernel, dim3(blocks_for(total, kBlock * kPerThread)), dim3(kBlock), 0, as_stream(stream), d_x, total, cols,
-                       d_mean, noise_to_signal, seed, stream_id);
+    const dim3 grid(blocks_for(total, kBlock * kPerThread)), block(kBlock);
+    hipStream_t s = as_stream(stream);
+#define SSC_AN(C) hipLaunchKernelGGL(add_noise_kernel<C>, grid, block, 0, s, d_x, total, cols, d_mean, noise_to_signal, seed, stream_id)
+    if (cols == 1) SSC_AN(1); else if (cols == 2) SSC_AN(2); else if (cols == 3) SSC_AN(3); else if (cols == 4) SSC_AN(4); else SSC_AN(0);
+#undef SSC_AN
     return check_launch("ssc_add_noise");
 }
 
