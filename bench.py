@@ -204,7 +204,18 @@ def bench_config4(args, torch):
     for e0, e1 in evs:
         e0.record(); graph.replay(); e1.record()
     torch.cuda.synchronize()
-    kms = sum(x.elapsed_time(y) for x, y in evs) / (args.steps * reps)
+    kms_b2b = sum(x.elapsed_time(y) for x, y in evs) / (args.steps * reps)
+    # ... and the same kernel where the product runs it: inside the MPC step (simulate, score A, score B), one event pair
+    # around the simulation launch of every step of a second, untimed pass over the same steps.  This is the figure the
+    # roofline uses (it is what rocprofv3 averages for this kernel over the step loop); ten simulations back to back
+    # run 7-10 % slower -- the kernel is power-limited and the two scoring launches are its breathing space.
+    sim_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for t, (e0, e1) in enumerate(sim_evs):
+        sp = nav.mpc_sampling(N, [-2.0], [2.0], 1234, 0, t)
+        e0.record(); model.do_forward_sim_sampled(s0_p, sp, M, H, out=S); e1.record()
+        nav.mpc_score_select(ps, S, sampling=sp, act_dim=a, noise_amount=0.005, seed=1234, problem_id0=0, t=t, want_path=False, out=sel_out)
+    torch.cuda.synchronize()
+    kms = sum(x.elapsed_time(y) for x, y in sim_evs) / args.steps
     flop_row = 2.0 * ((d + a) * 500 + 500 * 500 + 500 * d)         # 507 000, SURVEY 8d
     res = {"metric": "row-steps/sec, NND_MB dynamics MLP 2x500 forward sim + MPC scoring, 65 536 rows", "value": M * H * args.steps / el,
            "unit": "row-steps/s", "env_steps_per_s": P * args.steps / el,
@@ -216,7 +227,9 @@ def bench_config4(args, torch):
                                           "200-state recorded path as waypoints; forward sim (in-kernel sampling) + score + select = 3 launches per MPC step" % (P, N, M, H)},
            "roofline": {"bound": "mfma", "achieved": flop_row * M * H / (kms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": flop_row * M * H / (kms * 1e-3) / 1e12 / 2500.0, "traffic": None, "kernel_ms": kms,
-                        "kernel": "ssc::dyn_mfma_sim_kernel<16,2,true,4> (weight image prepared once; HIP-graph replay of 10 launches)", "algorithmic_flop_per_launch": flop_row * M * H}}
+                        "kernel": "ssc::dyn_mfma_sim_kernel<16,2,true,4> (weight image prepared once; one event pair around the simulation launch of every MPC step)",
+                        "kernel_ms_back_to_back": kms_b2b, "kernel_ms_back_to_back_note": "HIP-graph replay of 10 simulation launches with nothing in between",
+                        "algorithmic_flop_per_launch": flop_row * M * H}}
     if not args.no_cpu_baseline:
         Wn, bn = [w.numpy() for w in Ws], [b.numpy() for b in bs]
         m_cpu = 2048
