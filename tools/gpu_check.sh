@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-O=gpurun_out/r02final
+O=gpurun_out/check
 mkdir -p $O
 step() { local name=$1 lim=$2; shift 2; timeout -k 10 $lim "$@"; local rc=$?; echo "[$name] rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] killed at its limit: stopping"; exit 1; fi; }
 step pytest 500 bash -c "python3 -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -4 $O/pytest.log"
