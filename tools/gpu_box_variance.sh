@@ -1,5 +1,5 @@
 #!/bin/bash
-# box-to-box variance: the three bench lines on whatever box this call got (tools/r03_var.sh <tag>)
+# box-to-box variance: the three bench lines on whatever box this call got (tools/gpu_box_variance.sh <tag>)
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/var_$1
