@@ -206,7 +206,7 @@ class TransitionGather:
     def submit(self, chunk, slot, stats):
         """Call right after the rollout that filled ``chunk`` was enqueued (same stream).
 
-        The pack (one small kernel, ~10 us) runs IN ORDER on the producing stream, so the rollout
+        The pack (one small kernel: 12 us for 26 MB, 1.5 us for 3 MB) runs IN ORDER on the producing stream, so the rollout
         stream never waits on another stream for its 1.7 GB chunk buffer; only the collective runs on
         the side stream, double-buffered through the two send slots (and the two receive slots on ``dst``:
         the caller must be done reading ``recv[slot]`` -- i.e. the chunk gathered two submits ago -- on the
