@@ -75,7 +75,9 @@ __global__ __launch_bounds__(kKdeThreads) void kde_kernel(KdeArgs a, const float
     constexpr int DM = D > 0 ? D : SSC_MAX_STATE;
     __shared__ double red[kKdeThreads / 64][kKdeQ];
     const int d = D > 0 ? D : a.d;
-    // whitened query points: y_q = Wh * x_q  (then || Wh (x_q - x_j) || = || y_q - Wh x_j ||)
+    // whitened query points: y_q = Wh * x_q  (then || Wh (x_q - x_j) || = || y_q - Wh x_j ||).  The whitening matrix is
+    // pre-scaled by sqrt(0.5 log2 e), so that exp(-0.5 ||.||^2) = exp2(-||scaled . ||^2): no multiply in front of v_exp_f32
+    const float kS = 0.84932180028801904272f;   // sqrt(0.5 * log2(e))
     float yq[kKdeQ][DM];
 #pragma unroll
     for (int q = 0; q < kKdeQ; ++q) {
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(kKdeThreads) void kde_kernel(KdeArgs a, const float
             float s = 0.0f;
 #pragma unroll
             for (int c = 0; c < DM; ++c)
-                if (r < d && c < d) s = fmaf(a.wh[r * d + c], points[qi * d + c], s);
+                if (r < d && c < d) s = fmaf(a.wh[r * d + c] * kS, points[qi * d + c], s);
             yq[q][r] = s;
         }
     }
@@ -109,9 +111,11 @@ __global__ __launch_bounds__(kKdeThreads) void kde_kernel(KdeArgs a, const float
                 float s = 0.0f;
 #pragma unroll
                 for (int c = 0; c < DM; ++c)
-                    if (r < d && c < d) s = fmaf(a.wh[r * d + c], x[u][c], s);
+                    if (r < d && c < d) s = fmaf(a.wh[r * d + c] * kS, x[u][c], s);
                 y[r] = s;
             }
+            // a data point past the end sits infinitely far away: exp2(-inf) = 0, no select per query
+            if (!live) y[0] = INFINITY;
 #pragma unroll
             for (int q = 0; q < kKdeQ; ++q) {
                 float e = 0.0f;
@@ -121,8 +125,7 @@ __global__ __launch_bounds__(kKdeThreads) void kde_kernel(KdeArgs a, const float
                         const float t = yq[q][r] - y[r];
                         e = fmaf(t, t, e);
                     }
-                const float k = __expf(-0.5f * e);
-                sum[q] += live ? k : 0.0f;
+                sum[q] += __builtin_amdgcn_exp2f(-e);
             }
         }
     }
