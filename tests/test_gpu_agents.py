@@ -289,7 +289,8 @@ def test_critic_kde_ucb_kernels(ssc):
         ref_ab = O.actor_forward(big, **aw, last_layer_tanh=llt, obs_clip=5.0)
         assert np.max(np.abs(ab - ref_ab)) <= 2e-5
     # KDE (Scott) + UCB against the oracle (itself pinned to scipy.stats.gaussian_kde on the CPU)
-    for n, d, m in [(5000, 2, 2000), (100000, 2, 2000), (3000, 3, 77)]:
+    # d = 1, 2, 3 run the dimension-templated kernel, d = 5 the guarded generic one; n = 4099 leaves a ragged last trip
+    for n, d, m in [(5000, 2, 2000), (100000, 2, 2000), (3000, 3, 77), (4099, 1, 9), (2500, 5, 130)]:
         data = (np.cumsum(rng.normal(size=(n, d)) * 0.01, axis=0) % 1.0).astype(np.float32)
         pts = data[rng.integers(0, n, m)]
         dt, pt = torch.as_tensor(data, device="cuda"), torch.as_tensor(pts, device="cuda")
