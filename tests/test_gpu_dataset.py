@@ -124,6 +124,16 @@ def test_column_stats_zscore_and_noise(ssc):
         # device Box-Muller runs on v_log/v_sqrt/v_cos (~1e-6 relative) and the sum rounds to fp32
         tol = 2e-5 * abs(m_ref[c]) * 0.01 + 1.2e-7 * np.abs(x[:, c])
         assert np.all(np.abs(got[:, c] - ref[:, c]) <= tol)
+    # every column-count instantiation of the two elementwise kernels (1..4 are compile-time, anything else run-time)
+    for cols in (1, 2, 3, 5):
+        xc = (rng.normal(size=(7001, cols)) * 2.0 + 3.0).astype(np.float32)
+        xcd = torch.as_tensor(xc, device="cuda")
+        mc, sc = cs.column_stats(xcd)
+        outc = cs.zscore_into(xcd, mc, sc, torch.empty((7001, cols), device="cuda")).cpu().numpy()
+        assert np.allclose(outc, O.zscore(xc, mc.cpu().numpy(), sc.cpu().numpy()), rtol=2e-7, atol=0), cols
+        nz = cs.add_noise_device(xcd.clone(), 0.02, seed=9, stream_id=1, mean=mc).cpu().numpy()
+        refn = O.add_noise_keyed(xc, mc.cpu().numpy(), 0.02, 9, 1)
+        assert np.all(np.abs(nz - refn) <= 2e-5 * 3.0 * 0.02 * 4 + 1.2e-7 * np.abs(xc)), cols
     assert abs((got[:, 0] - x[:, 0]).std() / (0.01 * m_ref[0]) - 1.0) < 0.02
 
 
