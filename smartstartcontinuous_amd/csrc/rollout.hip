@@ -333,7 +333,11 @@ struct Rollout {
         }
 #pragma unroll
         for (int c = 0; c < OBS; ++c) obs[c] = obs2[c];
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(done) != 0, 0)) {  // wave-uniform, rare
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(done) != 0, 0)) reset_path(done, k);  // wave-uniform, rare
+    }
+
+    __device__ __forceinline__ void reset_path(bool done, int32_t k) {
+        {
             if (done) {
                 if (ra.has_ring && active && owner) {
                     const uint32_t slot = atomicAdd(ra.ring.cursor, 1u);
@@ -513,9 +517,10 @@ static int launch_rollout(const typename EnvT::Const &ec, const PolicyArgs &pa, 
     const dim3 grid(blocks_for(ra.n, kBlock / PolT::kLanesPerEnv));
     // One running row pointer + per-column lane offsets (ONEBASE) takes ~30 scalar address instructions out of every
     // step: 12 % faster for the actor policies, whose step is instruction-bound (0.254 -> 0.224 ms per 65 536 x 256).
-    // The random policy is HBM-bound and gets SLOWER with it (0.243 -> 0.282 ms per 65 536 x 1024): its seven stores then
-    // leave the wave back to back, 256 KB apart, instead of spread over the step by the address arithmetic between
-    // them -- it keeps the per-column pointers.
+    // The random policy is HBM-bound and gets SLOWER with it (0.242 -> 0.27-0.28 ms per 65 536 x 1024, median; the minimum
+    // stays at 0.237): with the stores in one burst AND with the stores spread over the step by scheduling fences -- so
+    // it is not the burst.  The launch-time distribution widens, as if the 1024 waves, freed of ~30 scalar instructions
+    // of per-step jitter, fell into step with each other.  It keeps the per-column pointers.
     constexpr bool kOneBase = !PolT::kPipelined;
     if (ra.has_log && ra.one_base && kOneBase)
         hipLaunchKernelGGL((rollout_kernel<EnvT, PolT, true, kOneBase>), grid, dim3(kBlock), 0, stream, ec, pa, ra);
