@@ -269,6 +269,9 @@ struct ActorMfma {
 #ifndef SSC_ACT_ABL
 #define SSC_ACT_ABL 0      // diagnostic ablations (tools/exp_actor_abl.py); results are WRONG when set
 #endif
+#ifndef SSC_ACT_PACKED
+#define SSC_ACT_PACKED 1
+#endif
 #ifndef SSC_ACT_STAGED
 #define SSC_ACT_STAGED 0
 #endif
@@ -415,6 +418,25 @@ struct ActorMfma2 {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) part[et][q & 1] = fmaf(e[q], w3[8 * b + q], part[et][q & 1]);
                 }
+        } else
+#endif
+#if SSC_ACT_PACKED && SSC_ACT_ABL != 1
+        if (LAST_TANH) {
+            // the "+ 1" and the w3-weighted sum as packed fp32 ops (v_pk_add_f32 / v_pk_fma_f32: two values per issue
+            // slot); the partial sums keep their order (even registers in .x, odd ones in .y): bit-identical results
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 p2[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+#pragma unroll
+            for (int reg = 0; reg < 16; reg += 2)
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    f32x2 e = {__builtin_amdgcn_exp2f(acc2[et][reg]), __builtin_amdgcn_exp2f(acc2[et][reg + 1])};
+                    e += f32x2{1.0f, 1.0f};
+                    const f32x2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+                    p2[et] = __builtin_elementwise_fma(r, f32x2{w3[reg], w3[reg + 1]}, p2[et]);
+                }
+            part[0][0] = p2[0].x; part[0][1] = p2[0].y;
+            part[1][0] = p2[1].x; part[1][1] = p2[1].y;
         } else
 #endif
 #pragma unroll
