@@ -468,7 +468,11 @@ int ssc_replay_episode_path(const ssc_replay_ring *ring, int64_t count, int64_t 
 /* n_iters sequential training iterations in ONE launch (one workgroup: the iterations are a serial
  * chain through the parameters).  d_batch_idx [n_iters][batch_size] are record indices
  * (ReplayBuffer.sample_batch, replay_buffer.py:79-91, draws them on the host).  d_losses
- * [n_iters][2] = (critic_loss, actor_loss) per iteration, may be NULL. */
+ * [n_iters][2] = (critic_loss, actor_loss) per iteration, may be NULL.
+ * Shapes: batch 64, act_dim 1.  The shipped 64-32 actor / critic with a 2- or 3-d observation runs a kernel compiled
+ * for that shape; any other layer sizes <= 64 run a step interpreter as long as the batch's activations plus the four
+ * parameter vectors fit the 160 KB of LDS (64-32 with obs_dim <= 8 does; 64-64 does not) -- otherwise SSC_EUNSUPPORTED
+ * with the byte count in ssc_last_error(). */
 int ssc_ddpg_train(const ssc_ddpg_desc *ddpg, const ssc_replay_view *replay, const int32_t *d_batch_idx,
                    int32_t n_iters, float *d_losses, ssc_stream_t stream);
 
