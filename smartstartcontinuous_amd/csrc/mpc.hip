@@ -186,9 +186,19 @@ __device__ __forceinline__ void block_argmax(float &score, int &best, float *rs,
 }
 
 // dynamic LDS: reduction scratch | wps [Wmax*d] | lefts [Wmax] | inv_r [8]
-__global__ __launch_bounds__(kMpcBlock) void mpc_pass_a_kernel(MpcArgs a, int Wmax, const float *__restrict__ S,
-                                                               double *__restrict__ partial,
-                                                               int32_t *__restrict__ ticket) {
+// The kernels below dispatch on the state dimension once and run a copy of their (inlined) body in which `a.d` is a
+// known constant: the walk's distance and projection loops are written over SSC_MAX_STATE = 8 slots with `k < d` guards,
+// which for the 2- and 3-d states of the shipped envs is otherwise two thirds predicated-off work per sample and point.
+#define SSC_MPC_DISPATCH_D(a, CALL)                                  \
+    do {                                                            \
+        if ((a).d == 2) { (a).d = 2; CALL; }                        \
+        else if ((a).d == 3) { (a).d = 3; CALL; }                   \
+        else if ((a).d == 1) { (a).d = 1; CALL; }                   \
+        else { CALL; }                                              \
+    } while (0)
+
+__device__ __forceinline__ void mpc_pass_a_body(MpcArgs a, int Wmax, const float *__restrict__ S, double *__restrict__ partial,
+                                                int32_t *__restrict__ ticket) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);  // [4 waves][H+1][2]
     float *wps = reinterpret_cast<float *>(red + 4 * kMaxH1 * 2);
@@ -212,6 +222,12 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_pass_a_kernel(MpcArgs a, int Wm
     }
 }
 
+__global__ __launch_bounds__(kMpcBlock) void mpc_pass_a_kernel(MpcArgs a, int Wmax, const float *__restrict__ S,
+                                                               double *__restrict__ partial,
+                                                               int32_t *__restrict__ ticket) {
+    SSC_MPC_DISPATCH_D(a, mpc_pass_a_body(a, Wmax, S, partial, ticket));
+}
+
 // What ssc_mpc_select_action does, folded into pass B's last block (ssc_mpc_score_select)
 struct SelectArgs {
     float *action;       // [P][act]; nullptr: no selection epilogue
@@ -225,13 +241,10 @@ struct SelectArgs {
     float low[SSC_MAX_ACT], span[SSC_MAX_ACT];
 };
 
-__global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wmax, int stage_partials, SelectArgs sel, const float *__restrict__ S,
-                                                               const double *__restrict__ partial,
-                                                               float *__restrict__ scores,
-                                                               float *blk_best_score, int32_t *blk_best_idx,
-                                                               int32_t *__restrict__ ticket,
-                                                               int32_t *__restrict__ best_idx,
-                                                               float *__restrict__ best_score) {
+__device__ __forceinline__ void mpc_pass_b_body(MpcArgs a, int Wmax, int stage_partials, const SelectArgs &sel, const float *__restrict__ S,
+                                                const double *__restrict__ partial, float *__restrict__ scores,
+                                                float *blk_best_score, int32_t *blk_best_idx, int32_t *__restrict__ ticket,
+                                                int32_t *__restrict__ best_idx, float *__restrict__ best_score) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *cproj = reinterpret_cast<float *>(smem);  // [H+1] sum(a.b) / sum(b.b) of the whole problem
     float *rs = cproj + kMaxH1 + 1;                   // [4] block argmax scratch
@@ -337,6 +350,17 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wm
             sel.best_path[(int64_t)p * (a.H + 1) * a.d + e] = S[((int64_t)tt * M + row) * a.d + k];
         }
     }
+}
+
+__global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wmax, int stage_partials, SelectArgs sel, const float *__restrict__ S,
+                                                               const double *__restrict__ partial,
+                                                               float *__restrict__ scores,
+                                                               float *blk_best_score, int32_t *blk_best_idx,
+                                                               int32_t *__restrict__ ticket,
+                                                               int32_t *__restrict__ best_idx,
+                                                               float *__restrict__ best_score) {
+    SSC_MPC_DISPATCH_D(a, mpc_pass_b_body(a, Wmax, stage_partials, sel, S, partial, scores, blk_best_score, blk_best_idx, ticket,
+                                          best_idx, best_score));
 }
 
 struct ActBounds {
