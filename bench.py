@@ -434,9 +434,22 @@ def main():
     # profiles/r02/drift/window.txt).  W = 5 warm-up launches end in the middle of the first, so
     # W is followed by --settle-launches further untimed launches of the same step (1500 = 0.4 s): the timed K steps
     # then measure the state a rollout engine actually runs in.  The count is reported in the JSON line.
+    # For the record, the SAME K-step window is also timed right after the W warm-up launches, before any settling
+    # (`after_warmup_only` in the JSON line): that is the number a reader gets who wants W and nothing else.
+    cold_elapsed, cold_steps = None, 0
+    if args.settle_launches > 0:
+        cold_steps = args.steps
+        barrier()
+        t0c = time.perf_counter()
+        for i in range(cold_steps):
+            one_step(args.warmup + i, ev_pair("after warm-up only"))
+        if gather is not None:
+            gather.finish()
+        barrier()
+        cold_elapsed = time.perf_counter() - t0c
     for i in range(args.settle_launches):
-        one_step(args.warmup + i, ev_pair("settle"))
-    warm_total = args.warmup + args.settle_launches
+        one_step(args.warmup + cold_steps + i, ev_pair("settle"))
+    warm_total = args.warmup + cold_steps + args.settle_launches
     # The timed region carries ONE pair of HIP events (on the launch stream) around all K launches: an event pair around
     # every launch costs ~7 us of queue time per step (tools/exp_event_cost.py: 0.249 vs 0.2415 ms per step), which
     # would be charged to `value`.  The per-launch distribution comes from a second window of K launches right after
@@ -497,6 +510,10 @@ def main():
         kms = torch.tensor([kernel_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
         kernel_ms = float(kms.item())
+        if cold_elapsed is not None:
+            tc = torch.tensor([cold_elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            cold_elapsed = float(tc.item())
 
     if rank == 0:
         total_env_steps = float(n) * K * args.steps * world
@@ -512,6 +529,11 @@ def main():
             "warmup": args.warmup,
             "settle_launches": args.settle_launches,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "after_warmup_only": (None if cold_elapsed is None else
+                                  {"value": float(n) * K * cold_steps * world / cold_elapsed,
+                                   "ms_per_step": cold_elapsed / cold_steps * 1e3,
+                                   "note": "the same K-step window timed right after the W warm-up launches, before the "
+                                           "settle launches (post-idle clock transient, DESIGN.md section 6b)"}),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -559,7 +581,7 @@ def main():
             assert obs.shape == (env.obs_dim, gather.g_steps, n) and bool(torch.isfinite(act).all())
             # ... and the statistics that rode in the payloads add up to every rank's env-steps so far
             st = gather.global_stats.cpu().numpy()
-            assert st[2] == float(n) * K * world * (args.warmup + args.settle_launches + 2 * args.steps), st
+            assert st[2] == float(n) * K * world * (warm_total + 2 * args.steps), st
         dist.barrier()
         dist.destroy_process_group()
 
