@@ -236,7 +236,7 @@ def rl_train_vec(env, policy, num_chunks, chunk_steps=1024, ring_capacity=1 << 2
 
 
 def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1 << 20, train_iters=None,
-                      replay_last_steps=None, seed=0, ring_capacity=1 << 20, track_episodes=False):
+                      replay_last_steps=None, seed=0, ring_capacity=1 << 20, track_episodes=False, overlap=False):
     """Actor-learner loop entirely in HBM: every chunk is a fused rollout of ``chunk_steps`` steps of all
     ``env.n`` envs under the agent's current actor (+ OU noise), appended to a device replay ring, followed
     by ``train_iters`` DDPG iterations (default ``agent.num_train_iterations``) on batches drawn from it.
@@ -244,6 +244,11 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
     (rlTrain.py:75-100, DDPG_Baselines_agent.py:238-273).  ``track_episodes`` keeps the episode index in the device
     ring as well, so that ``smartstart.device_smart_start_path(replay, agent, radii, n_ss)`` can pick a smart-start
     state and recover the path to it without the replay contents leaving HBM.
+    ``overlap=True`` rolls chunk i+1 on a second stream WHILE the learner runs its iterations on chunk i: the rollout
+    then acts with a snapshot of the actor taken before those iterations (one chunk stale -- the single-GPU form of
+    ``rl_train_sharded_ddpg(pipelined=True)``); everything else (replay contents, epsilon decay per finished
+    generation, sampling) is ordered as in the synchronous loop, and the result is deterministic.  The default follows
+    the reference's order: act with the weights of the last completed train().
     Returns (Summary, losses per chunk, replay)."""
     import torch
     from .replay_buffer import DeviceReplayBuffer
@@ -257,6 +262,59 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
     generations = 0.0   # finished episodes / env.n: epsilon decays once per episode PER ENV (DDPG_Baselines_agent.py:255-258)
     side = torch.cuda.Stream(env.device)                 # episode-record readback, off the learner's stream
     rolled = torch.cuda.Event()
+
+    def decay(n_finished):
+        nonlocal generations
+        generations += n_finished / float(env.n)
+        while generations >= 1.0:
+            agent.decaying_ou_action_noise.reduce_epsilon()
+            generations -= 1.0
+
+    if overlap:
+        from .vec_env import ActorPolicy
+        cur = torch.cuda.current_stream(env.device)
+        act = torch.cuda.Stream(env.device)              # the rollouts' stream
+        chunks = [chunk, TransitionChunk(env.obs_dim, chunk_steps, env.n, env.device)]
+        snap = agent.actor_flat.clone()                  # the weights the NEXT rollout acts with
+        views, o = {}, 0
+        for k, v in agent.weights.items():               # same order and shapes as the flat array (flatten_params)
+            views[k] = snap[o:o + v.numel()].view(v.shape)
+            o += v.numel()
+        rolled2 = [torch.cuda.Event(), torch.cuda.Event()]
+        appended = [torch.cuda.Event(), torch.cuda.Event()]
+        snap_ready = torch.cuda.Event()
+
+        def launch_rollout(b, wait_for):
+            live = agent.as_policy()                     # OU parameters and the current epsilon
+            pol = ActorPolicy(views, last_layer_tanh=live.last_layer_tanh, precision=live.precision, ou_mu=live.ou_mu,
+                              ou_sigma=live.ou_sigma, ou_theta=live.ou_theta, ou_dt=live.ou_dt, ou_epsilon=live.ou_epsilon,
+                              obs_clip=live.obs_clip)
+            for e in wait_for:
+                act.wait_event(e)
+            with torch.cuda.stream(act):
+                env.rollout(chunk_steps, out=chunks[b], ring=ring, policy_desc=env.policy_desc(pol))
+                rolled2[b].record(act)
+
+        snap_ready.record(cur)
+        launch_rollout(0, [snap_ready])
+        for i in range(num_chunks):
+            b = i & 1
+            cur.wait_event(rolled2[b])
+            replay.append_chunk(chunks[b], reward_scale=agent.reward_scale, last_steps=replay_last_steps)
+            appended[b].record(cur)
+            snap.copy_(agent.actor_flat)                 # behind train i-1 on this stream, in front of train i
+            snap_ready.record(cur)
+            l = agent.train_from(replay, train_iters)    # queued BEFORE the host blocks on the episode records below
+            if l is not None:
+                losses.append(l)
+            (ids, lens, rets), _d, drained = ring.drain_overlapped(side, rolled2[b])
+            summary.extend_records(lens, rets)
+            decay(len(lens))
+            if i + 1 < num_chunks:                       # chunk buffer b^1 was last read by append i-1
+                launch_rollout(b ^ 1, [snap_ready, drained] + ([appended[b ^ 1]] if i >= 1 else []))
+        cur.wait_stream(act)
+        return summary, losses, replay
+
     for _ in range(num_chunks):
         pd = env.policy_desc(agent.as_policy())          # weights are views into the flat parameter arrays
         out = env.rollout(chunk_steps, out=chunk, ring=ring, policy_desc=pd)
@@ -270,8 +328,5 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
         (ids, lens, rets), _d, drained = ring.drain_overlapped(side, rolled)
         torch.cuda.current_stream(env.device).wait_event(drained)
         summary.extend_records(lens, rets)
-        generations += len(lens) / float(env.n)
-        while generations >= 1.0:
-            agent.decaying_ou_action_noise.reduce_epsilon()
-            generations -= 1.0
+        decay(len(lens))
     return summary, losses, replay

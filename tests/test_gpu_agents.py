@@ -538,6 +538,45 @@ def test_rl_train_vec_ddpg_loop_in_hbm(ssc):
     assert np.allclose(r[t == 0], 0.5 * (-0.1 * a[t == 0] ** 2), atol=1e-6)
 
 
+def test_rl_train_vec_ddpg_overlapped_rollout(ssc):
+    """``overlap=True``: chunk i+1 is rolled on a second stream under a snapshot of the actor while the learner works on
+    chunk i.  (1) With both learning rates at zero the weights never move, so the overlapped loop must reproduce the
+    synchronous one bit for bit (episodes, replay contents, losses) -- every cross-stream dependency (chunk buffers,
+    episode ring, epsilon decay, replay append) is then exercised against a known answer.  (2) With learning on, the
+    loop is deterministic (two runs agree bit for bit) and differs from the synchronous one only through the one-chunk
+    staleness: chunk 0 (rolled with the initial weights in both modes) is identical, chunk 1 is not."""
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    N, K = 512, 40
+
+    def run(overlap, lr_scale, chunks=5):
+        env = ssc.VecEnv("MountainCarContinuous-v0", N, seed=2, max_episode_steps=50)
+        env.reset()
+        agent = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, batch_size=64, num_train_iterations=7,
+                                     actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32, lastLayerTanh=True, seed=3,
+                                     actor_lr=1e-2 * lr_scale, critic_lr=1e-2 * lr_scale)
+        summary, losses, replay = ssc.rl_train_vec_ddpg(env, agent, num_chunks=chunks, chunk_steps=K, replay_capacity=1 << 17,
+                                                        seed=9, overlap=overlap)
+        torch.cuda.synchronize()
+        return (summary, torch.stack(losses).cpu(), replay.s.cpu(), replay.a.cpu(), replay.r.cpu(), replay.t.cpu(),
+                agent.actor_flat.cpu(), agent.decaying_ou_action_noise.epsilon, env.stats.cpu())
+
+    a, b = run(False, 0.0), run(True, 0.0)
+    # (records of one chunk arrive in the order the waves claimed ring slots: compare as multisets)
+    assert sorted(a[0].episodes) == sorted(b[0].episodes) and len(a[0].episodes) == 4 * N
+    for x, y in zip(a[1:7], b[1:7]):
+        assert torch.equal(x, y)
+    assert a[7] == b[7] and torch.equal(a[8], b[8])
+
+    c, d, e = run(True, 1.0), run(True, 1.0), run(False, 1.0)
+    assert sorted(c[0].episodes) == sorted(d[0].episodes)
+    for x, y in zip(c[1:7], d[1:7]):
+        assert torch.equal(x, y)
+    assert not torch.equal(c[6], a[6])                                    # the learner did move the actor
+    one = K * N                                                           # records of chunk 0 (ring not yet wrapped)
+    assert torch.equal(c[3][:one], e[3][:one])                            # chunk 0: the initial weights in both modes
+    assert not torch.equal(c[3][one:2 * one], e[3][one:2 * one])          # chunk 1: initial (stale) vs once-trained weights
+
+
 def _fake_chunk(ssc, K, n, done, step0, base=0.0):
     """A TransitionChunk with recognisable content: obs = (global step, env), obs2 = (global step + 1, env)."""
     chunk = ssc.TransitionChunk(2, K, n, "cuda")

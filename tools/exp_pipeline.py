@@ -6,19 +6,21 @@ import torch
 import smartstartcontinuous_amd as ssc
 from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
 
-for n_envs, chunk, iters in [(65536, 256, 50), (65536, 256, 500), (4096, 64, 50), (256, 40, 50)]:
+for n_envs, chunk, iters, overlap in [(65536, 256, 50, False), (65536, 256, 50, True), (65536, 256, 500, False),
+                                      (65536, 256, 500, True), (4096, 64, 50, False), (4096, 64, 50, True), (256, 40, 50, False)]:
     env = ssc.VecEnv("MountainCarContinuous-v0", n_envs, seed=1)
     env.reset()
     agent = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, batch_size=64, num_train_iterations=iters,
                                  actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32, lastLayerTanh=True, seed=3)
-    ssc.rl_train_vec_ddpg(env, agent, num_chunks=2, chunk_steps=chunk, replay_capacity=1 << 20, replay_last_steps=16)
+    ssc.rl_train_vec_ddpg(env, agent, num_chunks=2, chunk_steps=chunk, replay_capacity=1 << 20, replay_last_steps=16,
+                          overlap=overlap)
     torch.cuda.synchronize()
-    n_chunks = 40
+    n_chunks = 200 if iters <= 50 else 40     # the call's set-up (ring, replay, chunk allocation) is ~10 ms: amortise it
     t0 = time.perf_counter()
     summary, losses, replay = ssc.rl_train_vec_ddpg(env, agent, num_chunks=n_chunks, chunk_steps=chunk,
-                                                    replay_capacity=1 << 20, replay_last_steps=16)
+                                                    replay_capacity=1 << 20, replay_last_steps=16, overlap=overlap)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps(dict(n_envs=n_envs, chunk_steps=chunk, train_iters_per_chunk=iters, ms_per_chunk=dt / n_chunks * 1e3,
+    print(json.dumps(dict(n_envs=n_envs, chunk_steps=chunk, overlap=overlap, train_iters_per_chunk=iters, ms_per_chunk=dt / n_chunks * 1e3,
                           env_steps_per_s=n_envs * chunk * n_chunks / dt, learner_iters_per_s=iters * n_chunks / dt,
                           episodes=len(summary.episodes))), flush=True)

@@ -22,6 +22,6 @@ print("launches", len(rows), "span_ms %.3f busy_ms(sum of kernels, streams overl
 names = [r["Kernel_Name"][:50] for r in rows]
 i0 = next(i for i, n in enumerate(names) if "rollout_kernel" in n and i > 40)
 t0 = int(rows[i0]["Start_Timestamp"])
-for r in rows[i0:i0 + 16]:
-    print("%8.1f us  +%7.1f us  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"][:70]))
+for r in rows[i0:i0 + 14]:
+    print("%8.1f us  +%7.1f us  q%s  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", "?"), r["Kernel_Name"][:60]))
 PY
