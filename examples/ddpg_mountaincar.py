@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--episodes", type=int, default=5, help="single: episodes to run")
     ap.add_argument("--envs", type=int, default=4096, help="vec: parallel envs")
     ap.add_argument("--chunks", type=int, default=20, help="vec: rollout chunks of 250 steps")
+    ap.add_argument("--overlap", action="store_true",
+                    help="vec: roll chunk i+1 on a second stream while the learner works on chunk i (one chunk stale)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--save-dir", default=None)
     args = ap.parse_args()
@@ -49,7 +51,7 @@ def main():
         env = ssc.VecEnv("MountainCarContinuousActionX%s-v0" % args.power_scalar, args.envs, seed=args.seed)
         agent = make_agent(ssc.SingleEnvView(ssc.VecEnv(env.spec.id, 1, seed=args.seed)), args.seed)
         summary, losses, replay = ssc.rl_train_vec_ddpg(env, agent, num_chunks=args.chunks, chunk_steps=250,
-                                                        replay_capacity=1 << 20, train_iters=50)
+                                                        replay_capacity=1 << 20, train_iters=50, overlap=args.overlap)
         goals = sum(1 for steps, ret in summary.episodes if ret > 0)
         print("%d env-steps, %d finished episodes (%d reached the goal), %d records in the replay ring, "
               "last critic/actor loss %.4g / %.4g" % (args.envs * args.chunks * 250, len(summary), goals, len(replay),
