@@ -32,6 +32,10 @@
 #include "ssc_device.h"
 #include "ssc_host.h"
 
+#ifndef SSC_DYN_BARRIER_KEEP_LDS_READS
+#define SSC_DYN_BARRIER_KEEP_LDS_READS 1
+#endif
+
 namespace ssc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -553,7 +557,18 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                         }
                         if (f == (GROUP ? X1 : X0)) {  // barrier tl
                             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tl+1 landed
+#if SSC_DYN_BARRIER_KEEP_LDS_READS
+                            // A bare s_barrier: __syncthreads() also waits for lgkmcnt(0), i.e. drains the fragment ring
+                            // (the read issued one instruction ago included) in every tile.  Nothing here needs that: the
+                            // reads of tile tl-1 have all been consumed by MFMAs (LDS reads return in order), the reads in
+                            // flight belong to tile tl, and tile tl+1 is only read after the barrier.  The empty asms keep
+                            // the compiler from moving LDS accesses across it.
+                            asm volatile("" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+#else
                             __syncthreads();
+#endif
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
