@@ -49,6 +49,7 @@ constexpr int kNW = kDynThreads / 64;
 constexpr int kMaxIn = 12;        // network inputs (state + action)
 constexpr int kMaxKS1 = 2;        // layer-1 k-steps of 32 slots: 2 bias slots + 3 per input
 // Diagnostic builds for tools/exp_dyn_clock.py (results are WRONG when set; never in libssc.so):
+//  1 no W2 stream (LDS-DMA never issued), 2 no ring barrier: price the tile-boundary work (tools/gpu_c4_ab.sh)
 // 16 clock stamps: every block overwrites S[32*block .. +31] with {d_memtime, d_memrealtime} of its step loop and
 //    the cycles of its phases, for one wave of each group
 #ifndef SSC_DYN_ABLATE
@@ -553,9 +554,10 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                         const int f0 = GROUP ? X1 + 2 : 1;  // first issue slot after this group's barrier
                         if (f >= f0 && (f - f0) % 4 == 0 && (f - f0) / 4 < PPW) {
                             const int p = (f - f0) / 4;
-                            lds_dma_1k(a2_rsrc, lane * 16, dma_src + p * kNW * 1024, dma_dst + p * kNW * 1024);
+                            if (!(SSC_DYN_ABLATE & 1))   // ablation 1: no W2 stream (wrong results; prices the LDS-DMA issue)
+                                lds_dma_1k(a2_rsrc, lane * 16, dma_src + p * kNW * 1024, dma_dst + p * kNW * 1024);
                         }
-                        if (f == (GROUP ? X1 : X0)) {  // barrier tl
+                        if (!(SSC_DYN_ABLATE & 2) && f == (GROUP ? X1 : X0)) {  // barrier tl (ablation 2: none)
                             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tl+1 landed
 #if SSC_DYN_BARRIER_KEEP_LDS_READS
                             // A bare s_barrier: __syncthreads() also waits for lgkmcnt(0), i.e. drains the fragment ring
