@@ -58,11 +58,10 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def bench_config3(args, torch):
+def bench_config3(args, torch, emit=True):
     """BASELINE configs[2]: 65 536 MountainCar envs + DDPG actor 64-32 (bf16 MFMA) + OU noise, fused."""
     import numpy as np
 
-    from oracle import ssc_oracle as O
     from smartstartcontinuous_amd import ActorPolicy, TransitionChunk, VecEnv
     from smartstartcontinuous_amd.agents import init_actor_weights
     n, K = args.envs_per_gpu, 256
@@ -105,6 +104,7 @@ def bench_config3(args, torch):
                                 "relu/convert + OU Box-Muller per env-step); reported against the HBM roof of its 25 B/step "
                                 "log (the only HBM traffic), with the MFMA-eligible rate beside it"}}
     if not args.no_cpu_baseline:
+        from oracle import ssc_oracle as O               # the checker, timed as the CPU baseline only
         wn = {k: v.numpy() for k, v in w.items()}
         obs = np.random.default_rng(0).uniform(-1, 1, (n, 2)).astype(np.float32)
         pos, vel = obs[:, 0].astype(np.float64) * 0.5 - 0.5, obs[:, 1].astype(np.float64) * 0.05
@@ -117,15 +117,16 @@ def bench_config3(args, torch):
             k += 1
         res["cpu_baseline"] = {"value": n * k / (time.perf_counter() - t0), "unit": "env-steps/s", "cores": 1, "kind": "port",
                                "sample": "numpy fp64 oracle (actor + OU + step), %d envs x %d steps" % (n, k)}
-    print(json.dumps(res), flush=True)
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
 
 
-def bench_config4(args, torch):
+def bench_config4(args, torch, emit=True):
     """BASELINE configs[3]: NND_MB dynamics MLP 2x500 (Pendulum: in 4, out 3), M = 65 536 rows, H = 4:
     MPC sampling + forward simulation (bf16 MFMA) + trajectory scoring."""
     import numpy as np
 
-    from oracle import ssc_oracle as O
     from smartstartcontinuous_amd import navigator as nav
     from smartstartcontinuous_amd.agents import init_dynamics_weights
     from smartstartcontinuous_amd import RandomPolicy, VecEnv
@@ -231,6 +232,7 @@ def bench_config4(args, torch):
                         "kernel_ms_back_to_back": kms_b2b, "kernel_ms_back_to_back_note": "HIP-graph replay of 10 simulation launches with nothing in between",
                         "algorithmic_flop_per_launch": flop_row * M * H}}
     if not args.no_cpu_baseline:
+        from oracle import ssc_oracle as O               # the checker, timed as the CPU baseline only
         Wn, bn = [w.numpy() for w in Ws], [b.numpy() for b in bs]
         m_cpu = 2048
         An = rng.uniform(-2, 2, (m_cpu, H, a))
@@ -241,7 +243,9 @@ def bench_config4(args, torch):
             k += 1
         res["cpu_baseline"] = {"value": m_cpu * H * k / (time.perf_counter() - t0), "unit": "row-steps/s", "cores": 1, "kind": "port",
                                "sample": "numpy fp64 oracle forward sim + scoring, %d rows x H=%d x %d repeats" % (m_cpu, H, k)}
-    print(json.dumps(res), flush=True)
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
 
 
 def profiled_traffic():
@@ -340,6 +344,8 @@ def main():
     ap.add_argument("--series-out", default=None,
                     help="diagnostic: write (phase, start, duration) of every launch of the run to this CSV")
     ap.add_argument("--no-single-step", action="store_true", help="skip the single-step-API (ssc_mc_step) line")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="config 2, one GPU: skip the BASELINE configs[2] / configs[3] lines attached as `other_configs`")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
                     help="BASELINE.json config (1-based): 2 = headline random-policy rollout (default), "
                          "3 = + DDPG actor MFMA, 4 = NND_MB 2x500 forward sim + MPC")
@@ -573,6 +579,24 @@ def main():
             result["single_step_api"] = single_step_api(env, torch)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+        if world == 1 and not args.no_other_configs and n == N_ENVS_PER_GPU:
+            # BASELINE configs[2] (fused actor rollout) and configs[3] (forward simulation + MPC scoring) measured in the
+            # same process AFTER the headline's timed region: the same functions `--config 3` / `--config 4` print as
+            # lines of their own (without their CPU legs), so that the driver's run carries all three
+            import copy
+            import gc
+            chunks.clear()                               # give the headline's buffers back first: the other configurations
+            del env                                      # then start from the allocator state their own runs start from
+            gc.collect()
+            torch.cuda.empty_cache()
+            a2 = copy.copy(args)
+            a2.no_cpu_baseline = True
+            other = {}
+            for name, fn in (("config3", bench_config3), ("config4", bench_config4)):
+                r = fn(a2, torch, emit=False)
+                other[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline") if k in r}
+                other[name]["workload"] = r["config"]["workload"]
+            result["other_configs"] = other
         print(json.dumps(result), flush=True)
     if use_dist:
         if gather is not None and rank == 0:

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 O=gpurun_out/var_$1
 mkdir -p $O
 step() { local name=$1 lim=$2; shift 2; timeout -k 10 $lim "$@"; local rc=$?; echo "[$name] rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] killed at its limit: stopping"; exit 1; fi; }
-step c2 240 bash -c "python3 bench.py --no-cpu-baseline --no-single-step > $O/c2.json 2>/dev/null"
+step c2 240 bash -c "python3 bench.py --no-cpu-baseline --no-single-step --no-other-configs > $O/c2.json 2>/dev/null"
 step c3 240 bash -c "python3 bench.py --config 3 --no-cpu-baseline > $O/c3.json 2>/dev/null"
 step c4 240 bash -c "python3 bench.py --config 4 --no-cpu-baseline > $O/c4.json 2>/dev/null"
 step train 120 bash -c "python3 tools/exp_train.py > $O/train.txt 2>/dev/null"

@@ -3,7 +3,7 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/r02r
 mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 bench.py --force-dist --steps 20 --warmup 5 --settle-launches 200 --steady-launches 0 --no-cpu-baseline --no-single-step > $O/kt.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 bench.py --force-dist --steps 20 --warmup 5 --settle-launches 200 --steady-launches 0 --no-cpu-baseline --no-single-step --no-other-configs > $O/kt.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/r02r/kt/**/*kernel_trace.csv', recursive=True)[0]

@@ -10,7 +10,7 @@ mkdir -p $O
 step() { local name=$1 lim=$2; shift 2; timeout -k 10 $lim "$@"; local rc=$?; echo "[$name] rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] killed at its limit: stopping"; exit 1; fi; }
 line() { python3 -c "import json,sys;d=json.loads(open('$O/$1.json').read().strip().splitlines()[-1]);r=d['roofline'];print('$1', '%.4g' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'kernel %.4f' % r['kernel_ms'], 'median %.4f' % r['kernel_ms_dist']['median'], 'steady', r.get('steady',{}).get('median'), r.get('steady',{}).get('min'))"; }
 ARGS="--config $C --no-cpu-baseline"
-[ "$C" = 2 ] && ARGS="--no-cpu-baseline --no-single-step"
+[ "$C" = 2 ] && ARGS="--no-cpu-baseline --no-single-step --no-other-configs"
 for rep in 1 2; do
   step base$rep 200 bash -c "python3 bench.py $ARGS > $O/c${C}_base$rep.json 2>/dev/null"; line c${C}_base$rep
   for V in "$@"; do

@@ -6,7 +6,7 @@ CFG=${1:-3}
 OUT=${2:-gpurun_out/pmc_c$CFG}
 export TMPDIR=/tmp
 mkdir -p $OUT
-ARGS="--config $CFG --no-cpu-baseline --steps 5 --warmup 2 --steady-launches 0 --no-single-step"
+ARGS="--config $CFG --no-cpu-baseline --steps 5 --warmup 2 --steady-launches 0 --no-single-step --no-other-configs"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA \
   --output-format csv -d $OUT/pmc_a -- python3 bench.py $ARGS > $OUT/pmc_a.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_WR SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES \
