@@ -270,6 +270,41 @@ def profiled_traffic():
     return best
 
 
+def next_rows(torch):
+    """SURVEY.md section 8(f) rows that have a kernel of their own, one figure each, for the default line's
+    `other_configs`: the DDPG learner (batch 64, 64-32 nets, 1000 iterations in one launch) and the SmartStart KDE
+    (2000 candidates x 100 000 buffer states)."""
+    import numpy as np
+
+    import smartstartcontinuous_amd as ssc
+    from smartstartcontinuous_amd import smartstart as SS
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    rng = np.random.default_rng(0)
+    agent = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32,
+                                 lastLayerTanh=True, seed=1, training=False)
+    cap, n_it = 100000, 1000
+    dev = lambda x, dt: torch.as_tensor(x, dtype=dt, device="cuda").contiguous()
+    s, a = dev(rng.uniform(-1.2, 0.6, (cap, 2)), torch.float32), dev(rng.uniform(-1, 1, (cap, 1)), torch.float32)
+    r, t = dev(rng.normal(size=cap), torch.float32), dev(rng.random(cap) < 0.01, torch.uint8)
+    idx = torch.randint(0, cap, (n_it, 64), dtype=torch.int32, device="cuda")
+
+    def timed(fn, warm=2):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    learner_ms = timed(lambda: agent.train_on(s, a, r, t, s, idx, n_it))
+    pts = s[torch.randint(0, cap, (2000,), device="cuda")]
+    wh, norm = SS.kde_scott_bandwidth(s)
+    kde_ms = timed(lambda: SS.kde_evaluate(s, pts, wh, norm), warm=3)
+    return {"ddpg_learner_us_per_iteration": learner_ms / n_it * 1e3,
+            "ddpg_learner_note": "ssc_ddpg_train, batch 64, actor/critic 64-32, %d iterations in one launch" % n_it,
+            "kde_2000x100000_ms": kde_ms}
+
+
 def single_step_api(env, torch, steps=200):
     """the gym-shaped single-step API (`ssc_mc_step`, one launch per env-step,
     actions pre-generated in HBM) on the same 65 536 envs -- launch/L2-bound by construction (1.6 MB per step),
@@ -596,6 +631,7 @@ def main():
                 r = fn(a2, torch, emit=False)
                 other[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline") if k in r}
                 other[name]["workload"] = r["config"]["workload"]
+            other["next_rows"] = next_rows(torch)
             result["other_configs"] = other
         print(json.dumps(result), flush=True)
     if use_dist:
