@@ -42,3 +42,24 @@ for case in range(cases):
     print("case %2d n %5d K %3d t0 %2d steps0 %4d limit %3d power x%.1f id0 %d: %d episodes ended, ok" % (case, n, K, t0, steps0, max_steps, ps, id0, n_done),
           flush=True)
 print("random-policy rollout: %d random configurations ok" % cases)
+
+# Pendulum-v0 (the data-collection env of NND_MB_agent): same sweep, generic replay
+for case in range(cases // 2):
+    n = int(rng.choice([1, 63, 64, 65, 777, 4099]))
+    K = int(rng.choice([1, 3, 4, 5, 8, 40, 129]))
+    seed, id0, t0 = int(rng.integers(0, 2**31)), int(rng.choice([0, 5, 2**33 + 5])), int(rng.integers(0, 50))
+    limit = int(rng.choice([7, 200]))
+    steps0 = int(rng.integers(0, limit))
+    env = ssc.VecEnv("Pendulum-v0", n, seed=seed, env_id0=id0, max_episode_steps=limit)
+    obs0 = env.reset().cpu().numpy()
+    env.steps.fill_(steps0)
+    env.t = t0
+    chunk = env.rollout(K, ssc.RandomPolicy())
+    torch.cuda.synchronize()
+    log = dict(obs=chunk.obs.cpu().numpy(), act=chunk.act.cpu().numpy(), rew=chunk.rew.cpu().numpy(), done=chunk.done.cpu().numpy(),
+               obs2=chunk.obs2.cpu().numpy())
+    res = O.replay_rollout("pend", log, seed, id0, t0, limit, obs0, np.full(n, steps0), O.OracleRandomPolicy(seed, id0, n, -2.0, 2.0))
+    assert res["start_max_err"] == 0 and res["continuity_mismatch"] == 0 and res["done_mismatch"] == 0 and res["max_dact"] == 0, (case, res)
+    assert (res["max_dobs2"] <= [3e-6, 3e-6, 3e-6]).all() and res["max_drew_rel"] <= 2e-5 and res["reset_max_err"] <= 2e-6, (case, res)
+    print("pend case %2d n %4d K %3d t0 %2d steps0 %3d limit %3d id0 %d: ok" % (case, n, K, t0, steps0, limit, id0), flush=True)
+print("Pendulum random-policy rollout: %d random configurations ok" % (cases // 2))
