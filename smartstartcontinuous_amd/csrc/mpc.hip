@@ -32,7 +32,8 @@ struct WalkState {
 
 // One horizon step t of one sample at point pt.  PASS 0: accumulate a.b / b.b into sums[t][2].
 // PASS 1: add the progress and penalty terms to the score using the global G1/G2 of step t.
-template <int PASS>
+// G = lanes that share one problem's reduction (64: a whole wave; 16 / 32: the small-N kernel's sub-wave groups).
+template <int PASS, int G = 64>
 __device__ __forceinline__ void walk_step(const MpcArgs &a, const float *pt, int t, const float *wps, const float *lefts,
                                           int W, const float *inv_r, double *wave_sums, const float *cproj,
                                           WalkState &w) {
@@ -64,11 +65,11 @@ __device__ __forceinline__ void walk_step(const MpcArgs &a, const float *pt, int
         // per-thread [H+1][2] array of doubles, which a runtime t would push into scratch memory
         double v0 = w.live ? (double)ab : 0.0, v1 = w.live ? (double)bb : 0.0;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
+        for (int m = G / 2; m >= 1; m >>= 1) {
             v0 += __shfl_xor(v0, m);
             v1 += __shfl_xor(v1, m);
         }
-        if ((threadIdx.x & 63) == 0) {
+        if ((threadIdx.x & (G - 1)) == 0) {
             wave_sums[t * 2 + 0] = v0;
             wave_sums[t * 2 + 1] = v1;
         }
@@ -88,7 +89,7 @@ __device__ __forceinline__ void walk_step(const MpcArgs &a, const float *pt, int
 }
 
 // One sample's walk, trajectory points read from S step by step (any horizon / state dim)
-template <int PASS>
+template <int PASS, int G = 64>
 __device__ __forceinline__ float mpc_walk(const MpcArgs &a, const float *__restrict__ S, int64_t row, int64_t M,
                                           const float *wps, const float *lefts, int W, int idx0,
                                           const float *inv_r, bool live, double *wave_sums, const float *cproj) {
@@ -99,7 +100,7 @@ __device__ __forceinline__ float mpc_walk(const MpcArgs &a, const float *__restr
         const float *p = S + ((int64_t)t * M + row) * d;
 #pragma unroll
         for (int k = 0; k < SSC_MAX_STATE; ++k) pt[k] = (live && k < d) ? p[k] : 0.0f;
-        walk_step<PASS>(a, pt, t, wps, lefts, W, inv_r, wave_sums, cproj, w);
+        walk_step<PASS, G>(a, pt, t, wps, lefts, W, inv_r, wave_sums, cproj, w);
     }
     return w.score;
 }
@@ -121,51 +122,54 @@ __device__ __forceinline__ void mpc_fetch_pts(const MpcArgs &a, const float *__r
             pts.v[t][k] = (live && k < kPreD && t <= a.H && k < a.d) ? S[((int64_t)t * M + row) * a.d + k] : 0.0f;
 }
 
-template <int PASS>
+template <int PASS, int G = 64>
 __device__ __forceinline__ float mpc_walk_pre(const MpcArgs &a, const PrePts &pp, const float *wps, const float *lefts, int W,
                                               int idx0, const float *inv_r, bool live, double *wave_sums, const float *cproj) {
     const float (&pts)[kPreT][SSC_MAX_STATE] = pp.v;
     WalkState w{idx0, 0.0f, 0.0f, 1.0f, live};
 #pragma unroll
     for (int t = 0; t < kPreT; ++t)
-        if (t <= a.H) walk_step<PASS>(a, pts[t], t, wps, lefts, W, inv_r, wave_sums, cproj, w);
+        if (t <= a.H) walk_step<PASS, G>(a, pts[t], t, wps, lefts, W, inv_r, wave_sums, cproj, w);
     return w.score;
 }
 
 __device__ __forceinline__ bool mpc_can_prefetch(const MpcArgs &a) { return a.H + 1 <= kPreT && a.d <= kPreD; }  // block-uniform
 
-template <int PASS>
+template <int PASS, int G = 64>
 __device__ __forceinline__ float mpc_walk_any(const MpcArgs &a, const PrePts &pp, const float *__restrict__ S, int64_t row,
                                               int64_t M, const float *wps, const float *lefts, int W, int idx0,
                                               const float *inv_r, bool live, double *wave_sums, const float *cproj) {
-    if (mpc_can_prefetch(a)) return mpc_walk_pre<PASS>(a, pp, wps, lefts, W, idx0, inv_r, live, wave_sums, cproj);
-    return mpc_walk<PASS>(a, S, row, M, wps, lefts, W, idx0, inv_r, live, wave_sums, cproj);
+    if (mpc_can_prefetch(a)) return mpc_walk_pre<PASS, G>(a, pp, wps, lefts, W, idx0, inv_r, live, wave_sums, cproj);
+    return mpc_walk<PASS, G>(a, S, row, M, wps, lefts, W, idx0, inv_r, live, wave_sums, cproj);
 }
 
-__device__ __forceinline__ void load_problem(const MpcArgs &a, int p, float *wps, float *lefts, float *inv_r,
-                                             int &W, int &idx0) {
+// The walk of a sample that starts at waypoint idx0 can only touch waypoints idx0-1 ... idx0+H+1 (the index advances
+// by at most one per horizon step, NND_MB_agent.py:600; the penalty segment starts at max(idx-1, 0), :615), so a
+// WINDOW of at most H + 4 waypoints is staged -- not the whole plan (up to ~1000 waypoints per problem in the
+// reference's runs, which the first versions of this file copied into 48 KB of LDS per block).  The walk then runs in
+// window-relative indices: W and idx0 come back relative to the window base max(idx0-1, 0), which leaves every
+// comparison of the walk (idx != W-1, min(idx+1, W-1), max(idx-1, 0)) unchanged.
+constexpr int kWinMax = kMaxH1 + 3;                   // waypoints in a window
+constexpr int kWinFloats = kWinMax * (SSC_MAX_STATE + 1) + SSC_MAX_STATE;   // wps | lefts | inv_r
+
+// lanes `lane` of `nl` cooperating lanes stage problem p's window; the caller synchronises them afterwards
+__device__ __forceinline__ void load_window(const MpcArgs &a, int p, int lane, int nl, float *win, int &W, int &idx0) {
     const int off = a.wp_off[p];
-    W = a.wp_off[p + 1] - off;
-    idx0 = a.cur_idx[p];
-    // up to 4 + 2 loads per thread in flight before the first LDS store (a plain copy loop waits for every load in
-    // turn: W * d / 256 dependent round trips)
-    const float *wsrc = a.wp + (int64_t)off * a.d;
-    const int nw = W * a.d;
-    for (int e0 = threadIdx.x; e0 < nw; e0 += 4 * (int)blockDim.x) {
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = (e0 + q * (int)blockDim.x < nw) ? wsrc[e0 + q * (int)blockDim.x] : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (e0 + q * (int)blockDim.x < nw) wps[e0 + q * (int)blockDim.x] = v[q];
-    }
-    for (int e0 = threadIdx.x; e0 < W; e0 += 2 * (int)blockDim.x) {
-        const float v0 = a.left[off + e0];
-        const float v1 = (e0 + (int)blockDim.x < W) ? a.left[off + e0 + blockDim.x] : 0.0f;
-        lefts[e0] = v0;
-        if (e0 + (int)blockDim.x < W) lefts[e0 + blockDim.x] = v1;
-    }
-    if ((int)threadIdx.x < a.d) inv_r[threadIdx.x] = 1.0f / a.radii[p * a.d + threadIdx.x];
+    const int Wabs = a.wp_off[p + 1] - off;
+    const int iabs = a.cur_idx[p];
+    const int wb = max(iabs - 1, 0);
+    const int cnt = max(min(Wabs - wb, a.H + 4), 0);
+    float *wps = win, *lefts = win + kWinMax * a.d, *inv_r = lefts + kWinMax;
+    const float *wsrc = a.wp + (int64_t)(off + wb) * a.d;
+    for (int e = lane; e < cnt * a.d; e += nl) wps[e] = wsrc[e];
+    for (int e = lane; e < cnt; e += nl) lefts[e] = a.left[off + wb + e];
+    if (lane < a.d) inv_r[lane] = 1.0f / a.radii[p * a.d + lane];
+    W = Wabs - wb;
+    idx0 = iabs - wb;
+}
+
+__device__ __forceinline__ void load_problem(const MpcArgs &a, int p, float *win, int &W, int &idx0) {
+    load_window(a, p, threadIdx.x, blockDim.x, win, W, idx0);
     __syncthreads();
 }
 
@@ -185,7 +189,6 @@ __device__ __forceinline__ void block_argmax(float &score, int &best, float *rs,
             if (rs[w] > score || (rs[w] == score && ri[w] < best)) { score = rs[w]; best = ri[w]; }
 }
 
-// dynamic LDS: reduction scratch | wps [Wmax*d] | lefts [Wmax] | inv_r [8]
 // The kernels below dispatch on the state dimension once and run a copy of their (inlined) body in which `a.d` is a
 // known constant: the walk's distance and projection loops are written over SSC_MAX_STATE = 8 slots with `k < d` guards,
 // which for the 2- and 3-d states of the shipped envs is otherwise two thirds predicated-off work per sample and point.
@@ -197,35 +200,35 @@ __device__ __forceinline__ void block_argmax(float &score, int &best, float *rs,
         else { CALL; }                                              \
     } while (0)
 
-__device__ __forceinline__ void mpc_pass_a_body(MpcArgs a, int Wmax, const float *__restrict__ S, double *__restrict__ partial,
+// Blocks are numbered problem-major in grid.x (block = p * nblk + b): a problem count of 65 536 -- one navigation
+// problem per env at the BASELINE env count -- does not fit gridDim.y.
+__device__ __forceinline__ void mpc_pass_a_body(MpcArgs a, const float *__restrict__ S, double *__restrict__ partial,
                                                 int32_t *__restrict__ ticket) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *red = reinterpret_cast<double *>(smem);  // [4 waves][H+1][2]
-    float *wps = reinterpret_cast<float *>(red + 4 * kMaxH1 * 2);
-    float *lefts = wps + Wmax * a.d;
-    float *inv_r = lefts + Wmax;
-    const int p = blockIdx.y;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ticket[p] = 0;  // pass B elects its last block with it
-    const int n = blockIdx.x * kMpcBlock + threadIdx.x;
+    __shared__ double red[4 * kMaxH1 * 2];  // [4 waves][H+1][2]
+    __shared__ float win[kWinFloats];
+    const int p = blockIdx.x / a.nblk, bx = blockIdx.x - p * a.nblk;
+    if (bx == 0 && threadIdx.x == 0) ticket[p] = 0;  // pass B elects its last block with it
+    const int n = bx * kMpcBlock + threadIdx.x;
     const bool live = n < a.N;
     const int64_t row = (int64_t)p * a.N + (live ? n : 0), M = (int64_t)a.P * a.N;
     PrePts pp;
     if (mpc_can_prefetch(a)) mpc_fetch_pts(a, S, row, M, live, pp);
     int W, idx0;
-    load_problem(a, p, wps, lefts, inv_r, W, idx0);
+    load_problem(a, p, win, W, idx0);
+    const float *wps = win, *lefts = win + kWinMax * a.d, *inv_r = lefts + kWinMax;
     mpc_walk_any<0>(a, pp, S, row, M, wps, lefts, W, idx0, inv_r, live, red + (threadIdx.x >> 6) * kMaxH1 * 2, nullptr);
     __syncthreads();
     for (int e = threadIdx.x; e < (a.H + 1) * 2; e += kMpcBlock) {
         double v = 0.0;
         for (int w = 0; w < kMpcBlock / 64; ++w) v += red[w * kMaxH1 * 2 + e];
-        partial[((int64_t)p * a.nblk + blockIdx.x) * (a.H + 1) * 2 + e] = v;
+        partial[((int64_t)p * a.nblk + bx) * (a.H + 1) * 2 + e] = v;
     }
 }
 
-__global__ __launch_bounds__(kMpcBlock) void mpc_pass_a_kernel(MpcArgs a, int Wmax, const float *__restrict__ S,
+__global__ __launch_bounds__(kMpcBlock) void mpc_pass_a_kernel(MpcArgs a, const float *__restrict__ S,
                                                                double *__restrict__ partial,
                                                                int32_t *__restrict__ ticket) {
-    SSC_MPC_DISPATCH_D(a, mpc_pass_a_body(a, Wmax, S, partial, ticket));
+    SSC_MPC_DISPATCH_D(a, mpc_pass_a_body(a, S, partial, ticket));
 }
 
 // What ssc_mpc_select_action does, folded into pass B's last block (ssc_mpc_score_select)
@@ -241,24 +244,52 @@ struct SelectArgs {
     float low[SSC_MAX_ACT], span[SSC_MAX_ACT];
 };
 
-__device__ __forceinline__ void mpc_pass_b_body(MpcArgs a, int Wmax, int stage_partials, const SelectArgs &sel, const float *__restrict__ S,
+// get_action_with_predicted_states tail (NND_MB_agent.py:339-358) for problem p whose winner is sample `best`, by
+// lanes `lane` of `nl` cooperating lanes; the same draws as mpc_select_kernel.
+__device__ __forceinline__ void mpc_select_epilogue(const MpcArgs &a, const SelectArgs &sel, const float *__restrict__ S,
+                                                    int p, int best, int lane, int nl) {
+    const uint64_t tb = sel.t_base != nullptr ? *sel.t_base : 0;
+    if (lane < sel.act) {
+        const int ai = lane;
+        float first;
+        if (sel.A != nullptr) {
+            first = sel.A[((int64_t)p * a.N + best) * a.H * sel.act + ai];
+        } else {   // flat index h * act + ai = ai < 4: word ai of the sample's first Philox call
+            const int per = (a.H * sel.act + 3) / 4;
+            const u32x4 w = rng_words(sel.s_seed, ((sel.s_pid0 + (uint64_t)p) << 32) + (uint64_t)best,
+                                      (sel.s_t + tb) * (uint64_t)per, TAG_MPC);
+            first = uniform_f32(pick(w, (uint32_t)ai), sel.low[ai], sel.span[ai]);
+        }
+        float g = 0.0f;
+        if (sel.noise != 0.0f) {
+            const u32x4 w = rng_words(sel.seed, sel.pid0 + (uint64_t)p, sel.t + tb, TAG_MPC_NOISE);
+            const u32x4 w2 = rng_words(sel.seed, sel.pid0 + (uint64_t)p, sel.t + tb + ((uint64_t)1 << 40), TAG_MPC_NOISE);
+            g = (ai == 0) ? gaussian_f32(w.x, w.y) : (ai == 1) ? gaussian_f32(w.z, w.w)
+                : (ai == 2) ? gaussian_f32(w2.x, w2.y) : gaussian_f32(w2.z, w2.w);
+        }
+        sel.action[p * sel.act + ai] = first + sel.noise * g;
+    }
+    if (sel.best_path != nullptr) {
+        const int64_t row = (int64_t)p * a.N + best, M = (int64_t)a.P * a.N;
+        for (int e = lane; e < (a.H + 1) * a.d; e += nl) {
+            const int tt = e / a.d, k = e % a.d;
+            sel.best_path[(int64_t)p * (a.H + 1) * a.d + e] = S[((int64_t)tt * M + row) * a.d + k];
+        }
+    }
+}
+
+__device__ __forceinline__ void mpc_pass_b_body(MpcArgs a, int stage_partials, const SelectArgs &sel, const float *__restrict__ S,
                                                 const double *__restrict__ partial, float *__restrict__ scores,
                                                 float *blk_best_score, int32_t *blk_best_idx, int32_t *__restrict__ ticket,
                                                 int32_t *__restrict__ best_idx, float *__restrict__ best_score) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *cproj = reinterpret_cast<float *>(smem);  // [H+1] sum(a.b) / sum(b.b) of the whole problem
-    float *rs = cproj + kMaxH1 + 1;                   // [4] block argmax scratch
-    int *ri = reinterpret_cast<int *>(rs + 4);
-    int *last = ri + 4;
-    float *wps = reinterpret_cast<float *>(last + 2);
-    float *lefts = wps + Wmax * a.d;
-    float *inv_r = lefts + Wmax;
-    // [nblk][H+1][2] doubles behind the floats, rounded up to an 8-byte boundary (the carve above ends on a multiple of 4)
-    double *pstage = stage_partials
-        ? reinterpret_cast<double *>(smem + ((reinterpret_cast<unsigned char *>(inv_r + 8) - smem + 7) & ~(ptrdiff_t)7))
-        : nullptr;
-    const int p = blockIdx.y;
-    const int n = blockIdx.x * kMpcBlock + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [nblk][H+1][2] doubles when stage_partials
+    __shared__ float cproj[kMaxH1 + 1];   // [H+1] sum(a.b) / sum(b.b) of the whole problem
+    __shared__ float rs[4];               // block argmax scratch
+    __shared__ int ri[4], last[2];
+    __shared__ float win[kWinFloats];
+    double *pstage = stage_partials ? reinterpret_cast<double *>(smem) : nullptr;
+    const int p = blockIdx.x / a.nblk, bx = blockIdx.x - p * a.nblk;
+    const int n = bx * kMpcBlock + threadIdx.x;
     const int64_t M = (int64_t)a.P * a.N;
     PrePts pp;
     if (mpc_can_prefetch(a)) mpc_fetch_pts(a, S, (int64_t)p * a.N + (n < a.N ? n : 0), M, n < a.N, pp);
@@ -280,7 +311,8 @@ __device__ __forceinline__ void mpc_pass_b_body(MpcArgs a, int Wmax, int stage_p
         cproj[t] = (float)(g0 / g1);
     }
     int W, idx0;
-    load_problem(a, p, wps, lefts, inv_r, W, idx0);  // ends with __syncthreads()
+    load_problem(a, p, win, W, idx0);  // ends with __syncthreads()
+    const float *wps = win, *lefts = win + kWinMax * a.d, *inv_r = lefts + kWinMax;
     float score = -INFINITY;
     int best = 0x7fffffff;
     if (n < a.N) {
@@ -294,9 +326,11 @@ __device__ __forceinline__ void mpc_pass_b_body(MpcArgs a, int Wmax, int stage_p
     if (threadIdx.x == 0) {
         // write-through (sc1) stores, drained by THIS lane, then a relaxed agent-scope ticket: the last block reads the
         // winners back with sc1 loads after its own add returned (MI355X_MICROARCH.md "Valid forms", first table row).
-        // An acq_rel ticket would add an L2 write-back + invalidate (~3.5 us) to every block's critical path.
-        __hip_atomic_store(&blk_best_score[p * a.nblk + blockIdx.x], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&blk_best_idx[p * a.nblk + blockIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // An acq_rel ticket would add an L2 write-back + invalidate (~3.5 us) to every block's critical path.  This
+        // library is built for gfx950 only (csrc/Makefile: --offload-arch=gfx950); the handoff relies on that
+        // target's agent-scope atomics being coherent at the memory side, see the static_assert below.
+        __hip_atomic_store(&blk_best_score[p * a.nblk + bx], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&blk_best_idx[p * a.nblk + bx], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int tk = __hip_atomic_fetch_add(&ticket[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last[0] = (tk == a.nblk - 1);
@@ -319,48 +353,84 @@ __device__ __forceinline__ void mpc_pass_b_body(MpcArgs a, int Wmax, int stage_p
         ri[0] = best;
     }
     if (sel.action == nullptr) return;
-    // ---- get_action_with_predicted_states tail (NND_MB_agent.py:339-358), same draws as mpc_select_kernel ----
     __syncthreads();
-    best = ri[0];
-    const uint64_t tb = sel.t_base != nullptr ? *sel.t_base : 0;
-    if ((int)threadIdx.x < sel.act) {
-        const int ai = threadIdx.x;
-        float first;
-        if (sel.A != nullptr) {
-            first = sel.A[((int64_t)p * a.N + best) * a.H * sel.act + ai];
-        } else {   // flat index h * act + ai = ai < 4: word ai of the sample's first Philox call
-            const int per = (a.H * sel.act + 3) / 4;
-            const u32x4 w = rng_words(sel.s_seed, ((sel.s_pid0 + (uint64_t)p) << 32) + (uint64_t)best,
-                                      (sel.s_t + tb) * (uint64_t)per, TAG_MPC);
-            first = uniform_f32(pick(w, (uint32_t)ai), sel.low[ai], sel.span[ai]);
-        }
-        float g = 0.0f;
-        if (sel.noise != 0.0f) {
-            const u32x4 w = rng_words(sel.seed, sel.pid0 + (uint64_t)p, sel.t + tb, TAG_MPC_NOISE);
-            const u32x4 w2 = rng_words(sel.seed, sel.pid0 + (uint64_t)p, sel.t + tb + ((uint64_t)1 << 40), TAG_MPC_NOISE);
-            g = (ai == 0) ? gaussian_f32(w.x, w.y) : (ai == 1) ? gaussian_f32(w.z, w.w)
-                : (ai == 2) ? gaussian_f32(w2.x, w2.y) : gaussian_f32(w2.z, w2.w);
-        }
-        sel.action[p * sel.act + ai] = first + sel.noise * g;
-    }
-    if (sel.best_path != nullptr) {
-        const int64_t row = (int64_t)p * a.N + best, M = (int64_t)a.P * a.N;
-        for (int e = threadIdx.x; e < (a.H + 1) * a.d; e += kMpcBlock) {
-            const int tt = e / a.d, k = e % a.d;
-            sel.best_path[(int64_t)p * (a.H + 1) * a.d + e] = S[((int64_t)tt * M + row) * a.d + k];
-        }
-    }
+    mpc_select_epilogue(a, sel, S, p, ri[0], threadIdx.x, kMpcBlock);
 }
 
-__global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int Wmax, int stage_partials, SelectArgs sel, const float *__restrict__ S,
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "mpc.hip: the relaxed ticket handoff of pass B is written for gfx950 (MI355X) only"
+#endif
+
+__global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int stage_partials, SelectArgs sel, const float *__restrict__ S,
                                                                const double *__restrict__ partial,
                                                                float *__restrict__ scores,
                                                                float *blk_best_score, int32_t *blk_best_idx,
                                                                int32_t *__restrict__ ticket,
                                                                int32_t *__restrict__ best_idx,
                                                                float *__restrict__ best_score) {
-    SSC_MPC_DISPATCH_D(a, mpc_pass_b_body(a, Wmax, stage_partials, sel, S, partial, scores, blk_best_score, blk_best_idx, ticket,
+    SSC_MPC_DISPATCH_D(a, mpc_pass_b_body(a, stage_partials, sel, S, partial, scores, blk_best_score, blk_best_idx, ticket,
                                           best_idx, best_score));
+}
+
+// ---- N <= 64 samples per problem: the whole scoring of a problem in ONE launch ---------------------------------------
+// With all samples of a problem inside one wave the two batch-global sums of numerical.py:89-92 are a butterfly over
+// the G = 16 / 32 / 64 lanes that hold the problem, so nothing crosses a block: pass A, the reduction, pass B, the
+// argmax and the selection epilogue run back to back in one kernel, 256 / G problems per block.  This is the shape of
+// "one navigator per env" at the BASELINE env count (P = 65 536 problems x 16-64 candidates); the f64 sums are formed
+// in the same order as the two-pass path forms them for N <= 64 (lanes past N add exact zeros), so scores and
+// winners are bit-identical to it.
+template <int G>
+__device__ __forceinline__ void mpc_small_body(MpcArgs a, const SelectArgs &sel, const float *__restrict__ S,
+                                               float *__restrict__ scores, int32_t *__restrict__ best_idx,
+                                               float *__restrict__ best_score) {
+    constexpr int kGroups = kMpcBlock / G;
+    __shared__ float win[kGroups][kWinFloats];
+    __shared__ double sums[kGroups][kMaxH1 * 2];
+    __shared__ float cproj[kGroups][kMaxH1 + 1];
+    const int g = threadIdx.x / G, n = threadIdx.x & (G - 1);
+    const int pq = blockIdx.x * kGroups + g;
+    const bool has = pq < a.P;
+    const int p = has ? pq : a.P - 1;            // a group past the last problem shadows it and writes nothing
+    const bool live = has && n < a.N;
+    const int64_t row = (int64_t)p * a.N + (n < a.N ? n : 0), M = (int64_t)a.P * a.N;
+    PrePts pp;
+    if (mpc_can_prefetch(a)) mpc_fetch_pts(a, S, row, M, live, pp);
+    int W, idx0;
+    load_window(a, p, n, G, win[g], W, idx0);
+    __syncthreads();
+    const float *wps = win[g], *lefts = win[g] + kWinMax * a.d, *inv_r = lefts + kWinMax;
+    mpc_walk_any<0, G>(a, pp, S, row, M, wps, lefts, W, idx0, inv_r, live, sums[g], nullptr);
+    __syncthreads();
+    for (int t = n; t <= a.H; t += G) cproj[g][t] = (float)(sums[g][t * 2 + 0] / sums[g][t * 2 + 1]);
+    __syncthreads();
+    float score = -INFINITY;
+    int best = 0x7fffffff;
+    if (n < a.N) {   // (a shadow group walks too: uniform control flow, no store)
+        score = mpc_walk_any<1, G>(a, pp, S, row, M, wps, lefts, W, idx0, inv_r, true, nullptr, cproj[g]);
+        if (has) scores[(int64_t)p * a.N + n] = score;
+        best = n;
+        if (isnan(score)) score = -INFINITY;
+    }
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) {
+        const float os = __shfl_xor(score, m);
+        const int oi = __shfl_xor(best, m);
+        if (os > score || (os == score && oi < best)) { score = os; best = oi; }
+    }
+    best = (best == 0x7fffffff) ? 0 : best;       // every lane of the group holds the winner now
+    if (!has) return;
+    if (n == 0) {
+        best_idx[p] = best;
+        if (best_score) best_score[p] = score;
+    }
+    if (sel.action != nullptr) mpc_select_epilogue(a, sel, S, p, best, n, G);
+}
+
+template <int G>
+__global__ __launch_bounds__(kMpcBlock) void mpc_small_kernel(MpcArgs a, SelectArgs sel, const float *__restrict__ S,
+                                                              float *__restrict__ scores, int32_t *__restrict__ best_idx,
+                                                              float *__restrict__ best_score) {
+    SSC_MPC_DISPATCH_D(a, mpc_small_body<G>(a, sel, S, scores, best_idx, best_score));
 }
 
 struct ActBounds {
@@ -480,15 +550,24 @@ static int mpc_score_common(const char *who, const ssc_mpc_problems *pr, const f
     const size_t need = ssc_mpc_score_workspace_bytes(pr->n_problems, pr->n_samples, pr->horizon);
     SSC_REQUIRE(d_workspace && workspace_bytes >= need, "%s: workspace %zu < %zu", who, workspace_bytes, need);
     hipStream_t s = as_stream(stream);
-    // the largest waypoint count decides the LDS carve: read wp_off back?  No host sync is allowed,
-    // so the caller passes packed arrays and we size LDS for the maximum the kernel supports.
-    const int Wmax = (int)((48 * 1024) / ((pr->state_dim + 1) * sizeof(float)));  // 48 KB of waypoints+left
     MpcArgs a;
     a.P = pr->n_problems; a.N = pr->n_samples; a.H = pr->horizon; a.d = pr->state_dim;
     a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx;
     a.theta = pr->theta; a.gamma = pr->gamma; a.hpf = pr->horizontal_penalty_factor;
     a.per_row = pr->per_row_projection;
     a.nblk = (a.N + kMpcBlock - 1) / kMpcBlock;
+    if (a.N <= 64) {
+        // one launch: every problem lives inside one wave (mpc_small_kernel)
+        const int G = a.N <= 16 ? 16 : a.N <= 32 ? 32 : 64;
+        const int64_t blocks = ((int64_t)a.P + kMpcBlock / G - 1) / (kMpcBlock / G);
+        SSC_REQUIRE(blocks <= 0x7fffffff, "%s: too many problems", who);
+        const dim3 grid((unsigned)blocks);
+        if (G == 16) hipLaunchKernelGGL(mpc_small_kernel<16>, grid, dim3(kMpcBlock), 0, s, a, sel, d_S, d_scores, d_best_idx, d_best_score);
+        else if (G == 32) hipLaunchKernelGGL(mpc_small_kernel<32>, grid, dim3(kMpcBlock), 0, s, a, sel, d_S, d_scores, d_best_idx, d_best_score);
+        else hipLaunchKernelGGL(mpc_small_kernel<64>, grid, dim3(kMpcBlock), 0, s, a, sel, d_S, d_scores, d_best_idx, d_best_score);
+        return check_launch(who);
+    }
+    SSC_REQUIRE((int64_t)a.P * a.nblk <= 0x7fffffff, "%s: too many blocks", who);
     char *w = static_cast<char *>(d_workspace);
     double *partial = reinterpret_cast<double *>(w);
     w += align256((size_t)a.P * a.nblk * (a.H + 1) * 2 * sizeof(double));
@@ -497,14 +576,12 @@ static int mpc_score_common(const char *who, const ssc_mpc_problems *pr, const f
     int32_t *bbi = reinterpret_cast<int32_t *>(w);
     w += align256((size_t)a.P * a.nblk * 4);
     int32_t *ticket = reinterpret_cast<int32_t *>(w);
-    const size_t lds_common = (size_t)Wmax * (a.d + 1) * 4 + 8 * 4;
-    const size_t lds_a = 4 * kMaxH1 * 2 * sizeof(double) + lds_common;
     const size_t part_bytes = (size_t)a.nblk * (a.H + 1) * 2 * sizeof(double);
     const int stage_partials = part_bytes <= 32 * 1024;
-    const size_t lds_b = (kMaxH1 + 1 + 4 + 4 + 2) * 4 + lds_common + (stage_partials ? part_bytes + 8 : 0);
-    const dim3 grid(a.nblk, a.P);
-    hipLaunchKernelGGL(mpc_pass_a_kernel, grid, dim3(kMpcBlock), lds_a, s, a, Wmax, d_S, partial, ticket);
-    hipLaunchKernelGGL(mpc_pass_b_kernel, grid, dim3(kMpcBlock), lds_b, s, a, Wmax, stage_partials, sel, d_S, partial, d_scores, bbs, bbi,
+    const size_t lds_b = stage_partials ? part_bytes : 0;
+    const dim3 grid((unsigned)((int64_t)a.P * a.nblk));     // problem-major in x: P may exceed the gridDim.y limit
+    hipLaunchKernelGGL(mpc_pass_a_kernel, grid, dim3(kMpcBlock), 0, s, a, d_S, partial, ticket);
+    hipLaunchKernelGGL(mpc_pass_b_kernel, grid, dim3(kMpcBlock), lds_b, s, a, stage_partials, sel, d_S, partial, d_scores, bbs, bbi,
                        ticket, d_best_idx, d_best_score);
     return check_launch(who);
 }

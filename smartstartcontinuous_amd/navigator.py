@@ -310,8 +310,6 @@ class MpcProblemSet:
             if len(w) < 2:
                 raise ValueError("every problem needs at least 2 waypoints (the reference indexes wp[b+1])")
             off[p + 1] = off[p] + len(w)
-        if max(off[p + 1] - off[p] for p in range(P)) * (d + 1) * 4 > 48 * 1024:
-            raise ValueError("too many waypoints for one problem (LDS carve of the scorer is 48 KB)")
         self.P, self.d = P, d
         self.wp = torch.as_tensor(np.concatenate([np.asarray(w, np.float32) for w in waypoints]), device=self.device)
         self.left = torch.as_tensor(np.concatenate([np.asarray(l, np.float32) for l in lefts]), device=self.device)
@@ -320,6 +318,26 @@ class MpcProblemSet:
         self.radii = torch.as_tensor(np.asarray(radii, np.float32).reshape(P, d), device=self.device).contiguous()
         self.theta, self.gamma, self.hpf = float(theta), float(gamma), float(horizontal_penalty_factor)
         self.per_row = bool(per_row_projection)
+
+    @classmethod
+    def from_packed(cls, wp, left, wp_off, radii, cur_idx, device="cuda", theta=1.0, gamma=0.75,
+                    horizontal_penalty_factor=0.5, per_row_projection=False):
+        """The same problem set from ALREADY PACKED arrays (or device tensors): ``wp`` [sum W_p, d], ``left`` [sum W_p],
+        ``wp_off`` [P + 1] (int32 prefix sums of the waypoint counts), ``radii`` [P, d], ``cur_idx`` [P] -- the form
+        to use for tens of thousands of problems (one navigator per env), where a Python list per problem is the
+        slow part."""
+        self = cls.__new__(cls)
+        self.device = torch.device(device)
+        t = lambda x, dt: torch.as_tensor(x, dtype=dt).to(self.device).contiguous()
+        self.wp, self.left = t(wp, torch.float32), t(left, torch.float32).reshape(-1)
+        self.wp_off, self.cur_idx = t(wp_off, torch.int32).reshape(-1), t(cur_idx, torch.int32).reshape(-1)
+        self.P, self.d = self.wp_off.numel() - 1, self.wp.shape[1]
+        self.radii = t(radii, torch.float32).reshape(self.P, self.d)
+        if self.cur_idx.numel() != self.P or self.left.numel() != self.wp.shape[0]:
+            raise ValueError("packed problem set: inconsistent array sizes")
+        self.theta, self.gamma, self.hpf = float(theta), float(gamma), float(horizontal_penalty_factor)
+        self.per_row = bool(per_row_projection)
+        return self
 
     def as_struct(self, n_samples, horizon):
         s = _ffi.MpcProblems()

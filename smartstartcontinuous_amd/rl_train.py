@@ -260,8 +260,9 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
                                 n_envs=env.n, max_path_len=(env.spec.max_episode_steps or 1000) + 1)
     losses = []
     generations = 0.0   # finished episodes / env.n: epsilon decays once per episode PER ENV (DDPG_Baselines_agent.py:255-258)
-    side = torch.cuda.Stream(env.device)                 # episode-record readback, off the learner's stream
-    rolled = torch.cuda.Event()
+    with torch.cuda.device(env.device):                  # env.device need not be the process's current device
+        side = torch.cuda.Stream(env.device)             # episode-record readback, off the learner's stream
+        rolled = torch.cuda.Event()
 
     def decay(n_finished):
         nonlocal generations
@@ -318,7 +319,7 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
     for _ in range(num_chunks):
         pd = env.policy_desc(agent.as_policy())          # weights are views into the flat parameter arrays
         out = env.rollout(chunk_steps, out=chunk, ring=ring, policy_desc=pd)
-        rolled.record()
+        rolled.record(torch.cuda.current_stream(env.device))
         replay.append_chunk(out, reward_scale=agent.reward_scale, last_steps=replay_last_steps)
         l = agent.train_from(replay, train_iters)
         if l is not None:

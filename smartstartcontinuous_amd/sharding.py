@@ -23,6 +23,8 @@ full stream is available (``g_steps = K``) and is link-bound.
 """
 from __future__ import annotations
 
+import dataclasses
+
 import torch
 import torch.distributed as dist
 
@@ -203,8 +205,10 @@ class TransitionGather:
             self._stats_from_payload = False
         return self._global_stats
 
-    def submit(self, chunk, slot, stats):
-        """Call right after the rollout that filled ``chunk`` was enqueued (same stream).
+    def submit(self, chunk, slot, stats, after=None):
+        """Call right after the rollout that filled ``chunk`` was enqueued (same stream).  ``after``: an event the
+        COLLECTIVE (not the rollout stream) additionally waits for -- e.g. "the learner stream has finished reading
+        recv[slot]" when the consumer runs on a stream of its own.
 
         The pack (one small kernel: 12 us for 26 MB, 1.5 us for 3 MB) runs IN ORDER on the producing stream, so the rollout
         stream never waits on another stream for its 1.7 GB chunk buffer; only the collective runs on
@@ -224,6 +228,8 @@ class TransitionGather:
         ready.record(main)                            # also orders the learner's reads of recv[slot] before the refill
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
+            if after is not None:
+                self.side.wait_event(after)
             self._collective(slot)
             sent = torch.cuda.Event()
             sent.record(self.side)
@@ -268,12 +274,14 @@ def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, lear
     learner trains, and the broadcast lands in ``agent.actor_flat`` -- which the rollout policy reads through views --
     before the next chunk starts.  Every actor idles while the learner trains.
 
-    ``pipelined=True``: nothing on an actor's rollout stream waits for the learner.  Gather AND broadcast run on the
-    side stream; the parameters are double-buffered (generation g, = trained on the chunks <= g, lands in buffer
-    g & 1) and chunk j is rolled with generation j - 2, so the learner trains on chunk j-1 while every rank already
-    rolls chunk j: ONE CHUNK STALE compared with the synchronous loop (which rolls chunk j with generation j - 1).
-    The receive side is double-buffered too (``TransitionGather``), so the gather of chunk j never overwrites what
-    the learner is still appending from chunk j-1.
+    ``pipelined=True``: nothing on a rollout stream waits for the learner -- on the learner rank either: the append
+    and the DDPG iterations run on a LEARNER STREAM of their own (ordered against the receive slots and the parameter
+    buffers by events), gather AND broadcast run on the side stream; the parameters are double-buffered (generation g,
+    = trained on the chunks <= g, lands in buffer g & 1) and chunk j is rolled with generation j - 2, so the learner
+    trains on chunk j-1 while every rank (its own included) already rolls chunk j: ONE CHUNK STALE compared with the
+    synchronous loop (which rolls chunk j with generation j - 1).  The per-chunk critical path is
+    max(T_rollout, T_gather + T_train + T_broadcast) instead of their sum.  The receive side is double-buffered too
+    (``TransitionGather``), and the gather that refills a receive slot waits for the learner stream to have consumed it.
 
     Returns (Summary of THIS rank's finished episodes, losses per chunk [learner only], replay [learner only])."""
     from .replay_buffer import DeviceReplayBuffer
@@ -299,6 +307,10 @@ def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, lear
         wbuf = [agent.actor_flat.clone(), agent.actor_flat.clone()]     # generation g lives in wbuf[g & 1]
         wviews = [_views_like(b, agent.weights) for b in wbuf]
         bcast_done = [None, None]
+        learned = [None, None]                                          # learner stream is done with recv[slot] / wrote wbuf[slot]
+        lstream = torch.cuda.Stream(env.device) if (cuda and rank == learner) else None
+        if lstream is not None:
+            lstream.wait_stream(torch.cuda.current_stream(env.device))  # replay / parameter setup happened on the main stream
 
     def learn(slot):
         gather.wait_received(slot)
@@ -322,17 +334,23 @@ def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, lear
             main = torch.cuda.current_stream(env.device) if cuda else None
             if cuda and bcast_done[slot] is not None:
                 main.wait_event(bcast_done[slot])                       # generation i-2 has landed in wbuf[slot]
-            pol = agent.as_policy()
-            pol = ActorPolicy(wviews[slot], last_layer_tanh=pol.last_layer_tanh, precision=pol.precision, ou_mu=pol.ou_mu,
-                              ou_sigma=pol.ou_sigma, ou_theta=pol.ou_theta, ou_dt=pol.ou_dt, ou_epsilon=pol.ou_epsilon)
+            # the SAME policy the synchronous loop builds (observation clip included), reading generation i-2
+            pol = dataclasses.replace(agent.as_policy(), weights=wviews[slot])
             env.rollout(chunk_steps, out=chunks[slot], ring=ring, policy_desc=env.policy_desc(pol))
-            gather.submit(chunks[slot], slot, env.stats)                # side stream: gather(i) after this rollout
-            if rank == learner:
-                learn(slot)                                             # generation i (main stream waits for gather(i) only)
-                wbuf[slot].copy_(agent.actor_flat)                      # after rollout(i) on this stream: wbuf[slot] is free
+            # side stream: gather(i) after this rollout -- and after the learner stream has read chunk i-2 out of recv[slot]
+            gather.submit(chunks[slot], slot, env.stats, after=learned[slot])
             if cuda:
                 trained = torch.cuda.Event()
-                trained.record(main)
+                if rank == learner:
+                    # learner stream: waits for gather(i) (hence for rollout(i), which read generation i-2 out of
+                    # wbuf[slot]), trains generation i and parks it in wbuf[slot]; the main stream goes on to rollout(i+1)
+                    with torch.cuda.stream(lstream):
+                        learn(slot)
+                        wbuf[slot].copy_(agent.actor_flat)
+                        trained.record(lstream)
+                    learned[slot] = trained
+                else:
+                    trained.record(main)                                # broadcast(i) overwrites wbuf[slot]: after rollout(i)
                 with torch.cuda.stream(gather.side):                    # same order on every rank: gather(i), broadcast(i)
                     gather.side.wait_event(trained)
                     broadcast_flat(wbuf[slot], src=learner, group=group)
@@ -340,6 +358,9 @@ def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, lear
                     ev.record(gather.side)
                     bcast_done[slot] = ev
             else:
+                if rank == learner:
+                    learn(slot)
+                    wbuf[slot].copy_(agent.actor_flat)
                 broadcast_flat(wbuf[slot], src=learner, group=group)
         (ids, lens, rets), _d = ring.drain()
         summary.extend_records(lens, rets)
@@ -349,6 +370,8 @@ def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, lear
             generations -= 1.0
     if pipelined:
         gather.finish()
+        if lstream is not None:
+            torch.cuda.current_stream(env.device).wait_stream(lstream)
         if rank != learner:
             # the actors end with the newest generation they received
             newest = (num_chunks - 1) & 1

@@ -37,7 +37,9 @@ def parse_env_id(env_id, power_scalar=None, max_episode_steps=None):
     'MountainCarContinuous-v0'  : stock gym env, TimeLimit 999
     'MountainCarContinuousActionX<ps>-v0' : Continuous_MountainCarEnv_Editted.get_name()
         (continuous_mountain_car_editted.py:151-152); the examples wrap it in TimeLimit(1000)
-    'Pendulum-v0' : gym 0.10.5, TimeLimit 200 [third-party]
+    'Pendulum-v0' : gym 0.10.5, TimeLimit 200 [third-party]; theta integrates the UNCLIPPED new velocity
+    'Pendulum-v1' : the modern update order (velocity clipped before theta integrates) -- the id BASELINE
+        configs[3] names; VecEnv sets ``params.pend_v1_order`` from the id
     """
     if env_id == "MountainCarContinuous-v0":
         ps = 1.0 if power_scalar is None else power_scalar
@@ -211,6 +213,8 @@ class VecEnv:
         kind, ps, mes, spec_id = parse_env_id(env_id, power_scalar, max_episode_steps)
         self.kind, self.power_scalar, self.n = kind, ps, int(n_envs)
         self.params = _ffi.default_params(kind, ps, mes or 0)
+        if kind == _ffi.SSC_ENV_PENDULUM:
+            self.params.pend_v1_order = 1 if spec_id == "Pendulum-v1" else 0
         self.spec = EnvSpec(spec_id, mes)
         self.env_id0 = int(env_id0)
         self.auto_reset = auto_reset

@@ -194,6 +194,41 @@ def test_pendulum_step_kernel(ssc):
         assert d[: n // 2].all() and not d[n // 2:].any()       # TimeLimit(200) only
 
 
+@pytest.mark.parametrize("env_id,v1", [("Pendulum-v0", False), ("Pendulum-v1", True)])
+def test_pendulum_env_id_selects_update_order(ssc, env_id, v1):
+    """The env built BY ID runs the update order its id names (gym 0.10.5 'v0': theta integrates the unclipped new
+    velocity; modern 'v1', the id BASELINE configs[3] uses: clip first) -- through VecEnv.step and through the fused
+    rollout, with a third of the envs at |theta-dot| close to 8 so that the two orders differ."""
+    n, K, seed, id0 = 1536, 24, 99, 11
+    env = ssc.VecEnv(env_id, n, seed=seed, env_id0=id0)
+    assert env.params.pend_v1_order == int(v1) and env.spec.id == env_id
+    env.reset()
+    env.s1[: n // 3] = torch.where(env.s1[: n // 3] >= 0, 7.9, -7.9)
+    # single-step API
+    th, thd = env.s0.cpu().numpy().copy(), env.s1.cpu().numpy().copy()
+    act = np.where(thd >= 0, 2.0, -2.0).astype(np.float32)
+    env.step(torch.as_tensor(act))
+    torch.cuda.synchronize()
+    rt, rd, _, _ = O.pend_step(th, thd, act, v1_order=v1)
+    wt, _, _, _ = O.pend_step(th, thd, act, v1_order=not v1)
+    assert np.max(np.abs(env.s0.cpu().numpy() - rt)) <= 4e-6 and np.max(np.abs(env.s1.cpu().numpy() - rd)) <= 2e-6
+    assert np.max(np.abs(wt - rt)) > 1e-3                        # the case separates the two orders
+    # fused rollout, teacher forced
+    env.s1[: n // 3] = torch.where(env.s1[: n // 3] >= 0, 7.9, -7.9)
+    obs0 = env.observe().cpu().numpy().copy()
+    steps0 = env.steps.cpu().numpy().astype(np.int64)
+    t0 = env.t
+    chunk = env.rollout(K, ssc.RandomPolicy())
+    torch.cuda.synchronize()
+    pol = O.OracleRandomPolicy(seed, id0, n, -2.0, 2.0)
+    res = O.replay_rollout("pend", _log(chunk), seed, id0, t0, 200, obs0, steps0, pol, v1_order=v1)
+    assert res["start_max_err"] == 0 and res["continuity_mismatch"] == 0 and res["done_mismatch"] == 0, res
+    assert res["max_dact"] == 0 and (res["max_dobs2"] <= [3e-6, 3e-6, 3e-6]).all(), res
+    wrong = O.replay_rollout("pend", _log(chunk), seed, id0, t0, 200, obs0, steps0,
+                             O.OracleRandomPolicy(seed, id0, n, -2.0, 2.0), v1_order=not v1)
+    assert wrong["max_dobs2"][:2].max() > 1e-3, wrong
+
+
 @pytest.mark.parametrize("policy", ["random", "actor_f32", "actor_mfma", "actor_f32_clip", "actor_mfma_clip"])
 def test_rollout_pendulum_teacher_forced(ssc, policy):
     n, K, seed, id0 = 777, 40, 4321, 5

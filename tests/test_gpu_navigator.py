@@ -133,16 +133,21 @@ def test_mpc_score_reference_kats(nav, golden_dir):
         assert ref[int(np.argmax(scores[0]))] >= ref.max() - 1e-3 * np.maximum(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("per_row,P,N", [(False, 5, 1000), (True, 5, 1000), (False, 3, 37), (False, 2, 8192),
-                                         (False, 2, 9001), (True, 2, 9001)])
-def test_mpc_score_multi_problem(nav, per_row, P, N):
-    """N <= 8192 takes the fused one-block-per-problem kernel, larger N the three-pass path."""
+@pytest.mark.parametrize("per_row,P,N,H,Wmax", [(False, 5, 1000, 4, 60), (True, 5, 1000, 4, 60), (False, 3, 37, 4, 60),
+                                                (False, 2, 8192, 4, 60), (False, 2, 9001, 4, 60), (True, 2, 9001, 4, 60),
+                                                (False, 70, 16, 4, 60), (True, 33, 9, 4, 60), (False, 21, 32, 7, 60),
+                                                (False, 19, 33, 9, 60), (False, 9, 64, 4, 60), (False, 7, 65, 4, 60),
+                                                (False, 3, 300, 4, 6000), (False, 5, 48, 12, 6000)])
+def test_mpc_score_multi_problem(nav, per_row, P, N, H, Wmax):
+    """N <= 64: the one-launch kernel (a problem inside one wave, 16 / 32 / 64 lanes); larger N the two-pass path.
+    Only a window of H + 4 waypoints around the current one is staged, so plans of any length work (Wmax = 6000:
+    more than the 48 KB LDS carve of the first versions held)."""
     rng = np.random.default_rng(11)
-    H, d = 4, 2
+    d = 2
     wps, lefts, radii, cur = [], [], [], []
     S = np.empty((H + 1, P, N, d))
     for p in range(P):
-        W = int(rng.integers(2, 60))
+        W = int(rng.integers(2, Wmax))
         wp = np.cumsum(rng.normal(scale=[0.02, 0.004], size=(W, d)), axis=0) + [-0.5, 0.0]
         stds, means = O.path_deltas_stds_and_means_per_dim(wp) if W > 2 else (np.array([0.01, 0.002]), np.array([0.02, 0.004]))
         r = O.radii_calc(means, stds, 1, 1, 1) + 1e-4
@@ -714,3 +719,104 @@ def test_score_select_equals_score_then_select(nav):
         assert torch.equal(sc2, scores) and torch.equal(b2, best) and torch.equal(a2, action) and torch.equal(p2, path)
     with pytest.raises(nav._ffi.SscError):
         nav.mpc_score_select(ps, S, noise_amount=0.0)                # neither A nor a sampling spec
+
+
+def test_mpc_rollout_baseline_config4_one_navigator_per_env(nav):
+    """BASELINE configs[3] AS WRITTEN: Pendulum-v1, NND_MB dynamics MLP 2x500 on the bf16 MFMA, 65 536 envs, every
+    env navigating its own plan (P = 65 536 MPC problems x 16 candidate sequences = 1 Mi simulated rows, H = 4)
+    through rollout(K, 'mpc').  The graph path must equal the step-by-step path bit for bit, and a slice of problems
+    (the first, the last, and a spread in between) is re-derived by the oracle: candidate samples bit-exact, the
+    forward simulation at the bf16 tolerance, the scores of the kernel's own trajectories at 1e-3 (incl. the
+    batch-global projection sums over exactly the 16 samples of a problem), the executed action, the Pendulum-v1
+    step and the waypoint bookkeeping."""
+    import smartstartcontinuous_amd as ssc
+    rng = np.random.default_rng(65536)
+    P, N, H, K, d, seed, pid0 = 65536, 16, 4, 3, 3, 77, 5
+    Ws, bs = make_mlp(rng, (4, 500, 500, 3))
+    Ws[-1] *= 0.05
+    bs[-1] *= 0.05                                              # small deltas: simulated states stay near the plan
+    norm = dict(mean_x=[0.0, 0.0, 0.0], std_x=[0.7, 0.7, 3.0], mean_y=[0.0], std_y=[1.2], mean_z=[0.0, 0.0, 0.0], std_z=[0.05, 0.05, 0.4])
+    # 64 recorded Pendulum paths (oracle rollouts under random torques), tiled over the envs
+    base, W = [], 30
+    for b in range(64):
+        th, thd = rng.uniform(-np.pi, np.pi), rng.uniform(-1, 1)
+        pts = []
+        for _ in range(W):
+            pts.append([np.cos(th), np.sin(th), thd])
+            th, thd, _, _ = O.pend_step(th, thd, rng.uniform(-2, 2), v1_order=True)
+        base.append(np.asarray(pts))
+    radii_b, left_b = [], []
+    for pth in base:
+        stds, means = O.path_deltas_stds_and_means_per_dim(pth)
+        r = O.radii_calc(means, stds, 1, 1, 1) + 1e-3
+        radii_b.append(r); left_b.append(O.distances_left(pth, O.distance_func(r)))
+    which = np.arange(P) % 64
+    wp = np.stack(base)[which].reshape(P * W, d).astype(np.float32)
+    left = np.stack(left_b)[which].reshape(-1).astype(np.float32)
+    radii = np.stack(radii_b)[which].astype(np.float32)
+    off = (np.arange(P + 1) * W).astype(np.int32)
+    cur0 = (np.arange(P) % 5).astype(np.int32)                  # plans in progress: windows start at different waypoints
+
+    def setup(graph):
+        env = ssc.VecEnv("Pendulum-v1", P, seed=seed)
+        assert env.params.pend_v1_order == 1
+        env.reset()
+        start = np.stack(base)[which, cur0]                     # every env sits at its current waypoint
+        env.s0.copy_(torch.as_tensor(np.arctan2(start[:, 1], start[:, 0]), dtype=torch.float32))
+        env.s1.copy_(torch.as_tensor(start[:, 2], dtype=torch.float32))
+        model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=1, precision="bf16_mfma")
+        ps = nav.MpcProblemSet.from_packed(wp, left, off, radii, cur0)
+        batch = nav.NavigatorBatch(model, ps, num_control_samples=N, horizon=H, action_low=[-2.0], action_high=[2.0],
+                                   seed=seed, problem_id0=pid0, steps_before_giving_up_on_waypoint=2)
+        return env, ps, batch, ssc.MpcPolicy(batch, graph=graph)
+
+    eg, pg, bg, polg = setup(True)
+    c1 = eg.rollout(K - 1, polg)
+    cur_before = pg.cur_idx.cpu().numpy().copy()
+    done_before = bg.actions_done.cpu().numpy().copy()
+    c2 = eg.rollout(1, polg)
+    torch.cuda.synchronize()
+    ee, pe, be, pole = setup(False)
+    d1 = ee.rollout(K - 1, pole)
+    d2 = ee.rollout(1, pole)
+    torch.cuda.synchronize()
+    for a, b in ((c1, d1), (c2, d2)):
+        for key in ("obs", "act", "rew", "done", "obs2"):
+            assert torch.equal(getattr(a, key), getattr(b, key)), key
+    assert torch.equal(eg.s0, ee.s0) and torch.equal(eg.s1, ee.s1) and torch.equal(pg.cur_idx, pe.cur_idx)
+    assert torch.equal(bg.actions_done, be.actions_done)
+    assert eg.stats.cpu().numpy()[2] == P * K and eg.t == K
+    assert int(pg.cur_idx.max()) > int(cur0.max())              # plans advanced
+    # ---- oracle slice of the LAST step (t = K - 1) ----
+    fb = bg._fused_buffers(eg.device)
+    Sk = bg._S.cpu().numpy()                                    # [H+1, P*N, d] trajectories of the last step
+    scores_k = fb["scores"].cpu().numpy().reshape(P, N)
+    best_k = fb["best"].cpu().numpy()
+    obs, act, obs2 = (x.cpu().numpy() for x in (c2.obs, c2.act, c2.obs2))
+    nm32 = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in norm.items()}
+    t = K - 1
+    for p in [0, 1, 63, 64, 4097, 32768, 50001, 65534, 65535] + rng.integers(0, P, 23).tolist():
+        s = obs[:, 0, p].astype(np.float64)
+        A = O.mpc_action_samples(seed, pid0 + p, N, H, 1, t, [-2.0], [2.0])
+        rows = slice(p * N, (p + 1) * N)
+        assert np.array_equal(Sk[0, rows], np.broadcast_to(obs[:, 0, p], (N, d)))
+        ref = O.dyn_forward_sim(s, A, nm32, Ws, bs)
+        assert np.max(np.abs(Sk[:, rows] - ref)) <= 3e-2 * max(1.0, np.abs(ref).max()), p
+        b = which[p]
+        sc, best_score, _, _ = O.mpc_scores_add_delta(Sk[:, rows].astype(np.float64), base[b].astype(np.float32),
+                                                      left_b[b].astype(np.float32), radii_b[b].astype(np.float32), int(cur_before[p]))
+        tol = 1e-3 * max(1.0, np.abs(sc).max())
+        assert np.max(np.abs(scores_k[p] - sc)) <= tol, p
+        assert best_k[p] == int(np.argmax(scores_k[p])) and sc[best_k[p]] >= best_score - tol
+        noise = 0.005 * O.mpc_noise_gaussian(seed, np.array([pid0 + p], np.uint64), t, 0)[0]
+        assert abs(A[best_k[p], 0, 0] + noise - act[0, p]) <= 1e-6
+        th = np.arctan2(s[1], s[0])
+        th2, thd2, _, _ = O.pend_step(th, s[2], act[0, p], v1_order=True)
+        assert np.max(np.abs(obs2[:, 0, p] - [np.cos(th2), np.sin(th2), thd2])) <= 3e-6
+        # NND_MB_agent.observe (:360-373)
+        dist = O.distance_func(radii_b[b])
+        i0, da = int(cur_before[p]), int(done_before[p]) + 1
+        dc = dist(obs2[:, 0, p], base[b][i0]); dn = dist(obs2[:, 0, p], base[b][min(i0 + 1, W - 1)])
+        if ((dc <= 1 or dn <= dc) and i0 != W - 1) or (da > 2 and i0 != W - 1):
+            i0, da = i0 + 1, 0
+        assert int(pg.cur_idx[p]) == i0 and int(bg.actions_done[p]) == da, p
