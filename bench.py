@@ -6,6 +6,7 @@ for N>1).
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      # no launcher: starts the N ranks itself (child processes)
 
 One "step" = one ssc_rollout launch: every env of the rank advances CHUNK (=1024) env-steps
 and the whole transition log (25 B per env-step, SoA [K][n]) is written to HBM.  Inputs
@@ -349,6 +350,26 @@ def single_step_api(env, torch, steps=200):
             "note": "ssc_mc_step, one launch per env-step, actions pre-generated in HBM; launch/L2-bound (1.6 MB per step)"}
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N ...` without a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>` as a child process and
+    return its exit code.  Nothing in THIS process has initialised a GPU (or imported torch) at this point."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -384,10 +405,34 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
                     help="BASELINE.json config (1-based): 2 = headline random-policy rollout (default), "
                          "3 = + DDPG actor MFMA, 4 = NND_MB 2x500 forward sim + MPC")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch rehearsal: parse, (self-)spawn the ranks, rendezvous (process group + barrier), print one "
+                         "JSON line on rank 0 and exit before anything touches a GPU -- what the CPU suite runs")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started as plain `python bench.py --gpus N` (the way the N = 1 line is started): become the launcher.  The N
+        # ranks are CHILD processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1), started before this
+        # process has imported torch or touched a GPU; rank 0's JSON line passes through on stdout and the exit code
+        # is the launcher's.
+        return spawn_ranks(args.gpus, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
+
+    if args.dry_run:
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            seen = torch.tensor([1.0])
+            dist.all_reduce(seen)
+            dist.barrier()
+            assert int(seen.item()) == world
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "requested_gpus": args.gpus, "steps": args.steps,
+                              "warmup": args.warmup, "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}), flush=True)
+        return 0
 
     if args.config != 2:
         if int(os.environ.get("WORLD_SIZE", "1")) != 1:
@@ -400,9 +445,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world          # the launcher's world size wins over a stale --gpus
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     n_dev = torch.cuda.device_count()
@@ -584,6 +627,7 @@ def main():
                 "workload": ("MountainCarContinuous-v0, %d batched envs per MI355X, random-policy fused rollout, "
                              "%d env-steps per launch, full transition log to HBM" % (n, K)),
                 "envs_per_gpu": n, "chunk_steps": K, "global_envs": n * world,
+                "settle_launches": args.settle_launches,
                 "parallelism": "env-sharded x%d" % world,
                 "gather": (args.gather if use_dist else "none"),
                 "backend": (("rccl" if args.backend == "nccl" else "gloo (host-staged rehearsal)") if use_dist else "none"),
@@ -654,4 +698,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

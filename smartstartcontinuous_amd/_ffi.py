@@ -11,7 +11,9 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssc.so")
+# SSC_LIB_PATH: development override (A/B of variant builds under tools/, e.g. tools/gpu_variant_ab.sh) -- the
+# package itself always ships and loads the in-tree libssc.so
+LIB_PATH = os.environ.get("SSC_LIB_PATH") or os.path.join(_HERE, "libssc.so")
 
 SSC_OK, SSC_EINVAL, SSC_EUNSUPPORTED, SSC_EHIP = 0, -1, -2, -3
 SSC_ENV_MOUNTAINCAR, SSC_ENV_PENDULUM = 0, 1

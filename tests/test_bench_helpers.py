@@ -46,3 +46,35 @@ def test_traffic_is_reported_only_for_the_sources_it_was_measured_on(tmp_path, m
     (csrc / "rollout.hip").write_bytes(b"// edited\n")          # the kernel changes: every committed figure goes stale
     value, note = bench.profiled_traffic()
     assert value is None and "stale" in note
+
+
+def _run_bench(cmd, extra_env=None):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+def test_bench_starts_its_own_ranks_when_there_is_no_launcher():
+    """Both launch forms of the N > 1 bench reach the rendezvous and rank 0 prints exactly ONE JSON line: (i) plain
+    `python bench.py --gpus 2` (the way the driver starts the N = 1 line) spawns torch.distributed.run as a child
+    process before anything touches a GPU and passes the exit code on; (ii) the torch.distributed.run form.  --dry-run
+    stops after the rendezvous (gloo, CPU), which is as far as a box without GPUs can go."""
+    r, lines = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["dry_run"] and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3
+    port = bench.free_port()
+    r, lines = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                           "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+    # a failing rank makes the self-spawned run fail too (exit code relayed): without --dry-run there is no GPU here
+    import torch
+    if not torch.cuda.is_available():
+        r, lines = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo"])
+        assert r.returncode != 0 and not lines

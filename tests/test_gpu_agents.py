@@ -190,6 +190,67 @@ def test_sharded_actor_learner_loop_world1_equals_vec_loop(ssc):
     assert not torch.equal(agent_b.actor_flat, setup()[1].actor_flat)          # it did learn something
 
 
+def test_sharded_pipelined_loop_clips_observations_like_the_learner(ssc):
+    """rl_train_sharded_ddpg(pipelined=True) on Pendulum-v1 with every env started at |theta-dot| = 7: the actors must
+    see clip(obs, -5, 5) exactly as the learner does (ddpg_editted.py:106-109) -- a hand replay of the pipelined
+    schedule with the agent's own policy (observation clip included) has to reproduce it bit for bit, and the same
+    replay WITHOUT the clip must not (the case binds)."""
+    import dataclasses
+    import os
+    import torch.distributed as dist
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    from smartstartcontinuous_amd.replay_buffer import DeviceReplayBuffer
+    from smartstartcontinuous_amd.sharding import _views_like, rl_train_sharded_ddpg
+    from smartstartcontinuous_amd.vec_env import EpisodeRing
+
+    def setup():
+        env = ssc.VecEnv("Pendulum-v1", 256, seed=13, max_episode_steps=40)
+        env.reset()
+        env.s1.copy_(torch.where(env.s1 >= 0, 7.0, -7.0))
+        one = ssc.SingleEnvView(ssc.VecEnv("Pendulum-v1", 1, seed=13))
+        agent = DDPG_Baselines_agent(one, None, batch_size=64, num_train_iterations=5, actor_h1=64, actor_h2=32,
+                                     critic_h1=64, critic_h2=32, lastLayerTanh=True, seed=4)
+        return env, agent
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29537"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        env_c, agent_c = setup()
+        assert agent_c.as_policy().obs_clip == 5.0
+        _, losses_c, replay_c = rl_train_sharded_ddpg(env_c, agent_c, num_chunks=5, chunk_steps=24, rank=0, world=1,
+                                                      gather_steps=8, replay_capacity=4096, seed=3, pipelined=True)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+    def hand(clip):
+        env_d, agent_d = setup()
+        replay_d = DeviceReplayBuffer(4096, 3, 1, env_d.device, seed=3)
+        gens = {-2: agent_d.actor_flat.clone(), -1: agent_d.actor_flat.clone()}
+        ring_d, finished = EpisodeRing(1 << 16, env_d.device), 0.0
+        for j in range(5):
+            pol = dataclasses.replace(agent_d.as_policy(), weights=_views_like(gens[j - 2], agent_d.weights))
+            if not clip:
+                pol.obs_clip = 0.0
+            chunk = env_d.rollout(24, pol, ring=ring_d)
+            tail = ssc.TransitionChunk.from_columns(chunk.obs[:, -8:], chunk.act[-8:], chunk.rew[-8:], chunk.obs2[:, -8:], chunk.done[-8:])
+            replay_d.append_chunk(tail, reward_scale=agent_d.reward_scale)
+            agent_d.train_from(replay_d, None)
+            gens[j] = agent_d.actor_flat.clone()
+            (_, lens, _), _ = ring_d.drain()
+            finished += len(lens) / float(env_d.n)
+            while finished >= 1.0:
+                agent_d.decaying_ou_action_noise.reduce_epsilon()
+                finished -= 1.0
+        return env_d, agent_d, replay_d
+    env_d, agent_d, replay_d = hand(True)
+    assert torch.equal(replay_c.s, replay_d.s) and torch.equal(replay_c.a, replay_d.a)
+    assert torch.equal(agent_c.actor_flat, agent_d.actor_flat) and torch.equal(env_c.s0, env_d.s0)
+    assert float(replay_d.s[:, 2].abs().max()) > 5.0                       # the clip had something to do
+    _, _, replay_u = hand(False)
+    assert not torch.equal(replay_c.a, replay_u.a)
+
+
 def test_navigator_loads_and_saves_training_data_like_the_reference(ssc, golden_dir, tmp_path):
     """load_existing_training_data / save_training_data (NND_MB_agent.py:203-213, :289-296): the directory layout of
     the reference (<models>/NND_MB_agent/<name>/training_data/*.npy), so its shipped data sets load unchanged."""

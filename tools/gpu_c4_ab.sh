@@ -1,6 +1,6 @@
 #!/bin/bash
 # config-4 bench line (MPC step, simulation kernel) for the committed library and variant builds, interleaved:
-#   tools/gpu_c4_ab.sh <variant.so> [...]; then the navigator parity tests with the LAST variant in place of libssc.so
+#   tools/gpu_c4_ab.sh <variant.so> [...]; then the navigator parity tests with the LAST variant loaded through SSC_LIB_PATH (libssc.so itself is never overwritten)
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/c4_ab; mkdir -p $O
@@ -14,5 +14,4 @@ for rep in 1 2 3; do
   done
 done
 for V in "$@"; do :; done
-cp $V smartstartcontinuous_amd/libssc.so
-step pytest 500 bash -c "python3 -m pytest tests/test_gpu_navigator.py -x -q -m gpu > $O/pytest.log 2>&1; tail -4 $O/pytest.log"
+step pytest 500 bash -c "SSC_LIB_PATH=$PWD/$V python3 -m pytest tests/test_gpu_navigator.py -x -q -m gpu > $O/pytest.log 2>&1; tail -4 $O/pytest.log"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of variant libraries against the committed one on the same box:
 #   tools/gpu_variant_ab.sh <config: 2|3> <variant.so> [<variant2.so> ...]
-# (bench line base / variants, interleaved twice; then the rollout parity tests with the LAST variant in place of libssc.so)
+# (bench line base / variants, interleaved twice; then the rollout parity tests with the LAST variant loaded through SSC_LIB_PATH (libssc.so itself is never overwritten))
 set -u
 export TMPDIR=/tmp
 C=$1; shift
@@ -19,5 +19,4 @@ for rep in 1 2; do
   done
 done
 for V in "$@"; do :; done
-cp $V smartstartcontinuous_amd/libssc.so
-step pytest 500 bash -c "python3 -m pytest tests/test_gpu_env.py tests/test_gpu_actor_pendulum.py tests/test_gpu_dataset.py -x -q -m gpu > $O/pytest.log 2>&1; tail -4 $O/pytest.log"
+step pytest 500 bash -c "SSC_LIB_PATH=$PWD/$V python3 -m pytest tests/test_gpu_env.py tests/test_gpu_actor_pendulum.py tests/test_gpu_dataset.py -x -q -m gpu > $O/pytest.log 2>&1; tail -4 $O/pytest.log"
