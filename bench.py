@@ -249,6 +249,75 @@ def bench_config4(args, torch, emit=True):
     return res
 
 
+def bench_config4_envs(args, torch, emit=True, P=N_ENVS_PER_GPU, N=16, H=4, K=40):
+    """BASELINE configs[3] read literally: Pendulum-v1, 65 536 ENVS, every env navigated by its own MPC problem
+    (NND_MB 2x500, P = 65 536 problems x N candidate sequences = P*N simulated rows per env-step) through
+    VecEnv.rollout(K, MpcPolicy): per env-step 3 graph-replayed launches (forward simulation with in-kernel sampling,
+    one-launch scoring, fused action / env.step / log / waypoint bookkeeping)."""
+    import numpy as np
+
+    from smartstartcontinuous_amd import MpcPolicy, RandomPolicy, TransitionChunk, VecEnv
+    from smartstartcontinuous_amd import collect_samples as cs
+    from smartstartcontinuous_amd import navigator as nav
+    from smartstartcontinuous_amd import numerical as num
+    from smartstartcontinuous_amd.agents import init_dynamics_weights
+    d, a = 3, 1
+    denv = VecEnv("Pendulum-v1", 64, seed=1234)
+    dchunk = denv.rollout(200, RandomPolicy())
+    ts = cs.dataset_from_chunk(dchunk)
+    (mx, sx), (my, sy), (mz, sz) = (cs.column_stats(v) for v in (ts.dataX, ts.dataY, ts.dataZ))
+    host = lambda t: t.cpu().numpy()
+    norm = dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz))
+    Ws, bs = init_dynamics_weights(d + a, d, 2, 500, torch.Generator().manual_seed(1234))
+    model = nav.DynamicsModel(Ws, bs, norm, d, a, precision="bf16_mfma")
+    # plans: the 64 recorded 200-state paths, one per env (env p follows path p mod 64)
+    paths = dchunk.obs[:, :200, :].permute(2, 1, 0).double().cpu().numpy()           # [64, 200, 3]
+    radii, lefts = [], []
+    for pth in paths:
+        stds, means = num.path_deltas_stds_and_means_per_dim(pth)
+        r = num.radii_calc(means, stds, 1, 1, 1)
+        radii.append(r)
+        lefts.append(num.distances_left(pth, num.elliptical_euclidean_distance_function_generator(r)))
+    which = np.arange(P) % 64
+    W = paths.shape[1]
+    ps = nav.MpcProblemSet.from_packed(paths[which].reshape(P * W, d), np.stack(lefts)[which].reshape(-1),
+                                       (np.arange(P + 1) * W).astype(np.int32), np.stack(radii)[which], np.zeros(P, np.int32))
+    env = VecEnv("Pendulum-v1", P, seed=1234)
+    env.reset()
+    start = paths[which, 0]
+    env.s0.copy_(torch.as_tensor(np.arctan2(start[:, 1], start[:, 0]), dtype=torch.float32))
+    env.s1.copy_(torch.as_tensor(start[:, 2], dtype=torch.float32))
+    batch = nav.NavigatorBatch(model, ps, num_control_samples=N, horizon=H, action_low=[-2.0], action_high=[2.0], seed=1234)
+    pol = MpcPolicy(batch)
+    chunk = TransitionChunk(d, K, P, env.device)
+    env.rollout(K, pol, out=chunk)                         # captures the graph, warms up
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(1, args.steps // 4)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        env.rollout(K, pol, out=chunk)
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms_step = el / (reps * K) * 1e3
+    flop_row = 2.0 * ((d + a) * 500 + 500 * 500 + 500 * d)
+    res = {"metric": "env-steps/sec, Pendulum-v1 + NND_MB 2x500 MPC navigation, 65 536 envs (one navigator per env)",
+           "value": P / (ms_step * 1e-3), "unit": "env-steps/s", "row_steps_per_s": P * N * H / (ms_step * 1e-3),
+           "n_gpus": 1, "steps": reps * K, "ms_per_step": ms_step, "gpu_ms_per_step": e0.elapsed_time(e1) / (reps * K),
+           "higher_is_better": True, "dtype": "bf16 (MFMA), fp32 accumulate", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[3] as written: Pendulum-v1, %d envs x %d candidates = %d rows, horizon %d, "
+                                  "num_fc_layers 2, depth 500; rollout(K=%d, 'mpc'), 3 launches per env-step from a HIP graph; "
+                                  "200-waypoint plans" % (P, N, P * N, H, K)},
+           "roofline": {"bound": "mfma", "achieved": flop_row * P * N * H / (ms_step * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": flop_row * P * N * H / (ms_step * 1e-3) / 1e12 / 2500.0, "traffic": None,
+                        "note": "whole env-step (simulate + score + act/step/log) against the bf16 MFMA roof of its simulated rows"}}
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
+
+
 def profiled_traffic():
     """HBM bytes per launch of the rollout kernel from the committed rocprofv3 PMC passes
     (profiles/<tag>/traffic.json: WRITE_SIZE*1024 + 2*FETCH_SIZE*1024, gfx950 correction) -- the counters cannot
@@ -439,7 +508,10 @@ def main():
             sys.exit("--config 3/4 are single-GPU measurements")
         if not torch.cuda.is_available():
             sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-        return (bench_config3 if args.config == 3 else bench_config4)(args, torch)
+        if args.config == 4:
+            bench_config4(args, torch)
+            return bench_config4_envs(args, torch) and 0
+        return bench_config3(args, torch) and 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -672,7 +744,7 @@ def main():
             a2.no_cpu_baseline = True
             other = {}
             # (a failure in one of these legs must not cost the headline line: it is reported in place of the leg)
-            for name, fn in (("config3", bench_config3), ("config4", bench_config4)):
+            for name, fn in (("config3", bench_config3), ("config4", bench_config4), ("config4_per_env", bench_config4_envs)):
                 try:
                     r = fn(a2, torch, emit=False)
                     other[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline") if k in r}

@@ -390,7 +390,7 @@ int ssc_ucb_argmax(int64_t m, const float *d_value, const float *d_pdf, float al
 typedef struct ssc_ddpg_desc {
     int32_t obs_dim, act_dim, actor_h1, actor_h2, critic_h1, critic_h2;
     int32_t last_layer_tanh;
-    int32_t batch_size;                                   /* 64 */
+    int32_t batch_size;                                   /* 64 in every shipped run; 1..4096 through ssc_ddpg_train_ws */
     float *actor, *critic, *target_actor, *target_critic; /* device, flat */
     float *adam_m_actor, *adam_v_actor, *adam_m_critic, *adam_v_critic; /* device, flat, zero-initialised */
     int32_t *adam_t;                                      /* device [2]: MpiAdam step counters (actor, critic) */
@@ -440,8 +440,9 @@ int ssc_replay_append(const ssc_replay_ring *ring, const ssc_transition_log *log
 
 /* ReplayBuffer.sample_batch (replay_buffer.py:79-91: random.sample, i.e. uniform WITHOUT replacement
  * inside a batch) for n_batches batches at once: d_idx [n_batches][batch_size] row indices in
- * [0, size), size = min(records appended, capacity) >= batch_size, batch_size <= 64.
- * Philox(seed; counter0 + batch, attempt << 8 | slot, TAG_REPLAY); oracle: replay_sample_indices. */
+ * [0, size), size = min(records appended, capacity) >= batch_size, batch_size <= 4096.
+ * Philox(seed; counter0 + batch, attempt << 8 | slot, TAG_REPLAY) for batch_size <= 64 (one wave per batch),
+ * attempt << 16 | slot above (one workgroup per batch); oracle: replay_sample_indices. */
 int ssc_replay_sample(uint64_t seed, uint64_t counter0, int64_t size, int32_t n_batches, int32_t batch_size,
                       int32_t *d_idx, ssc_stream_t stream);
 
@@ -475,6 +476,19 @@ int ssc_replay_episode_path(const ssc_replay_ring *ring, int64_t count, int64_t 
  * with the byte count in ssc_last_error(). */
 int ssc_ddpg_train(const ssc_ddpg_desc *ddpg, const ssc_replay_view *replay, const int32_t *d_batch_idx,
                    int32_t n_iters, float *d_losses, ssc_stream_t stream);
+
+/* The same training step for ANY layer sizes and batch sizes 1..4096 -- the reference's own grid of actor / critic
+ * 64-32, 128-64, 200-100 (DDPG_Baselines_agent.py:86-92, data/ddpg_baselines_summaries/hidden_layer_size_experiment/)
+ * and the large batches of a vectorised actor-learner loop.  Shapes the single-workgroup kernels cover (batch 64,
+ * layers <= 64) still run there; everything else runs multi-workgroup: the batch is tiled over workgroups of 16 rows
+ * (whole forward / backward chain per tile, weights streamed from L2), per-workgroup gradient partials are summed in
+ * workgroup order by a second launch that also applies MpiAdam and the soft target update -- two launches per
+ * iteration, bitwise reproducible.  d_workspace: ssc_ddpg_train_workspace_bytes(ddpg) bytes of device memory (the
+ * gradient partials; caller-owned like every buffer).  SSC_EUNSUPPORTED only when a 16-row tile's activations exceed
+ * the 160 KB of LDS (roughly: 2 h1 + 2 h2 of the actor + 2 h1 + 4 h2 of the critic > 2500 units). */
+size_t ssc_ddpg_train_workspace_bytes(const ssc_ddpg_desc *ddpg);
+int ssc_ddpg_train_ws(const ssc_ddpg_desc *ddpg, const ssc_replay_view *replay, const int32_t *d_batch_idx,
+                      int32_t n_iters, float *d_losses, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Dynamics-model training step

@@ -165,6 +165,9 @@ _SIGNATURES = {
     "ssc_replay_episode_path": (c_int, [POINTER(ReplayRing), c_int64, c_int64, c_void_p, c_int32, c_void_p, c_void_p,
                                         c_void_p]),
     "ssc_ddpg_train": (c_int, [POINTER(DdpgDesc), POINTER(ReplayView), c_void_p, c_int32, c_void_p, c_void_p]),
+    "ssc_ddpg_train_workspace_bytes": (c_size_t, [POINTER(DdpgDesc)]),
+    "ssc_ddpg_train_ws": (c_int, [POINTER(DdpgDesc), POINTER(ReplayView), c_void_p, c_int32, c_void_p, c_void_p, c_size_t,
+                                  c_void_p]),
     "ssc_dataset_scan_workspace_bytes": (c_size_t, [c_int64]),
     "ssc_dataset_scan": (c_int, [POINTER(TransitionLog), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),

@@ -326,9 +326,16 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         rv = _ffi.ReplayView(s.data_ptr(), a.data_ptr(), r.data_ptr(), t.data_ptr(), s2.data_ptr(), s.shape[0])
         losses = torch.empty((n_iters, 2), dtype=torch.float32, device=self.device)
         d = self.ddpg_desc()
+        if tuple(batch_idx.shape) != (n_iters, self.batch_size):
+            raise ValueError(f"batch_idx must be [{n_iters}, {self.batch_size}], got {tuple(batch_idx.shape)}")
         with torch.cuda.device(self.device):
-            _ffi.check(self.lib.ssc_ddpg_train(ctypes.byref(d), ctypes.byref(rv), _ffi.ptr(batch_idx), n_iters,
-                                               _ffi.ptr(losses), _stream()))
+            # gradient partials of the multi-workgroup path (layers wider than 64 / batch != 64); kept with the agent
+            need = self.lib.ssc_ddpg_train_workspace_bytes(ctypes.byref(d))
+            ws = getattr(self, "_train_ws", None)
+            if ws is None or ws.numel() < need:
+                ws = self._train_ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            _ffi.check(self.lib.ssc_ddpg_train_ws(ctypes.byref(d), ctypes.byref(rv), _ffi.ptr(batch_idx), n_iters,
+                                                  _ffi.ptr(losses), _ffi.ptr(ws), ws.numel(), _stream()))
         return losses
 
     def train_from(self, device_replay, n_iters=None):

@@ -1,5 +1,5 @@
-// ddpg_device.h -- pieces shared by the two DDPG learner kernels (ddpg_train.hip: step interpreter for any layer
-// sizes; ddpg_train_fixed.hip: the shipped 64-32 shape compiled straight-line).
+// ddpg_device.h -- pieces shared by the DDPG learner kernels (ddpg_train.hip: single-workgroup step interpreter;
+// ddpg_train_fixed.hip: the shipped 64-32 shape compiled straight-line; ddpg_train_wide.hip: any shape, multi-workgroup).
 #pragma once
 
 #include "ssc_device.h"
@@ -38,5 +38,10 @@ struct AdamCfg {
 bool ddpg_fixed_shape(const ssc_ddpg_desc *d);
 int ddpg_train_fixed(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
                      float *d_losses, hipStream_t stream);
+
+// ddpg_train_wide.hip: any layer sizes / batch sizes, batch tiled over workgroups
+size_t ddpg_wide_workspace_bytes(const ssc_ddpg_desc *d);
+int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
+                    float *d_losses, void *d_workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace ssc

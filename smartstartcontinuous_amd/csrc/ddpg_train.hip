@@ -649,32 +649,54 @@ struct StepList {
 
 using namespace ssc;
 
+extern "C" size_t ssc_ddpg_train_workspace_bytes(const ssc_ddpg_desc *d) {
+    if (d == nullptr || d->batch_size < 1 || d->batch_size > 4096 || d->obs_dim < 1 || d->act_dim < 1 || d->actor_h1 < 1 ||
+        d->actor_h2 < 1 || d->critic_h1 < 1 || d->critic_h2 < 1)
+        return 256;
+    return ddpg_wide_workspace_bytes(d);
+}
+
+// Which kernel serves a shape: the shipped 64-32 / batch-64 shape has a kernel of its own (ddpg_train_fixed.hip); other
+// nets <= 64 wide at batch 64 run the single-workgroup step interpreter below; everything else -- wider layers (the
+// reference's 128-64 and 200-100 grid), other batch sizes -- the multi-workgroup kernels of ddpg_train_wide.hip, which
+// need a workspace.  SSC_DDPG_INTERPRETER=1 / SSC_DDPG_WIDE=1 force a path (A/B measurements, and the tests that
+// check every path against the oracle on the shipped shape).
+static int ddpg_train_any(const char *who, const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx,
+                          int32_t n_iters, float *d_losses, void *d_ws, size_t ws_bytes, bool have_ws, ssc_stream_t stream);
+
+extern "C" int ssc_ddpg_train_ws(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
+                                 float *d_losses, void *d_workspace, size_t workspace_bytes, ssc_stream_t stream) {
+    return ddpg_train_any("ssc_ddpg_train_ws", d, rp, d_batch_idx, n_iters, d_losses, d_workspace, workspace_bytes, true, stream);
+}
+
 extern "C" int ssc_ddpg_train(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx,
                               int32_t n_iters, float *d_losses, ssc_stream_t stream) {
-    SSC_REQUIRE(d && rp, "ssc_ddpg_train: NULL descriptor");
-    SSC_REQUIRE(n_iters >= 0, "ssc_ddpg_train: n_iters < 0");
-    if (d->batch_size != kB)
-        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: batch_size %d (only 64, the value of every shipped run)",
-                         d->batch_size);
+    return ddpg_train_any("ssc_ddpg_train", d, rp, d_batch_idx, n_iters, d_losses, nullptr, 0, false, stream);
+}
+
+static int ddpg_train_any(const char *who, const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx,
+                          int32_t n_iters, float *d_losses, void *d_ws, size_t ws_bytes, bool have_ws, ssc_stream_t stream) {
+    SSC_REQUIRE(d && rp, "%s: NULL descriptor", who);
+    SSC_REQUIRE(n_iters >= 0, "%s: n_iters < 0", who);
+    SSC_REQUIRE(d->batch_size >= 1, "%s: batch_size %d", who, d->batch_size);
     SSC_REQUIRE(d->obs_dim >= 1 && d->obs_dim <= SSC_MAX_STATE && d->act_dim >= 1 && d->act_dim <= SSC_MAX_ACT,
-                "ssc_ddpg_train: obs_dim/act_dim out of range");
+                "%s: obs_dim/act_dim out of range", who);
     SSC_REQUIRE(d->actor_h1 >= 1 && d->actor_h2 >= 1 && d->critic_h1 >= 1 && d->critic_h2 >= 1,
-                "ssc_ddpg_train: bad hidden sizes");
-    if (d->actor_h1 > 64 || d->actor_h2 > 64 || d->critic_h1 > 64 || d->critic_h2 > 64)
-        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: hidden layers wider than 64 units (the batch's activations "
-                                           "and the parameters must fit the 160 KB of LDS)");
+                "%s: bad hidden sizes", who);
+    const char *force_i = getenv("SSC_DDPG_INTERPRETER"), *force_w = getenv("SSC_DDPG_WIDE");
+    const bool want_interp = force_i && force_i[0] == '1', want_wide = force_w && force_w[0] == '1' && have_ws;
+    const bool narrow = d->batch_size == kB && d->actor_h1 <= 64 && d->actor_h2 <= 64 && d->critic_h1 <= 64 && d->critic_h2 <= 64;
+    if (!have_ws && !narrow)
+        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: batch_size %d / hidden layers wider than 64 run the multi-workgroup "
+                                           "kernels, which need a workspace: call ssc_ddpg_train_ws", d->batch_size);
     if (n_iters == 0) return SSC_OK;
     SSC_REQUIRE(d->actor && d->critic && d->target_actor && d->target_critic && d->adam_m_actor && d->adam_v_actor &&
                     d->adam_m_critic && d->adam_v_critic && d->adam_t,
-                "ssc_ddpg_train: NULL parameter / optimiser pointer");
+                "%s: NULL parameter / optimiser pointer", who);
     SSC_REQUIRE(rp->s && rp->a && rp->r && rp->t && rp->s2 && rp->capacity > 0 && d_batch_idx,
-                "ssc_ddpg_train: NULL replay pointer");
-    // the shipped shape has a kernel of its own (ddpg_train_fixed.hip); SSC_DDPG_INTERPRETER=1 keeps it on the step
-    // interpreter below (A/B measurements, and the tests that check both against the oracle)
-    if (ddpg_fixed_shape(d)) {
-        const char *force = getenv("SSC_DDPG_INTERPRETER");
-        if (!(force && force[0] == '1')) return ddpg_train_fixed(d, rp, d_batch_idx, n_iters, d_losses, as_stream(stream));
-    }
+                "%s: NULL replay pointer", who);
+    if (!narrow || want_wide) return ddpg_train_wide(d, rp, d_batch_idx, n_iters, d_losses, d_ws, ws_bytes, as_stream(stream));
+    if (ddpg_fixed_shape(d) && !want_interp) return ddpg_train_fixed(d, rp, d_batch_idx, n_iters, d_losses, as_stream(stream));
 
     const NetDims A{d->obs_dim, d->actor_h1, d->actor_h2, d->act_dim, 0};
     const NetDims C{d->obs_dim, d->critic_h1, d->critic_h2, 1, d->act_dim};
@@ -704,8 +726,11 @@ extern "C" int ssc_ddpg_train(const ssc_ddpg_desc *d, const ssc_replay_view *rp,
     const int TA = al4(p), TC = al4(TA + A.total()), TTA = al4(TC + C.total()), TTC = al4(TTA + A.total());
     g.off_theta[0] = TA; g.off_theta[1] = TC; g.off_theta[2] = TTA; g.off_theta[3] = TTC;
     p = TTC + C.total();
-    if ((size_t)p * sizeof(float) > 160 * 1024 - 128)   // 64 B of static LDS (loss partials, Adam step sizes)
-        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: these layer sizes need %zu B of LDS", (size_t)p * sizeof(float));
+    if ((size_t)p * sizeof(float) > 160 * 1024 - 128) { // 64 B of static LDS (loss partials, Adam step sizes)
+        if (have_ws) return ddpg_train_wide(d, rp, d_batch_idx, n_iters, d_losses, d_ws, ws_bytes, as_stream(stream));
+        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: these layer sizes need %zu B of LDS on the single-workgroup path; "
+                                           "call ssc_ddpg_train_ws", (size_t)p * sizeof(float));
+    }
     // ---- the steps of one iteration ----------------------------------------------------------------------------
     StepList L(g);
     L.add(ST_GATHER, true);

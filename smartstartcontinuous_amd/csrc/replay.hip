@@ -234,6 +234,80 @@ __global__ __launch_bounds__(64) void replay_sample_kernel(uint64_t seed, uint64
     if (slot) idx[(int64_t)blockIdx.x * batch + lane] = (int32_t)val;
 }
 
+// Batches of 65 .. 4096 indices (the multi-workgroup learner's batch sizes): ONE workgroup per batch, slot s served by
+// thread s % 1024, the same accept / reject rule as above decided through an open-addressing hash set in LDS
+// (keys[h] = index + 1 claimed by atomicCAS; owners[h] = (round << 12 | slot) lowered with atomicMin -- of all the slots
+// that want an index in a round the LOWEST keeps it whatever the thread order, and an index accepted in an earlier
+// round cannot be taken over).  The slot rides in 16 bits of the Philox counter here (attempt << 16 | slot): batches of
+// at most 64 keep the 8-bit form of the one-wave kernel, so their streams are unchanged.  Oracle: replay_sample_indices.
+constexpr int kSampleBlock = 1024;
+__global__ __launch_bounds__(kSampleBlock) void replay_sample_big_kernel(uint64_t seed, uint64_t counter0, int64_t size, int32_t batch,
+                                                                         int32_t tsize, int32_t *__restrict__ idx) {
+    constexpr int SPT = 4;
+    extern __shared__ uint32_t table[];   // keys [tsize] | owners [tsize]
+    uint32_t *keys = table, *owners = table + tsize;
+    __shared__ int n_unresolved;
+    const uint32_t mask = (uint32_t)tsize - 1u;
+    const uint64_t bid = counter0 + blockIdx.x;
+    for (int i = threadIdx.x; i < tsize; i += kSampleBlock) {
+        keys[i] = 0u;
+        owners[i] = 0xFFFFFFFFu;
+    }
+    int32_t val[SPT];
+    bool done[SPT];
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        val[q] = -1;
+        done[q] = (int)(threadIdx.x + q * kSampleBlock) >= batch;
+    }
+    __syncthreads();
+    for (uint32_t round = 0;; ++round) {
+        if (threadIdx.x == 0) n_unresolved = 0;
+        __syncthreads();
+        uint32_t cand[SPT];
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const uint32_t slot = threadIdx.x + q * kSampleBlock;
+            cand[q] = 0;
+            if (done[q]) continue;
+            cand[q] = (uint32_t)(((uint64_t)rng_words(seed, bid, ((uint64_t)round << 16) | slot, TAG_REPLAY).x * (uint64_t)size) >> 32);
+            uint32_t h = (cand[q] * 2654435761u) & mask;
+            for (int probe = 0; probe < tsize; ++probe) {
+                const uint32_t prev = atomicCAS(&keys[h], 0u, cand[q] + 1u);
+                if (prev == 0u || prev == cand[q] + 1u) {
+                    atomicMin(&owners[h], (round << 12) | slot);
+                    break;
+                }
+                h = (h + 1u) & mask;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const uint32_t slot = threadIdx.x + q * kSampleBlock;
+            if (done[q]) continue;
+            uint32_t h = (cand[q] * 2654435761u) & mask;
+            for (int probe = 0; probe < tsize; ++probe) {
+                if (keys[h] == cand[q] + 1u) {
+                    if (owners[h] == ((round << 12) | slot)) { val[q] = (int32_t)cand[q]; done[q] = true; }
+                    break;
+                }
+                h = (h + 1u) & mask;
+            }
+            if (!done[q]) atomicAdd(&n_unresolved, 1);
+        }
+        __syncthreads();
+        const bool finished = n_unresolved == 0 || round >= (1u << 19);   // (size >= batch: every round resolves at least one slot)
+        __syncthreads();
+        if (finished) break;
+    }
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int slot = threadIdx.x + q * kSampleBlock;
+        if (slot < batch) idx[(int64_t)blockIdx.x * batch + slot] = val[q];
+    }
+}
+
 }  // namespace ssc
 
 using namespace ssc;
@@ -325,12 +399,19 @@ int ssc_replay_episode_path(const ssc_replay_ring *ring, int64_t count, int64_t 
 
 int ssc_replay_sample(uint64_t seed, uint64_t counter0, int64_t size, int32_t n_batches, int32_t batch_size,
                       int32_t *d_idx, ssc_stream_t stream) {
-    SSC_REQUIRE(n_batches >= 0 && batch_size >= 1 && batch_size <= 64, "ssc_replay_sample: batch_size %d not in 1..64",
+    SSC_REQUIRE(n_batches >= 0 && batch_size >= 1 && batch_size <= 4096, "ssc_replay_sample: batch_size %d not in 1..4096",
                 batch_size);
     SSC_REQUIRE(size >= batch_size && size <= 0x7fffffffLL,
                 "ssc_replay_sample: %lld records cannot give %d distinct indices", (long long)size, batch_size);
     if (n_batches == 0) return SSC_OK;
     SSC_REQUIRE(d_idx != nullptr, "ssc_replay_sample: d_idx NULL");
+    if (batch_size > 64) {
+        int tsize = 1024;
+        while (tsize < 2 * batch_size) tsize <<= 1;
+        hipLaunchKernelGGL(replay_sample_big_kernel, dim3(n_batches), dim3(kSampleBlock), (size_t)tsize * 8, as_stream(stream), seed,
+                           counter0, size, batch_size, tsize, d_idx);
+        return check_launch("ssc_replay_sample");
+    }
     hipLaunchKernelGGL(replay_sample_kernel, dim3(n_batches), dim3(64), 0, as_stream(stream), seed, counter0, size,
                        batch_size, d_idx);
     return check_launch("ssc_replay_sample");

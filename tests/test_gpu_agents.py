@@ -416,24 +416,16 @@ class _BoxEnv:
         self.action_space = spaces.Box(low=np.array([-1.0], np.float32), high=np.array([1.0], np.float32))
 
 
-@pytest.mark.parametrize("obs_dim,h1,h2,interpreter", [(2, 64, 32, False), (3, 64, 32, False), (2, 64, 32, True), (3, 64, 32, True),
-                                                       (8, 64, 32, False), (2, 24, 20, False)])
-def test_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2, interpreter, monkeypatch):
-    """ssc_ddpg_train (train + update_target_net, n iterations in one launch) against the fp64 restatement
-    of ddpg_editted.py:287-339 (itself cross-checked against torch autograd on the CPU).  obs_dim 3 is the
-    Pendulum layout, 8 the widest the ABI admits (the LDS carve must hold), 24-20 exercises ragged unit groups.
-    The shipped 64-32 shape with a 2-d / 3-d observation runs the shape-specialised kernel (ddpg_train_fixed.hip),
-    everything else -- and 64-32 again with SSC_DDPG_INTERPRETER=1 -- the step interpreter (ddpg_train.hip)."""
+def _ddpg_kernel_vs_oracle(ssc, obs_dim, h1, h2, B=64, ch1=None, ch2=None, n_iters=6, llts=(True, False), cap=1000):
+    """ssc_ddpg_train_ws against the fp64 restatement of ddpg_editted.py:287-339 (itself cross-checked against torch
+    autograd on the CPU): parameters, targets, Adam moments, losses after ``n_iters`` iterations on batches of ``B``."""
     from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
-    if interpreter:
-        monkeypatch.setenv("SSC_DDPG_INTERPRETER", "1")
-    else:
-        monkeypatch.delenv("SSC_DDPG_INTERPRETER", raising=False)
+    ch1, ch2 = ch1 or h1, ch2 or h2
     rng = np.random.default_rng(11)
     env = ssc.make("MountainCarContinuous-v0") if obs_dim == 2 else _BoxEnv(obs_dim)
-    for llt in (True, False):
-        agent = DDPG_Baselines_agent(env, None, actor_h1=h1, actor_h2=h2, critic_h1=h1, critic_h2=h2, lastLayerTanh=llt,
-                                     actor_lr=1e-3, critic_lr=1e-3, gamma=0.99, tau=0.001, batch_size=64, seed=5,
+    for llt in llts:
+        agent = DDPG_Baselines_agent(env, None, actor_h1=h1, actor_h2=h2, critic_h1=ch1, critic_h2=ch2, lastLayerTanh=llt,
+                                     actor_lr=1e-3, critic_lr=1e-3, gamma=0.99, tau=0.001, batch_size=B, seed=5,
                                      training=False)
         # non-trivial starting point: perturb every parameter (biases and the 3e-3 output layers included)
         aw = {k: v.cpu().numpy() + (0.05 * rng.normal(size=tuple(v.shape))).astype(np.float32) for k, v in agent.weights.items()}
@@ -442,7 +434,7 @@ def test_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2, interpreter, monkeypa
         agent.set_critic_weights(cw)
         agent.target_actor_flat += 0.01
         agent.target_critic_flat -= 0.01
-        cap, n_iters, B = 1000, 6, 64
+        cap = max(cap, B)
         s = rng.uniform(-1.2, 0.6, (cap, obs_dim)).astype(np.float32)
         if obs_dim == 3:
             s[:, 2] = rng.uniform(-8, 8, cap)            # Pendulum's theta-dot: observation_range (-5, 5) clips it
@@ -481,6 +473,65 @@ def test_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2, interpreter, monkeypa
         assert np.allclose(agent._adam_critic[1].cpu().numpy(), adam["v_critic"], rtol=2e-3, atol=1e-9)
         # the weight VIEWS used by the forward kernels see the update
         assert np.max(np.abs(agent.weights["W2"].cpu().numpy() - o_a["W2"])) <= tol
+
+
+@pytest.mark.parametrize("obs_dim,h1,h2,interpreter", [(2, 64, 32, False), (3, 64, 32, False), (2, 64, 32, True), (3, 64, 32, True),
+                                                       (8, 64, 32, False), (2, 24, 20, False)])
+def test_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2, interpreter, monkeypatch):
+    """The single-workgroup learner kernels (batch 64, layers <= 64).  obs_dim 3 is the Pendulum layout, 8 the widest
+    the ABI admits (the LDS carve must hold), 24-20 exercises ragged unit groups.  The shipped 64-32 shape with a
+    2-d / 3-d observation runs the shape-specialised kernel (ddpg_train_fixed.hip), everything else -- and 64-32 again
+    with SSC_DDPG_INTERPRETER=1 -- the step interpreter (ddpg_train.hip)."""
+    monkeypatch.delenv("SSC_DDPG_WIDE", raising=False)
+    if interpreter:
+        monkeypatch.setenv("SSC_DDPG_INTERPRETER", "1")
+    else:
+        monkeypatch.delenv("SSC_DDPG_INTERPRETER", raising=False)
+    _ddpg_kernel_vs_oracle(ssc, obs_dim, h1, h2)
+
+
+@pytest.mark.parametrize("obs_dim,h1,h2,B", [(2, 128, 64, 64), (2, 128, 64, 256), (2, 128, 64, 1024),
+                                             (2, 200, 100, 64), (2, 200, 100, 256), (2, 200, 100, 1024),
+                                             (3, 200, 100, 64), (3, 200, 100, 256), (3, 200, 100, 1024),
+                                             (2, 64, 32, 32), (2, 64, 32, 4096), (3, 64, 32, 50), (8, 37, 19, 77)])
+def test_ddpg_train_wide_kernel_vs_oracle(ssc, obs_dim, h1, h2, B, monkeypatch):
+    """The multi-workgroup learner (ddpg_train_wide.hip): the reference's own network grid -- actor / critic 64-32,
+    128-64, 200-100 (data/ddpg_baselines_summaries/hidden_layer_size_experiment/, DDPG_Baselines_agent.py:86-92) -- at
+    batch sizes 32 .. 4096, batches that do not fill the last 16-row tile (50, 77) and layer sizes off the 16-unit
+    tiles (37-19), at the tolerance of the single-workgroup kernels."""
+    monkeypatch.delenv("SSC_DDPG_WIDE", raising=False)
+    monkeypatch.delenv("SSC_DDPG_INTERPRETER", raising=False)
+    _ddpg_kernel_vs_oracle(ssc, obs_dim, h1, h2, B=B, llts=(True, False) if B <= 256 else (True,), cap=5000)
+
+
+def test_ddpg_train_wide_on_the_shipped_shape_and_mixed_sizes(ssc, monkeypatch):
+    """SSC_DDPG_WIDE=1 sends the shipped 64-32 / batch-64 shape through the multi-workgroup kernels as well (same
+    oracle, same tolerance); actor and critic of different sizes; and the workspace-less entry point says which call
+    serves a wide shape."""
+    import ctypes
+    from smartstartcontinuous_amd import _ffi
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    monkeypatch.delenv("SSC_DDPG_INTERPRETER", raising=False)
+    monkeypatch.setenv("SSC_DDPG_WIDE", "1")
+    _ddpg_kernel_vs_oracle(ssc, 2, 64, 32)
+    _ddpg_kernel_vs_oracle(ssc, 3, 64, 32, llts=(True,))
+    monkeypatch.delenv("SSC_DDPG_WIDE", raising=False)
+    _ddpg_kernel_vs_oracle(ssc, 2, 128, 64, ch1=200, ch2=100, B=128, llts=(True,))
+    _ddpg_kernel_vs_oracle(ssc, 2, 200, 100, ch1=64, ch2=32, B=64, llts=(False,))
+    agent = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, actor_h1=200, actor_h2=100, critic_h1=200,
+                                 critic_h2=100, lastLayerTanh=True, seed=1, training=False)
+    d = agent.ddpg_desc()
+    z = torch.zeros(64, 2, device="cuda")
+    rv = _ffi.ReplayView(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 64)
+    idx = torch.zeros((1, 64), dtype=torch.int32, device="cuda")
+    rc = _ffi.lib().ssc_ddpg_train(ctypes.byref(d), ctypes.byref(rv), _ffi.ptr(idx), 1, None, None)
+    assert rc == _ffi.SSC_EUNSUPPORTED and b"ssc_ddpg_train_ws" in _ffi.lib().ssc_last_error()
+    # a width whose 16-row tile does not fit the LDS is refused with the byte count
+    big = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, actor_h1=512, actor_h2=512, critic_h1=512,
+                               critic_h2=512, lastLayerTanh=True, seed=1, training=False)
+    with pytest.raises(_ffi.SscError) as ei:
+        big.train_on(z, z[:, :1].contiguous(), z[:, 0].contiguous(), torch.zeros(64, dtype=torch.uint8, device="cuda"), z, idx, 1)
+    assert ei.value.code == _ffi.SSC_EUNSUPPORTED and "LDS" in str(ei.value)
 
 
 def test_ddpg_training_reduces_critic_loss(ssc):
@@ -572,6 +623,20 @@ def test_device_replay_ring_matches_oracle(ssc):
         assert np.array_equal(idx, O.replay_sample_indices(5, 0, len(replay), 9, 64))
         idx2 = replay.sample_indices(2, 17).cpu().numpy()                  # the batch counter runs on
         assert np.array_equal(idx2, O.replay_sample_indices(5, 9, len(replay), 2, 17))
+        # batches of more than 64 (the multi-workgroup learner's sizes): one workgroup per batch, same rule
+        drawn = 11
+        for nb, B in ((3, 65), (2, 256), (2, 1000), (1, 4096)):
+            if B > len(replay):
+                continue
+            big = replay.sample_indices(nb, B).cpu().numpy()
+            assert np.array_equal(big, O.replay_sample_indices(5, drawn, len(replay), nb, B)), (nb, B)
+            assert all(len(set(row.tolist())) == B for row in big)
+            drawn += nb
+    from smartstartcontinuous_amd import _ffi
+    for size, nb, B in ((10000, 2, 4096), (4096, 1, 4096), (5000, 3, 2049)):      # up to a dense draw of the largest batch
+        out = torch.empty((nb, B), dtype=torch.int32, device="cuda")
+        _ffi.check(_ffi.lib().ssc_replay_sample(9, 4, size, nb, B, _ffi.ptr(out), None))
+        assert np.array_equal(out.cpu().numpy(), O.replay_sample_indices(9, 4, size, nb, B)), (size, nb, B)
     tiny = DeviceReplayBuffer(64, 2, 1, seed=1)
     with pytest.raises(ValueError):
         tiny.sample_indices(1, 64)

@@ -207,6 +207,10 @@ def test_oracle_replay_ring_and_sampler():
     assert not np.array_equal(idx[0], idx[1])
     full = O.replay_sample_indices(1, 0, 64, 2, 64)
     assert all(sorted(row.tolist()) == list(range(64)) for row in full)
+    # batches above 64 (slot in 16 counter bits): distinct, dense draws included; batch <= 64 streams are unchanged by it
+    big = O.replay_sample_indices(7, 3, 700, 2, 512)
+    assert big.shape == (2, 512) and all(len(set(row.tolist())) == 512 for row in big) and big.max() < 700
+    assert sorted(O.replay_sample_indices(2, 0, 300, 1, 300)[0].tolist()) == list(range(300))
 
 
 def test_add_noise_matches_reference_rule():
