@@ -35,8 +35,9 @@ enum : int { EPI_NONE = 0, EPI_RELU, EPI_TANH, EPI_MASK_RELU, EPI_MASK_TANH };
 
 // out[m][row] = EPI( sum_kk A(m, kk) * B[kk][row] + bias[m] + add[m][row] ),  A(m, kk) = W[m * sm + kk * sk]
 struct WGemm {
-    const float *W;      // global (parameters; read-only during the launch)
-    const float *bias;   // global [M] or nullptr
+    const float *W;      // global: the h1 x h2 blocks (read-only during the launch); nullptr: the A operand is in LDS
+    int32_t w_off;       // LDS float offset of the A operand inside the small-parameter image (W == nullptr)
+    int32_t bias_off;    // LDS float offset of bias[M] inside the image, < 0: none
     int32_t sm, sk, M, K;
     int32_t b_off, out_off, add_off, aux_off;   // LDS float offsets; add_off / aux_off < 0: none
     int32_t epi;
@@ -48,6 +49,24 @@ struct WGrad {
     int32_t gW, gb;                   // offsets into the flat gradient vector (actor first, then critic)
 };
 
+// The per-level tables.  They reach the kernel as arguments, but a scalar load from the kernel-argument segment that
+// misses the (cold) scalar cache costs ~500 cycles and the job dispatch walks these tables level by level -- two to
+// three dependent misses per level, ten levels: more than the arithmetic of a 64-32 network.  Every workgroup
+// therefore copies the tables into LDS with ONE vector load per thread at kernel start and reads them from there
+// (lds_uniform: broadcast read + v_readfirstlane, so that dispatch and addressing still run on the scalar unit).
+struct WideTables {
+    int32_t level_first[kMaxLevel + 1];
+    int32_t n_seg, n_big, pad_;
+    WGemm gemm[kMaxGemm];
+    WGrad wg[kMaxWg];
+    // Everything of the four parameter vectors except their h1 x h2 blocks (first layers, biases, output layers, the
+    // critics' action rows: a few KB) is copied into LDS at kernel start, segment by segment; the h1 x h2 blocks are
+    // touched once (one load per 128-byte line) so that the contractions find them in this XCD's L2.
+    struct { const float *src; int32_t dst, n; } seg[8];
+    struct { const float *src; int32_t n, pad; } big[4];
+};
+static_assert(sizeof(WideTables) % 4 == 0 && sizeof(WideTables) <= 512 * 4, "one dword per thread copies the tables");
+
 struct WideArgs {
     ssc_replay_view rp;
     const int32_t *batch_idx;    // [batch] of this iteration
@@ -55,91 +74,226 @@ struct WideArgs {
     float gamma, obs_clip;
     int32_t off_S, off_S2, off_ACT, off_TACT, off_RT;   // LDS float offsets; RT: rows r, t, y, q, q', qpi, dq, dqb
     int32_t n_gemm, n_level, td_level, n_wg;
-    int32_t level_first[kMaxLevel + 1];
-    WGemm gemm[kMaxGemm];
-    WGrad wg[kMaxWg];
     float *gpart;   // [n_blocks][n_params]
     float *lpart;   // [n_blocks][2]
     int32_t n_params;
+    int32_t off_tab;             // LDS float offset of the copy of `tab`
+    WideTables tab;
 };
+
+template <class T> __device__ __forceinline__ T lds_uniform(const T *p) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized tables");
+    union { T t; uint32_t w[sizeof(T) / 4]; } u;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) u.w[i] = __builtin_amdgcn_readfirstlane(src[i]);
+    return u.t;
+}
 
 enum : int { RT_R = 0, RT_T, RT_Y, RT_Q, RT_QT, RT_QPI, RT_DQ, RT_DQB, RT_ROWS };
 
+// The hot loops below are written branch-free: an operand outside the valid range is read from a clamped (valid)
+// address and zeroed with a select -- a predicated load costs hipcc a basic block and a full s_waitcnt per load, which
+// serialises what should be sixteen loads in flight.  Offsets are 32-bit (SGPR base + VGPR offset addressing).
+__device__ __forceinline__ float act_epi(int epi, float v, float aux) {
+    if (epi == EPI_RELU) return fmaxf(v, 0.0f);
+    if (epi == EPI_TANH) return tanh_fast(v);
+    if (epi == EPI_MASK_RELU) return aux > 0.0f ? v : 0.0f;
+    if (epi == EPI_MASK_TANH) return v * (1.0f - aux * aux);
+    return v;
+}
+
+__device__ __forceinline__ void gemm_epilogue(const WGemm &g, float *lds, int tile0, int lane, const f32x4m &acc0, const f32x4m &acc1) {
+    const int lm = lane & 15, lk = lane >> 4;
+    // all (up to) 24 LDS reads of the epilogue are issued unconditionally -- an absent bias / addend / derivative row
+    // reads the output row instead and is dropped by a select -- so that they share ONE wait (a conditional read costs
+    // a basic block and a full lgkmcnt(0) each: 24 serialised LDS round trips were most of a small level's time)
+    const bool has_bias = g.bias_off >= 0, has_add = g.add_off >= 0, has_aux = g.aux_off >= 0;
+    const int bias_o = has_bias ? g.bias_off : g.out_off, add_o = has_add ? g.add_off : g.out_off, aux_o = has_aux ? g.aux_off : g.out_off;
+    float bias[8], add[8], aux[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int mc = min((tile0 + (e >> 2)) * 16 + 4 * lk + (e & 3), g.M - 1);
+        bias[e] = lds[bias_o + mc];
+        add[e] = lds[add_o + mc * kWR + lm];
+        aux[e] = lds[aux_o + mc * kWR + lm];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int m = (tile0 + (e >> 2)) * 16 + 4 * lk + (e & 3);
+        float x = (e < 4 ? acc0[e & 3] : acc1[e & 3]) + (has_bias ? bias[e] : 0.0f) + (has_add ? add[e] : 0.0f);
+        const float r = act_epi(g.epi, x, has_aux ? aux[e] : 0.0f);
+        if (m < g.M) lds[g.out_off + m * kWR + lm] = r;
+    }
+}
+
 // One job of a contraction: up to two 16-unit tiles (they share the B operand) for the workgroup's 16 rows.
-__device__ __forceinline__ void gemm_job(const WGemm &g, float *lds, int tile0, int lane) {
+// A operand in the LDS image (first / output layers, action rows -- short contractions); reads batched 8 k-steps at
+// a time (one wait per 24 reads).
+__device__ __forceinline__ void gemm_job_lds(const WGemm &g, float *lds, int tile0, int lane) {
     constexpr int KU = 8;
     const int lm = lane & 15, lk = lane >> 4;
     const int m0 = tile0 * 16 + lm, m1 = m0 + 16;
     const bool v0 = m0 < g.M, v1 = m1 < g.M;
-    const float *w0 = g.W + (int64_t)m0 * g.sm + (int64_t)lk * g.sk;
-    const float *w1 = w0 + (int64_t)16 * g.sm;
-    const float *b = lds + g.b_off + lk * kWR + lm;
+    const float *w0 = lds + g.w_off + min(m0, g.M - 1) * g.sm;
+    const float *w1 = lds + g.w_off + min(m1, g.M - 1) * g.sm;
+    const float *b = lds + g.b_off + lm;
     f32x4m acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
     const int steps = (g.K + 3) >> 2;
     for (int s0 = 0; s0 < steps; s0 += KU) {
         float a0[KU], a1[KU], bv[KU];
 #pragma unroll
         for (int j = 0; j < KU; ++j) {
-            const int kk = 4 * (s0 + j) + lk;
-            const bool ok = kk < g.K;
-            a0[j] = (ok && v0) ? w0[(int64_t)4 * (s0 + j) * g.sk] : 0.0f;
-            a1[j] = (ok && v1) ? w1[(int64_t)4 * (s0 + j) * g.sk] : 0.0f;
-            bv[j] = ok ? b[(s0 + j) * 4 * kWR] : 0.0f;
+            const int kc = min(4 * (s0 + j) + lk, g.K - 1);
+            a0[j] = w0[kc * g.sk];
+            a1[j] = w1[kc * g.sk];
+            bv[j] = b[kc * kWR];
         }
 #pragma unroll
         for (int j = 0; j < KU; ++j) {
-            acc0 = mfma4(a0[j], bv[j], acc0);
-            acc1 = mfma4(a1[j], bv[j], acc1);
+            const bool ok = 4 * (s0 + j) + lk < g.K;
+            acc0 = mfma4((ok && v0) ? a0[j] : 0.0f, ok ? bv[j] : 0.0f, acc0);
+            acc1 = mfma4((ok && v1) ? a1[j] : 0.0f, ok ? bv[j] : 0.0f, acc1);
         }
     }
+    gemm_epilogue(g, lds, tile0, lane, acc0, acc1);
+}
+
+// A operand streamed from L2 (the h1 x h2 blocks) in chunks of KU k-steps with one chunk of look-ahead, so that a
+// chunk's round trip runs under the previous chunk's 2 KU MFMAs.
+__device__ __forceinline__ void gemm_job_l2(const WGemm &g, float *lds, int tile0, int lane) {
+    constexpr int KU = 16;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int m0 = tile0 * 16 + lm, m1 = m0 + 16;
+    const bool v0 = m0 < g.M, v1 = m1 < g.M;
+    const float *__restrict__ W = g.W;
+    const uint32_t o0 = (uint32_t)(min(m0, g.M - 1) * g.sm), o1 = (uint32_t)(min(m1, g.M - 1) * g.sm);
+    const float *b = lds + g.b_off + lm;
+    f32x4m acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int steps = (g.K + 3) >> 2;
+    float a0[KU], a1[KU], n0[KU], n1[KU];
+    auto fetch = [&](int s0, float (&x0)[KU], float (&x1)[KU]) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const f32x4m &acc = t == 0 ? acc0 : acc1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = (tile0 + t) * 16 + 4 * lk + i;
-            if (m >= g.M) continue;
-            float v = acc[i];
-            if (g.bias != nullptr) v += g.bias[m];
-            if (g.add_off >= 0) v += lds[g.add_off + m * kWR + lm];
-            if (g.epi == EPI_RELU) v = fmaxf(v, 0.0f);
-            else if (g.epi == EPI_TANH) v = tanhf(v);
-            else if (g.epi == EPI_MASK_RELU) v = lds[g.aux_off + m * kWR + lm] > 0.0f ? v : 0.0f;
-            else if (g.epi == EPI_MASK_TANH) { const float a = lds[g.aux_off + m * kWR + lm]; v *= 1.0f - a * a; }
-            lds[g.out_off + m * kWR + lm] = v;
+        for (int j = 0; j < KU; ++j) {
+            const uint32_t ko = (uint32_t)(min(4 * (s0 + j) + lk, g.K - 1) * g.sk);
+            x0[j] = W[o0 + ko];
+            x1[j] = W[o1 + ko];
         }
+    };
+    fetch(0, a0, a1);
+    for (int s0 = 0; s0 < steps; s0 += KU) {
+        fetch(min(s0 + KU, steps - 1), n0, n1);      // in flight under this chunk's MFMAs (the last one re-reads valid data)
+        float bv[KU];
+#pragma unroll
+        for (int j = 0; j < KU; ++j) bv[j] = b[min(4 * (s0 + j) + lk, g.K - 1) * kWR];
+#pragma unroll
+        for (int j = 0; j < KU; ++j) {
+            const bool ok = 4 * (s0 + j) + lk < g.K;
+            acc0 = mfma4((ok && v0) ? a0[j] : 0.0f, ok ? bv[j] : 0.0f, acc0);
+            acc1 = mfma4((ok && v1) ? a1[j] : 0.0f, ok ? bv[j] : 0.0f, acc1);
+        }
+#pragma unroll
+        for (int j = 0; j < KU; ++j) { a0[j] = n0[j]; a1[j] = n1[j]; }
     }
+    gemm_epilogue(g, lds, tile0, lane, acc0, acc1);
 }
 
 // One 16 x 16 tile of a layer's weight gradient (tile i over the inputs, tile j over the units): the 16 rows are the
 // K of four MFMAs; lane group lk contracts rows 4 lk .. 4 lk + 3 (any pairing of k values is a valid contraction),
 // so both operands come in with one 16-byte LDS read per lane.
-__device__ __forceinline__ void wgrad_tile(const WGrad &w, const float *lds, float *gout, int ti, int tj, int lane) {
+__device__ __forceinline__ void wgrad_tile(const WGrad &w, const float *lds, float *__restrict__ gout, int ti, int tj, int lane) {
     const int lm = lane & 15, lk = lane >> 4;
     const int k = ti * 16 + lm, u = tj * 16 + lm;
-    f4 xa = {0.0f, 0.0f, 0.0f, 0.0f}, dz = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (k < w.in) xa = *reinterpret_cast<const f4 *>(lds + w.x_off + k * kWR + 4 * lk);
-    if (u < w.out) dz = *reinterpret_cast<const f4 *>(lds + w.dz_off + u * kWR + 4 * lk);
+    f4 xa = *reinterpret_cast<const f4 *>(lds + w.x_off + min(k, w.in - 1) * kWR + 4 * lk);
+    f4 dz = *reinterpret_cast<const f4 *>(lds + w.dz_off + min(u, w.out - 1) * kWR + 4 * lk);
+    if (k >= w.in) xa = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (u >= w.out) dz = f4{0.0f, 0.0f, 0.0f, 0.0f};
     f32x4m acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma4(xa[s], dz[s], acc);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int kk = ti * 16 + 4 * lk + i;
-        if (kk < w.in && u < w.out) gout[w.gW + kk * w.out + u] = acc[i];
+        if (kk < w.in && u < w.out) gout[(uint32_t)(w.gW + kk * w.out + u)] = acc[i];
     }
 }
 
 __global__ __launch_bounds__(kWThreads) void ddpg_wide_grad_kernel(WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SSC_WIDE_DIAG
+    const uint64_t t_entry = __builtin_amdgcn_s_memtime();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: job dispatch runs on the scalar unit
     const int row0 = blockIdx.x * kWR;
+    // ---- the tables: one dword per thread from the kernel-argument segment into LDS ----
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        typedef const __attribute__((address_space(4))) char *karg_bytes;
+        typedef const __attribute__((address_space(4))) uint32_t *karg_words;
+        const karg_words src = (karg_words)((karg_bytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WideArgs, tab));
+        if (tid < (int)(sizeof(WideTables) / 4)) reinterpret_cast<uint32_t *>(lds + a.off_tab)[tid] = src[tid];
+    }
+#endif
+    __syncthreads();
+    const WideTables *T = reinterpret_cast<const WideTables *>(lds + a.off_tab);
+    // ---- everything the launch needs from memory is requested up front, in one round trip where it can be:
+    //   * the batch indices (the rows need a second, dependent one);
+    //   * the small parameters -> LDS image (8 segments, up to kImgQ x 512 floats each per pass);
+    //   * one load per 128-byte line of the h1 x h2 blocks (L2 warm-up: the previous launch rewrote every parameter,
+    //     so the first touch of a line in this XCD goes to the memory side).
+    const bool row_thread = tid < kWR;
+    const bool valid = row0 + tid < a.batch;
+    int64_t rec = 0;
+    if (row_thread) rec = a.batch_idx[valid ? row0 + tid : a.batch - 1];
+    constexpr int kImgQ = 2;
+    {
+        const float *seg_src[8];
+        int seg_dst[8], seg_n[8], max_seg = 0;
+#pragma unroll
+        for (int si = 0; si < 8; ++si) {
+            const auto sg = lds_uniform(&T->seg[si]);
+            seg_src[si] = sg.src; seg_dst[si] = sg.dst; seg_n[si] = sg.n;     // (unused slots: n = 0, src = a valid pointer)
+            max_seg = max(max_seg, sg.n);
+        }
+        for (int q0 = 0; q0 * kWThreads < max_seg; q0 += kImgQ) {
+            float v[8][kImgQ];
+#pragma unroll
+            for (int si = 0; si < 8; ++si)
+#pragma unroll
+                for (int q = 0; q < kImgQ; ++q) v[si][q] = seg_src[si][max(min(tid + (q0 + q) * kWThreads, seg_n[si] - 1), 0)];
+#pragma unroll
+            for (int si = 0; si < 8; ++si)
+#pragma unroll
+                for (int q = 0; q < kImgQ; ++q) {
+                    const int e = tid + (q0 + q) * kWThreads;
+                    if (e < seg_n[si]) lds[seg_dst[si] + e] = v[si][q];
+                }
+        }
+        float sink = 0.0f;
+        const float *big_src[4];
+        int big_n[4], max_big = 0;
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) {
+            const auto bg = lds_uniform(&T->big[bi]);
+            big_src[bi] = bg.src; big_n[bi] = bg.n;
+            max_big = max(max_big, bg.n);
+        }
+        for (int e0 = 0; e0 < max_big; e0 += kWThreads * 32 * 2) {
+            float v[4][2];
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) v[bi][q] = big_src[bi][max(min(e0 + (tid + q * kWThreads) * 32, big_n[bi] - 1), 0)];
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) sink += v[bi][0] + v[bi][1];
+        }
+        if (sink == 1.2345e-30f) lds[a.off_RT + RT_Y * kWR] = sink;   // keeps the loads; the row is rewritten below
+    }
     // ---- ReplayBuffer.sample_batch rows of this workgroup (replay_buffer.py:79-91); rows past the batch shadow its
     // last record and carry zero weight in every loss ----
-    if (tid < kWR) {
+    if (row_thread) {
         const int r = tid;
-        const bool valid = row0 + r < a.batch;
-        const int64_t rec = a.batch_idx[valid ? row0 + r : a.batch - 1];
         for (int k = 0; k < a.obs_dim; ++k) {   // obs0 / obs1 enter every network clipped (ddpg_editted.py:106-109)
             float s = a.rp.s[rec * a.obs_dim + k], s2 = a.rp.s2[rec * a.obs_dim + k];
             if (a.obs_clip > 0.0f) {
@@ -154,16 +308,36 @@ __global__ __launch_bounds__(kWThreads) void ddpg_wide_grad_kernel(WideArgs a) {
         lds[a.off_RT + RT_T * kWR + r] = a.rp.t[rec] ? 1.0f : 0.0f;
     }
     __syncthreads();
+#ifdef SSC_WIDE_DIAG
+    // diagnostic build (tools/exp_ddpg_wide_phases.py): cycle stamps of block 0 at every level boundary, written behind
+    // the loss partials
+    uint64_t stamp[kMaxLevel + 4];
+    int n_stamp = 0;
+    stamp[n_stamp++] = t_entry;
+    stamp[n_stamp++] = __builtin_amdgcn_s_memtime();
+#endif
     float *gout = a.gpart + (int64_t)blockIdx.x * a.n_params;
+#ifdef SSC_WIDE_DIAG
+    // the level sequence runs TWICE in the diagnostic build and the stamps are those of the second pass: same work,
+    // but with the instruction cache warm -- the difference to the first pass is what a fresh launch pays for code fetch
+    for (int rep = 0; rep < SSC_WIDE_DIAG; ++rep) {
+    n_stamp = 2;
+    stamp[1] = __builtin_amdgcn_s_memtime();
+#endif
     for (int lv = 0; lv < a.n_level; ++lv) {
         // the level's independent contractions as (contraction, tile-pair) jobs, dealt round-robin to the waves
         int job = wave;
-        for (int gi = a.level_first[lv]; gi < a.level_first[lv + 1]; ++gi) {
-            const WGemm &g = a.gemm[gi];
-            const int pairs = (((g.M + 15) >> 4) + 1) >> 1;
-            while (job < pairs) {
-                gemm_job(g, lds, 2 * job, lane);
-                job += kWWaves;
+        const int g_first = __builtin_amdgcn_readfirstlane(T->level_first[lv]), g_end = __builtin_amdgcn_readfirstlane(T->level_first[lv + 1]);
+        for (int gi = g_first; gi < g_end; ++gi) {
+            const int M = __builtin_amdgcn_readfirstlane(T->gemm[gi].M);
+            const int pairs = (((M + 15) >> 4) + 1) >> 1;
+            if (job < pairs) {
+                const WGemm g = lds_uniform(&T->gemm[gi]);
+                if (g.W == nullptr) {
+                    for (; job < pairs; job += kWWaves) gemm_job_lds(g, lds, 2 * job, lane);
+                } else {
+                    for (; job < pairs; job += kWWaves) gemm_job_l2(g, lds, 2 * job, lane);
+                }
             }
             job -= pairs;
         }
@@ -171,10 +345,9 @@ __global__ __launch_bounds__(kWThreads) void ddpg_wide_grad_kernel(WideArgs a) {
         if (lv == a.td_level) {
             // target_Q = r + (1 - terminal) * gamma * Q'(s2, pi'(s2))  (:132-133); critic loss mean((Q - y)^2) (:181),
             // actor loss -mean Q(s, pi(s)) (:168): per-row loss terms and the two output deltas
-            if (tid < kWR) {
+            if (row_thread) {
                 const int r = tid;
                 float *rt = lds + a.off_RT;
-                const bool valid = row0 + r < a.batch;
                 const float y = rt[RT_R * kWR + r] + (1.0f - rt[RT_T * kWR + r]) * a.gamma * rt[RT_QT * kWR + r];
                 const float e = rt[RT_Q * kWR + r] - y;
                 const float inv_b = 1.0f / (float)a.batch;
@@ -194,27 +367,39 @@ __global__ __launch_bounds__(kWThreads) void ddpg_wide_grad_kernel(WideArgs a) {
             }
             __syncthreads();
         }
+#ifdef SSC_WIDE_DIAG
+        stamp[n_stamp++] = __builtin_amdgcn_s_memtime();
+#endif
     }
+#ifdef SSC_WIDE_DIAG
+    }
+#endif
     // ---- this workgroup's share of every gradient ----
     int job = wave;
     for (int wi = 0; wi < a.n_wg; ++wi) {
-        const WGrad &w = a.wg[wi];
+        const WGrad w = lds_uniform(&T->wg[wi]);
         const int tk = (w.in + 15) >> 4, tu = (w.out + 15) >> 4;
         const int tiles = tk * tu;
-        while (job < tiles) {
-            wgrad_tile(w, lds, gout, job / tu, job % tu, lane);
-            job += kWWaves;
-        }
+        for (; job < tiles; job += kWWaves) wgrad_tile(w, lds, gout, job / tu, job % tu, lane);
         job -= tiles;
     }
     for (int wi = 0; wi < a.n_wg; ++wi) {
-        const WGrad &w = a.wg[wi];
+        const WGrad w = lds_uniform(&T->wg[wi]);
         for (int u = tid; u < w.out; u += kWThreads) {
             const f4 *z = reinterpret_cast<const f4 *>(lds + w.dz_off + u * kWR);
             const f4 s4 = (z[0] + z[1]) + (z[2] + z[3]);
             gout[w.gb + u] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         }
     }
+#ifdef SSC_WIDE_DIAG
+    __syncthreads();
+    stamp[n_stamp++] = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && tid == 0) {
+        uint64_t *out = reinterpret_cast<uint64_t *>(a.lpart + 64);
+        out[0] = (uint64_t)n_stamp;
+        for (int i = 0; i < n_stamp; ++i) out[1 + i] = stamp[i];
+    }
+#endif
 }
 
 struct ApplyArgs {
@@ -295,7 +480,7 @@ static int wide_params(const ssc_ddpg_desc *d) {
 
 size_t ddpg_wide_workspace_bytes(const ssc_ddpg_desc *d) {
     const size_t nb = (size_t)wide_blocks(d);
-    return ((nb * (size_t)wide_params(d) * sizeof(float) + 255) & ~(size_t)255) + ((nb * 2 * sizeof(float) + 255) & ~(size_t)255);
+    return ((nb * (size_t)wide_params(d) * sizeof(float) + 255) & ~(size_t)255) + ((nb * 2 * sizeof(float) + 255) & ~(size_t)255) + 1024;
 }
 
 int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
@@ -324,65 +509,92 @@ int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int
     const int DU1 = TA1, DU2 = TA2, DZ1 = TC1, DZ2 = TZ2, DZB2 = Z2H;
     const int TPI = TC1 + C.h1 * kWR, ACT = C1 + C.h1 * kWR;
     g.off_S = S; g.off_S2 = S2; g.off_ACT = ACT; g.off_TACT = TPI; g.off_RT = RT;
+    // the small-parameter image: per net the flat vector without its h1 x h2 block, i.e. [W1 | b1] and
+    // [W2 action rows | b2 | W3 | b3]; img(net, flat offset) = LDS offset of that element
+    const float *theta[4] = {d->target_actor, d->target_critic, d->critic, d->actor};     // ta, tc, c, a
+    const WNet *nets[4] = {&A, &C, &C, &A};
+    int img_lo[4], img_hi[4];
+    g.tab.n_seg = 0; g.tab.n_big = 0;
+    for (int n = 0; n < 4; ++n) {
+        const WNet &N = *nets[n];
+        const int head = N.h1 * N.h2;
+        img_lo[n] = p;
+        g.tab.seg[g.tab.n_seg].src = theta[n]; g.tab.seg[g.tab.n_seg].dst = p; g.tab.seg[g.tab.n_seg].n = N.oW2();
+        ++g.tab.n_seg;
+        p += N.oW2();
+        img_hi[n] = p - (N.oW2() + head);        // flat offsets >= oW2 + head map to img_hi + offset
+        g.tab.seg[g.tab.n_seg].src = theta[n] + N.oW2() + head; g.tab.seg[g.tab.n_seg].dst = p; g.tab.seg[g.tab.n_seg].n = N.total() - N.oW2() - head;
+        ++g.tab.n_seg;
+        p += N.total() - N.oW2() - head;
+        g.tab.big[g.tab.n_big].src = theta[n] + N.oW2(); g.tab.big[g.tab.n_big].n = head;
+        ++g.tab.n_big;
+    }
+    auto img = [&](int n, int flat) { return flat < nets[n]->oW2() ? img_lo[n] + flat : img_hi[n] + flat; };
+    g.off_tab = (p + 3) & ~3;
+    p = g.off_tab + (int)(sizeof(WideTables) / 4);
+    enum { TA = 0, TC = 1, CR = 2, AC = 3 };
     const size_t lds = (size_t)p * sizeof(float);
     if (lds > 160 * 1024)
         return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: these layer sizes need %zu B of LDS per workgroup (160 KB available)", lds);
-    const float *ta = d->target_actor, *tc = d->target_critic, *th_a = d->actor, *th_c = d->critic;
     int ng = 0, nl = 0;
-    auto level = [&]() { g.level_first[nl++] = ng; };
-    auto gemm = [&](const float *W, int sm, int sk, int M, int K, const float *bias, int b_off, int out_off, int epi,
+    auto level = [&]() { g.tab.level_first[nl++] = ng; };
+    // net n, flat offset wflat of A(0, 0); big = true: the h1 x h2 block, streamed from L2
+    auto gemm = [&](int n, int wflat, bool big, int sm, int sk, int M, int K, int bias_flat, int b_off, int out_off, int epi,
                     int add_off = -1, int aux_off = -1) {
-        WGemm &x = g.gemm[ng++];
-        x.W = W; x.sm = sm; x.sk = sk; x.M = M; x.K = K; x.bias = bias; x.b_off = b_off; x.out_off = out_off; x.epi = epi;
+        WGemm &x = g.tab.gemm[ng++];
+        x.W = big ? theta[n] + wflat : nullptr;
+        x.w_off = big ? 0 : img(n, wflat);
+        x.bias_off = bias_flat >= 0 ? img(n, bias_flat) : -1;
+        x.sm = sm; x.sk = sk; x.M = M; x.K = K; x.b_off = b_off; x.out_off = out_off; x.epi = epi;
         x.add_off = add_off; x.aux_off = aux_off;
     };
     const int RQ = RT + RT_Q * kWR, RQT = RT + RT_QT * kWR, RQPI = RT + RT_QPI * kWR, RDQ = RT + RT_DQ * kWR, RDQB = RT + RT_DQB * kWR;
     // L0: the first layer of all four networks
     level();
-    gemm(ta + A.oW1(), 1, A.h1, A.h1, od, ta + A.ob1(), S2, TA1, EPI_RELU);
-    gemm(tc + C.oW1(), 1, C.h1, C.h1, od, tc + C.ob1(), S2, TC1, EPI_RELU);
-    gemm(th_c + C.oW1(), 1, C.h1, C.h1, od, th_c + C.ob1(), S, C1, EPI_RELU);
-    gemm(th_a + A.oW1(), 1, A.h1, A.h1, od, th_a + A.ob1(), S, U1, EPI_RELU);
+    gemm(TA, A.oW1(), false, 1, A.h1, A.h1, od, A.ob1(), S2, TA1, EPI_RELU);
+    gemm(TC, C.oW1(), false, 1, C.h1, C.h1, od, C.ob1(), S2, TC1, EPI_RELU);
+    gemm(CR, C.oW1(), false, 1, C.h1, C.h1, od, C.ob1(), S, C1, EPI_RELU);
+    gemm(AC, A.oW1(), false, 1, A.h1, A.h1, od, A.ob1(), S, U1, EPI_RELU);
     // L1: the h1 x h2 contractions; the critics' second layer without its action rows (they need pi' / pi)
     level();
-    gemm(ta + A.oW2(), 1, A.h2, A.h2, A.h1, ta + A.ob2(), TA1, TA2, act2);
-    gemm(th_a + A.oW2(), 1, A.h2, A.h2, A.h1, th_a + A.ob2(), U1, U2, act2);
-    gemm(th_c + C.oW2(), 1, C.h2, C.h2, C.h1, th_c + C.ob2(), C1, Z2H, EPI_NONE);
-    gemm(tc + C.oW2(), 1, C.h2, C.h2, C.h1, tc + C.ob2(), TC1, TZ2, EPI_NONE);
+    gemm(TA, A.oW2(), true, 1, A.h2, A.h2, A.h1, A.ob2(), TA1, TA2, act2);
+    gemm(AC, A.oW2(), true, 1, A.h2, A.h2, A.h1, A.ob2(), U1, U2, act2);
+    gemm(CR, C.oW2(), true, 1, C.h2, C.h2, C.h1, C.ob2(), C1, Z2H, EPI_NONE);
+    gemm(TC, C.oW2(), true, 1, C.h2, C.h2, C.h1, C.ob2(), TC1, TZ2, EPI_NONE);
     // L2: pi'(s2), pi(s), Q(s, a) layer 2 = act(head + W2[h1:]^T a)
     level();
-    gemm(ta + A.oW3(), 1, ad, ad, A.h2, ta + A.ob3(), TA2, TPI, EPI_TANH);
-    gemm(th_a + A.oW3(), 1, ad, ad, A.h2, th_a + A.ob3(), U2, PI, EPI_TANH);
-    gemm(th_c + C.oW2() + C.h1 * C.h2, 1, C.h2, C.h2, ad, nullptr, ACT, C2, act2, Z2H);
+    gemm(TA, A.oW3(), false, 1, ad, ad, A.h2, A.ob3(), TA2, TPI, EPI_TANH);
+    gemm(AC, A.oW3(), false, 1, ad, ad, A.h2, A.ob3(), U2, PI, EPI_TANH);
+    gemm(CR, C.oW2() + C.h1 * C.h2, false, 1, C.h2, C.h2, ad, -1, ACT, C2, act2, Z2H);
     // L3: Q'(s2, pi') layer 2, Q(s, pi(s)) layer 2, Q(s, a)
     level();
-    gemm(tc + C.oW2() + C.h1 * C.h2, 1, C.h2, C.h2, ad, nullptr, TPI, TZ2, act2, TZ2);
-    gemm(th_c + C.oW2() + C.h1 * C.h2, 1, C.h2, C.h2, ad, nullptr, PI, CB2, act2, Z2H);
-    gemm(th_c + C.oW3(), 1, 1, 1, C.h2, th_c + C.ob3(), C2, RQ, EPI_NONE);
+    gemm(TC, C.oW2() + C.h1 * C.h2, false, 1, C.h2, C.h2, ad, -1, TPI, TZ2, act2, TZ2);
+    gemm(CR, C.oW2() + C.h1 * C.h2, false, 1, C.h2, C.h2, ad, -1, PI, CB2, act2, Z2H);
+    gemm(CR, C.oW3(), false, 1, 1, 1, C.h2, C.ob3(), C2, RQ, EPI_NONE);
     // L4: Q'(s2, pi'(s2)) and Q(s, pi(s)); then target_Q, the losses and the output deltas
     level();
-    gemm(tc + C.oW3(), 1, 1, 1, C.h2, tc + C.ob3(), TZ2, RQT, EPI_NONE);
-    gemm(th_c + C.oW3(), 1, 1, 1, C.h2, th_c + C.ob3(), CB2, RQPI, EPI_NONE);
+    gemm(TC, C.oW3(), false, 1, 1, 1, C.h2, C.ob3(), TZ2, RQT, EPI_NONE);
+    gemm(CR, C.oW3(), false, 1, 1, 1, C.h2, C.ob3(), CB2, RQPI, EPI_NONE);
     g.td_level = nl - 1;
     // L5: dz2 = (W3 dq) * act'(z2) for the critic loss, the same through Q(s, pi(s)) for the actor loss
     level();
-    gemm(th_c + C.oW3(), 1, 1, C.h2, 1, nullptr, RDQ, DZ2, mask2, -1, C2);
-    gemm(th_c + C.oW3(), 1, 1, C.h2, 1, nullptr, RDQB, DZB2, mask2, -1, CB2);
+    gemm(CR, C.oW3(), false, 1, 1, C.h2, 1, -1, RDQ, DZ2, mask2, -1, C2);
+    gemm(CR, C.oW3(), false, 1, 1, C.h2, 1, -1, RDQB, DZB2, mask2, -1, CB2);
     // L6: critic layer-1 deltas; d(-mean Q)/d(action) through the actor's output tanh
     level();
-    gemm(th_c + C.oW2(), C.h2, 1, C.h1, C.h2, nullptr, DZ2, DZ1, EPI_MASK_RELU, -1, C1);
-    gemm(th_c + C.oW2() + C.h1 * C.h2, C.h2, 1, ad, C.h2, nullptr, DZB2, DPI, EPI_MASK_TANH, -1, PI);
+    gemm(CR, C.oW2(), true, C.h2, 1, C.h1, C.h2, -1, DZ2, DZ1, EPI_MASK_RELU, -1, C1);
+    gemm(CR, C.oW2() + C.h1 * C.h2, false, C.h2, 1, ad, C.h2, -1, DZB2, DPI, EPI_MASK_TANH, -1, PI);
     // L7, L8: back through the actor
     level();
-    gemm(th_a + A.oW3(), ad, 1, A.h2, ad, nullptr, DPI, DU2, mask2, -1, U2);
+    gemm(AC, A.oW3(), false, ad, 1, A.h2, ad, -1, DPI, DU2, mask2, -1, U2);
     level();
-    gemm(th_a + A.oW2(), A.h2, 1, A.h1, A.h2, nullptr, DU2, DU1, EPI_MASK_RELU, -1, U1);
-    g.level_first[nl] = ng;
+    gemm(AC, A.oW2(), true, A.h2, 1, A.h1, A.h2, -1, DU2, DU1, EPI_MASK_RELU, -1, U1);
+    g.tab.level_first[nl] = ng;
     g.n_gemm = ng; g.n_level = nl;
     // gradients, flat [actor | critic], TF trainable_vars order inside a net
     const int nA = A.total(), nC = C.total();
     int nw = 0;
-    auto wgrad = [&](int x_off, int dz_off, int in, int out, int gW, int gb) { g.wg[nw++] = WGrad{x_off, dz_off, in, out, gW, gb}; };
+    auto wgrad = [&](int x_off, int dz_off, int in, int out, int gW, int gb) { g.tab.wg[nw++] = WGrad{x_off, dz_off, in, out, gW, gb}; };
     wgrad(C1, DZ2, C.h1 + ad, C.h2, nA + C.oW2(), nA + C.ob2());       // the large ones first: they are dealt out first
     wgrad(U1, DU2, A.h1, A.h2, A.oW2(), A.ob2());
     wgrad(S, DZ1, od, C.h1, nA + C.oW1(), nA + C.ob1());
