@@ -59,6 +59,38 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
+def source_sha_of(files):
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "smartstartcontinuous_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+C3_SOURCES = ("rollout.hip", "ssc_device.h", "actor_device.h")
+
+
+def profiled_valu_issue():
+    """The roof that actually binds BASELINE configs[2] (fused actor rollout): VALU / transcendental ISSUE at one wave per
+    SIMD.  `frac` = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the rollout kernel (share of the resident wave's cycles in which
+    a VALU instruction was issuing), from the committed PMC pass of this same command (profiles/*/valu_issue.json, written
+    by tools/summarize_r03.py); like `traffic` it is reported only for the kernel sources it was measured on."""
+    import glob
+    sha, best = source_sha_of(C3_SOURCES), None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "valu_issue.json")) +
+                    glob.glob(os.path.join(ROOT, "profiles", "*", "*", "valu_issue.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        rel = os.path.relpath(f, ROOT)
+        if d.get("source_sha") == sha:
+            best = dict(d, source=rel)
+        elif best is None or "stale" in best:
+            best = {"stale": "%s was measured on kernel sources %s, this build is %s" % (rel, d.get("source_sha"), sha)}
+    return best
+
+
 def bench_config3(args, torch, emit=True):
     """BASELINE configs[2]: 65 536 MountainCar envs + DDPG actor 64-32 (bf16 MFMA) + OU noise, fused."""
     import numpy as np
@@ -104,6 +136,9 @@ def bench_config3(args, torch, emit=True):
                         "note": "neither contract roof binds: the kernel is VALU/transcendental-ISSUE-bound (33 tanh + 96 "
                                 "relu/convert + OU Box-Muller per env-step); reported against the HBM roof of its 25 B/step "
                                 "log (the only HBM traffic), with the MFMA-eligible rate beside it"}}
+    vi = profiled_valu_issue()
+    if vi is not None:
+        res["roofline"]["valu_issue"] = vi
     if not args.no_cpu_baseline:
         from oracle import ssc_oracle as O               # the checker, timed as the CPU baseline only
         wn = {k: v.numpy() for k, v in w.items()}

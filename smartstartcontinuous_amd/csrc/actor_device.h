@@ -272,6 +272,9 @@ struct ActorMfma {
 #ifndef SSC_ACT_PACKED
 #define SSC_ACT_PACKED 1
 #endif
+#ifndef SSC_ACT_SHARED_RCP
+#define SSC_ACT_SHARED_RCP 0
+#endif
 #ifndef SSC_ACT_STAGED
 #define SSC_ACT_STAGED 0
 #endif
@@ -418,6 +421,28 @@ struct ActorMfma2 {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) part[et][q & 1] = fmaf(e[q], w3[8 * b + q], part[et][q & 1]);
                 }
+        } else
+#endif
+#if SSC_ACT_SHARED_RCP && SSC_ACT_ABL != 1
+        if (LAST_TANH) {
+            // A/B variant (round-2 review, item 5): ONE reciprocal per PAIR of tanh -- r = 1 / ((1 + ea)(1 + eb)),
+            // 1 / (1 + ea) = r (1 + eb), 1 / (1 + eb) = r (1 + ea) -- i.e. 3 transcendentals per pair instead of 4, paid
+            // for with one v_mul and one v_pk_mul.  No overflow guard ((1 + ea)(1 + eb) overflows for pre-activations
+            // whose sum exceeds ~44): this build only measures the upper bound of the gain; see DESIGN.md section 4.3.
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 p2[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+#pragma unroll
+            for (int reg = 0; reg < 16; reg += 2)
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    f32x2 e = {__builtin_amdgcn_exp2f(acc2[et][reg]), __builtin_amdgcn_exp2f(acc2[et][reg + 1])};
+                    e += f32x2{1.0f, 1.0f};
+                    const float r = __builtin_amdgcn_rcpf(e.x * e.y);
+                    const f32x2 inv = f32x2{e.y, e.x} * f32x2{r, r};
+                    p2[et] = __builtin_elementwise_fma(inv, f32x2{w3[reg], w3[reg + 1]}, p2[et]);
+                }
+            part[0][0] = p2[0].x; part[0][1] = p2[0].y;
+            part[1][0] = p2[1].x; part[1][1] = p2[1].y;
         } else
 #endif
 #if SSC_ACT_PACKED && SSC_ACT_ABL != 1

@@ -1,0 +1,84 @@
+"""The DDPG path (actor forward + OU exploration + train step + target update, A8 / A9 / (f)-1 of SURVEY.md section 8)
+against the ONLY evidence the reference holds for it: the 125 learning curves it ships under
+data/ddpg_baselines_summaries/good_params/ (tests/golden/ddpg_good_params_curves.npz, made by
+tests/golden/make_ddpg_curves.py).  The reference's loop cannot be replayed step for step (TensorFlow initialisers and
+global MT19937 streams), so the comparison is distributional: scalar rlTrain(DDPG_Baselines_agent) runs through the HIP
+path with the reference's hyper-parameters must look like draws from the reference's own run-to-run distribution."""
+import json
+import time
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+E_TOTAL, LATE = 130, (90, 130)        # episodes per run; the "late" window whose median return is compared
+N_SEEDS = 8
+
+
+def reference_bands(golden_dir):
+    g = np.load(f"{golden_dir}/ddpg_good_params_curves.npz")
+    steps, rets = g["steps"].astype(np.int64), g["returns"].astype(np.float64)
+    goal = steps < 999                                              # TimeLimit(999) truncations are the [999, ...] records
+    first = np.array([int(np.argmax(r)) if r.any() else steps.shape[1] for r in goal])
+    late = np.median(rets[:, LATE[0]:LATE[1]], axis=1)
+    return dict(params=json.loads(str(g["param_dict"])), first=first, late=late,
+                first_band=np.percentile(first, [10, 90]), late_band=np.percentile(late, [10, 90]),
+                late_goal_rate=goal[:, LATE[0]:LATE[1]].mean(axis=1))
+
+
+def test_reference_curve_fixture_and_bands(golden_dir):
+    """(CPU) the fixture is what make_ddpg_curves.py extracts and the bands the GPU test uses are the reference's."""
+    b = reference_bands(golden_dir)
+    p = b["params"]
+    assert (p["actor_h1"], p["actor_h2"], p["critic_h1"], p["critic_h2"]) == (64, 32, 64, 32)
+    assert (p["batch_size"], p["num_train_iterations"], p["num_steps_before_train"], p["buffer_size"]) == (64, 1, 1, 100000)
+    assert (p["ou_mu"], p["ou_sigma"], p["ou_theta"], p["ou_epsilon_decay_factor"], p["ou_min_epsilon"]) == (0.4, 0.6, 0.15, 0.99, 0.01)
+    assert b["first"].shape == (125,)
+    assert b["first_band"][0] == 0 and 5 <= b["first_band"][1] <= 15          # first goal within the first ~10 episodes
+    assert 88.0 <= b["late_band"][0] <= 92.0 and 93.0 <= b["late_band"][1] <= 95.0
+    assert np.median(b["late_goal_rate"]) == 1.0
+
+
+@pytest.mark.gpu
+def test_scalar_rltrain_ddpg_learning_curves_fall_inside_the_reference_band(golden_dir):
+    """N_SEEDS x E_TOTAL episodes of rlTrain(DDPG_Baselines_agent) on stock MountainCarContinuous-v0 with the shipped
+    runs' hyper-parameters (examples/continuous/DDPG_Baselines_example.py:28-80): per seed the first episode that
+    reaches the goal and the median return of episodes 90..129.  The reference's own 125 runs define the inter-decile
+    bands; a seed outside a band is as likely as for a reference run (20 %), so: the across-seed MEDIANS lie inside the
+    bands and at most a quarter of the seeds lie outside each."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no fallback")
+    import smartstartcontinuous_amd as ssc
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    b = reference_bands(golden_dir)
+    p = b["params"]
+    firsts, lates, t0, n_steps = [], [], time.time(), 0
+    for seed in range(N_SEEDS):
+        np.random.seed(1000 + seed)
+        import random
+        random.seed(1000 + seed)
+        env = ssc.make("MountainCarContinuous-v0", seed=1000 + seed)
+        agent = DDPG_Baselines_agent(env, None, buffer_size=p["buffer_size"], batch_size=p["batch_size"],
+                                     num_train_iterations=p["num_train_iterations"], num_steps_before_train=p["num_steps_before_train"],
+                                     ou_epsilon=p["ou_epsilon"], ou_min_epsilon=p["ou_min_epsilon"],
+                                     ou_epsilon_decay_factor=p["ou_epsilon_decay_factor"], ou_mu=p["ou_mu"], ou_sigma=p["ou_sigma"],
+                                     ou_theta=p["ou_theta"], actor_lr=p["actor_lr"], actor_h1=p["actor_h1"], actor_h2=p["actor_h2"],
+                                     critic_lr=p["critic_lr"], critic_h1=p["critic_h1"], critic_h2=p["critic_h2"], gamma=p["gamma"],
+                                     tau=p["tau"], lastLayerTanh=p["lastLayerTanh"], seed=1000 + seed)
+        summary = ssc.rlTrain(agent, env, print_results=False, print_steps=False, num_episodes=E_TOTAL, max_steps=1000)
+        ep = np.asarray(summary.episodes, np.float64)
+        assert ep.shape == (E_TOTAL, 2)
+        n_steps += int(ep[:, 0].sum())
+        goal = ep[:, 0] < 999
+        firsts.append(int(np.argmax(goal)) if goal.any() else E_TOTAL)
+        lates.append(float(np.median(ep[LATE[0]:LATE[1], 1])))
+        print("seed %d: first goal episode %d, late median return %.2f, goals in the late window %d/%d (%.0f s so far, %d env-steps)"
+              % (seed, firsts[-1], lates[-1], int(goal[LATE[0]:LATE[1]].sum()), LATE[1] - LATE[0], time.time() - t0, n_steps), flush=True)
+    firsts, lates = np.asarray(firsts), np.asarray(lates)
+    fb, lb = b["first_band"], b["late_band"]
+    print("reference bands: first goal episode", fb, "late median return", lb, "| ours: median", np.median(firsts), np.median(lates))
+    assert fb[0] <= np.median(firsts) <= fb[1], (firsts, fb)
+    assert lb[0] <= np.median(lates) <= lb[1], (lates, lb)
+    assert np.sum((firsts < fb[0]) | (firsts > fb[1])) <= N_SEEDS // 4, (firsts, fb)
+    assert np.sum((lates < lb[0]) | (lates > lb[1])) <= N_SEEDS // 4, (lates, lb)
