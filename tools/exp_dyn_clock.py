@@ -7,7 +7,7 @@ import smartstartcontinuous_amd._ffi as F
 F.LIB_PATH = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "tools/_build/libssc_clk.so")
 import torch, numpy as np, time
 from exp_nav import make
-dims, M, H = (4, 500, 500, 3), 65536, 20
+dims, M, H = (4, 500, 500, 3), 65536, int(sys.argv[2]) if len(sys.argv) > 2 else 20
 model, d, a = make(dims)
 A = torch.rand((M, H, a), device="cuda") * 2 - 1
 s0 = torch.randn((M, d), device="cuda") * 0.3
