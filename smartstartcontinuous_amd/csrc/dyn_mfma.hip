@@ -42,12 +42,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t vu32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDynRows = 256;     // rows per block: 8 waves x two 16-row MFMA column tiles
 constexpr int kDynThreads = 512;
 constexpr int kNW = kDynThreads / 64;
 constexpr int kMaxIn = 12;        // network inputs (state + action)
 constexpr int kMaxKS1 = 2;        // layer-1 k-steps of 32 slots: 2 bias slots + 3 per input
+#ifndef SSC_DYN_LAG_BARRIER_PAIR
+#define SSC_DYN_LAG_BARRIER_PAIR 1
+#endif
+#ifndef SSC_DYN_LAG_PRIO
+#define SSC_DYN_LAG_PRIO 3
+#endif
+constexpr int kLagBarrierPair = SSC_DYN_LAG_BARRIER_PAIR;   // LAG kernel: layer-1 unit pair behind which group 0 takes its phase barrier
 // Diagnostic builds for tools/exp_dyn_clock.py (results are WRONG when set; never in libssc.so):
 //  1 no W2 stream (LDS-DMA never issued), 2 no ring barrier: price the tile-boundary work (tools/gpu_c4_ab.sh)
 // 16 clock stamps: every block overwrites S[32*block .. +31] with {d_memtime, d_memrealtime} of its step loop and
@@ -110,7 +118,18 @@ struct DynNet {
     const float *W1, *b1, *W2, *b2, *W3, *b3;  // W3/b3 = output layer; W2/b2 unused when nfc == 1
     int in, depth, out, nfc;
     bool biask;  // b2 in the spare k slots depth, depth+1 of the hidden contraction (needs depth + 2 <= 32*UT)
+    bool compact1;  // layer-1 fragments in the compact lane-group layout of the LAG kernel (see l1_compact below)
 };
+
+// Compact layer-1 layout (networks with <= 4 inputs on the streamed-W2 kernel): k group g = lane >> 4 of the MFMA carries
+// INPUT g alone -- slots 8g + {0, 1, 2} = {xh * wh, xl * wh, xh * wl}, slot 8g + 3 = 1 * (bf16 head of b1 in group 0, its
+// residual in group 1), slots 8g + 4..7 unused.  A lane then splits ONE input per step instead of selecting its eight
+// slots out of all of them (the per-step input code drops from ~120 to ~16 VALU ops per 16 rows), and a weight fragment
+// is 8 bytes per lane instead of 16: the layer-1 image is 16 KB instead of 32 KB, which is what buys the W2 ring its
+// fourth 32 KB slot.
+__host__ __device__ __forceinline__ bool l1_compact(int in, int out, int depth, int nfc) {
+    return nfc == 2 && depth > 128 && in <= 4 && out <= 4;
+}
 
 __device__ __forceinline__ __bf16 bf16_head(float v) { return (__bf16)v; }
 __device__ __forceinline__ __bf16 bf16_resid(float v) { return (__bf16)(v - (float)(__bf16)v); }
@@ -156,6 +175,23 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
         return;
     }
     e -= n_a3;
+    if (e < n_a1 && n.compact1) {   // [mt][64 lane][4]: slots 0..3 of the lane's k group (l1_compact)
+        if (e >= (int64_t)2 * UT * 64 * 4) return;
+        const int j = e & 3, lane = (e >> 2) & 63, mt = (int)(e >> 8);
+        const int i = lane >> 4, unit = mt * 16 + (lane & 15);
+        __bf16 v = (__bf16)0.0f;
+        if (unit < n.depth) {
+            if (j == 3) v = (i == 0) ? bf16_head(n.b1[unit]) : (i == 1 ? bf16_resid(n.b1[unit]) : (__bf16)0.0f);
+            else if (i < n.in) {
+                const float w = n.W1[(int64_t)i * n.depth + unit];
+                v = (j == 2) ? bf16_resid(w) : bf16_head(w);
+            }
+        } else if (n.biask && unit < n.depth + 2 && i == 0 && j == 3) {
+            v = (__bf16)1.0f;  // the carriers of b2 (see below)
+        }
+        reinterpret_cast<__bf16 *>(ws + pk.a1)[e] = v;
+        return;
+    }
     if (e < n_a1) {
         const int j = e & 7, lane = (e >> 3) & 63, mt = (int)((e >> 9) % (2 * UT)), ks = (int)((e >> 9) / (2 * UT));
         const int q = 32 * ks + 8 * (lane >> 4) + j, unit = mt * 16 + (lane & 15);
@@ -255,21 +291,41 @@ __host__ __device__ constexpr int dyn_a2_bufs() { return NFC == 2 ? (UT <= 4 ? U
 // KIN: compile-time bound on the network inputs AND outputs (4 covers MountainCar 3->2 and Pendulum 4->3; 10 is
 // what one layer-1 k-step holds): the per-step input/normalisation/state code is unrolled KIN times with
 // block-uniform guards, and layer 1 runs KS1(KIN) k-steps (unused slots carry zero weights).
-template <int UT, int NFC, bool BIASK, int KIN>
+//
+// LAG (streamed W2, <= 4 inputs: the BASELINE shape): the two wave groups of a SIMD run 1.5 tiles apart instead of half
+// a tile, so that one group's per-step phase (state update, input code, layer 1: VALU work, ~2 tiles long) runs while
+// the OTHER group still has W2 tiles to multiply, instead of both leaving the matrix pipe idle together:
+//   * the W2 ring has FOUR 32 KB slots (slot = tile & 3); the room comes from the compact layer-1 image (l1_compact);
+//   * barrier #k (k counts tiles over all steps) is taken by group 0 inside tile k at fragment X0 and by group 1 inside
+//     tile k - 1 at fragment X1; passing it retires every read of tile k - 2 and publishes tile k + 1, and after it a
+//     wave issues its pieces of tile k + 2 (group 0: at the start of tile k + 1; group 1: right behind the barrier);
+//   * group 0 takes the barrier of a step's tile 0 in the MIDDLE OF ITS PHASE instead (where group 1, inside tile 15 of
+//     the step before, arrives at about the same time) and runs tile 0 without one: its phase never makes group 1 wait
+//     for a barrier, and group 1's phase falls into group 0's tiles 0 and 1, which need none from it until X0 of tile 1;
+//   * every wave takes 16 H + 1 barriers: group 0 one per phase + tiles 1..15 + one behind its last tile, group 1 one in
+//     its first phase + one in every tile.
+// MODE (compile-time when >= 0): 0 simulation with the actions read from memory, 1 simulation drawing its candidate
+// actions itself, 2 plain forward; -1: decided by the run-time flags.  With the mode known the per-step input code holds
+// no load (mode 1), so no s_waitcnt vmcnt(0) in front of it has to sit out the LDS-DMA pieces still in flight.
+template <int UT, int NFC, bool BIASK, int KIN, bool LAG = false, int MODE = -1>
 __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs g) {
+    static_assert(!LAG || (UT == 16 && NFC == 2 && KIN == 4), "LAG: streamed W2 with the compact layer-1 layout");
     constexpr int DS = KIN < SSC_MAX_STATE ? KIN : SSC_MAX_STATE;  // state / output registers per row
     constexpr int KS1 = (2 + 3 * KIN + 31) / 32;                   // layer-1 k-steps compiled in
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const bool fwd_mode = MODE < 0 ? g.fwd_mode != 0 : MODE == 2;
+    const bool sample = MODE < 0 ? g.sample != 0 : MODE == 1;
     const uint64_t stamp_entry = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
     constexpr int MT = 2 * UT;          // 16-unit tiles of a hidden layer
     constexpr int A2_TILE = UT * 2048;  // W2^T fragments of one 32-unit output tile: NF fragments of 1 KiB
-    constexpr int NBUF = dyn_a2_bufs<UT, NFC>();
+    constexpr int NBUF = LAG ? 4 : dyn_a2_bufs<UT, NFC>();
     constexpr bool STREAM = (NFC == 2) && (UT > 4);
+    constexpr int A1_BYTES = LAG ? MT * 512 : KS1 * MT * 1024;   // layer-1 fragments: 8 B per lane when compact
     constexpr int A2_CHUNKS = A2_TILE / 1024;           // LDS-DMA pieces per tile
     constexpr int PPW = (A2_CHUNKS + kNW - 1) / kNW;    // pieces per wave per tile
     unsigned char *l_a2 = lds;
     unsigned char *l_a1 = l_a2 + NBUF * A2_TILE;
-    unsigned char *l_a3 = l_a1 + KS1 * MT * 1024;
+    unsigned char *l_a3 = l_a1 + A1_BYTES;
     float *l_b2 = reinterpret_cast<float *>(l_a3 + UT * 512);
     float *l_b3 = l_b2 + UT * 32;
 
@@ -289,7 +345,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     const __amdgpu_buffer_rsrc_t a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char *>(g.a2), 0, NFC == 2 ? UT * A2_TILE : 0, 0x00020000);   // reads past the end return 0
     {
-        constexpr int A1_PIECES = KS1 * MT;              // 1 KiB each
+        constexpr int A1_PIECES = A1_BYTES / 1024;       // 1 KiB each
         constexpr int A3_BYTES = UT * 512;
         const __amdgpu_buffer_rsrc_t a1_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned char *>(g.a1), 0, A1_PIECES * 1024, 0x00020000);
@@ -327,7 +383,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         row[nt] = (int64_t)blockIdx.x * kDynRows + wave * 32 + nt * 16 + c;
         valid[nt] = row[nt] < g.m;
         rowc[nt] = valid[nt] ? row[nt] : g.m - 1;
-        if (!g.fwd_mode) {
+        if (!fwd_mode) {
 #pragma unroll
             for (int k = 0; k < DS; ++k)
                 st[nt][k] = (k < g.d) ? g.s0[(rowc[nt] / g.s0_rows) * g.d + k] : 0.0f;   // s0_rows: rows per start state
@@ -345,14 +401,14 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     u32x4 wcache[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
     int wc = -1;  // Philox call the cached words belong to (block-uniform)
     uint64_t tt = 0;
-    if (g.sample) {
+    if (sample) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
             sid[nt] = ((g.pid0 + (uint64_t)(rowc[nt] / g.N)) << 32) + (uint64_t)(rowc[nt] % g.N);
         tt = (g.t + (g.t_base != nullptr ? *g.t_base : 0)) * (uint64_t)((g.H * g.a + 3) / 4);
     }
     auto fetch_actions = [&](int ts) {
-        if (g.sample) {
+        if (sample) {
 #pragma unroll
             for (int ai = 0; ai < AMAX; ++ai)
                 if (ai < g.a) {
@@ -382,7 +438,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int ai = 0; ai < AMAX; ++ai) act[nt][ai] = 0.0f;
-    if (!g.fwd_mode && g.H > 0) fetch_actions(0);
+    if (!fwd_mode && g.H > 0) fetch_actions(0);
 
     // Normalisation constants per network input (input k = state k for k < d, else action k-d) and per state
     // delta, read once through scalar loads: block-uniform, so they live in SGPRs and the per-step input code
@@ -400,6 +456,18 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         z_mean[k] = (k < g.d) ? uniform_f32(g.nm[4 * 8 + k]) : 0.0f;
         z_std[k] = (k < g.d) ? uniform_f32(g.nm[5 * 8 + k]) : 0.0f;
     }
+    // LAG: this lane's k group carries network input kg alone (l1_compact): its mean / 1/std, and the constant-1 slot
+    // (bias carrier) in k groups 0 and 1
+    float my_mean = 0.0f, my_inv = 0.0f;
+    uint32_t my_one = 0;
+    if (LAG) {
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) {
+            my_mean = (kg == k) ? n_mean[k] : my_mean;
+            my_inv = (kg == k) ? n_inv[k] : my_inv;
+        }
+        my_one = (kg < 2) ? 0x3F800000u : 0u;
+    }
 
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA pieces (and every load above)
     __syncthreads();
@@ -414,16 +482,55 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     }
     const uint64_t stamp_c0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memtime() : 0;
     const uint64_t stamp_r0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
-    uint64_t ph[4] = {0, 0, 0, 0};  // diagnostic: cycles in input code / layer 1 / hidden tiles / step tail
+    uint64_t ph[6] = {0, 0, 0, 0, 0, 0};  // diagnostic: cycles in input code / layer 1 / hidden tiles / step tail / phase barrier / tile barriers
 #define SSC_STAMP(var) uint64_t var = 0; if (SSC_DYN_ABLATE & 16) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     for (int t = 0; t < g.H; ++t) {
         SSC_STAMP(stamp_a)
         // ---- inputs: record S[t]; layer-1 B fragments of x = normalised (state, action) ---------------
         bf16x8 xf[2][KS1];
+        s16x4 xc[2];   // LAG: the compact layer-1 B fragments (four k slots per lane)
+        if constexpr (LAG) {
+            // The phase is what the other wave of this SIMD has to bridge with W2 tiles: it runs at raised issue priority
+            // (set behind the last hidden tile, dropped again in front of the first one) ...
+            if (t == 0) __builtin_amdgcn_s_setprio(SSC_DYN_LAG_PRIO);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float xv;
+                if (fwd_mode) {
+                    xv = (kg < g.in) ? g.A[rowc[nt] * g.in + kg] : 0.0f;
+                } else {
+                    xv = st[nt][0];
+#pragma unroll
+                    for (int k = 1; k < DS; ++k) xv = (kg == k) ? st[nt][k] : xv;       // (k >= d: overwritten below or unused)
+#pragma unroll
+                    for (int ai = 0; ai < AMAX; ++ai) xv = (kg - g.d == ai) ? act[nt][ai] : xv;
+                }
+                uint32_t xh, xl;
+                split_bf16(fwd_mode ? xv : zscore(xv, my_mean, my_inv), xh, xl);   // plain forward: x is fed as it is
+                typedef uint32_t vu32x2 __attribute__((ext_vector_type(2)));
+                // slots 0, 1: xh * wh, xl * wh; slots 2, 3: xh * wl, 1 * bias part
+                xc[nt] = __builtin_bit_cast(s16x4, vu32x2{xh | (xl << 16), xh | my_one});
+            }
+            // ... and everything that ENTERS the memory queue comes behind the input code: the actions above may come
+            // from global loads, so the compiler waits for vmcnt(0) in front of their first use -- which would also wait
+            // for stores and LDS-DMA issued a few instructions earlier (a full L2 round trip at the head of the phase)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (!fwd_mode) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    if (valid[nt] && kg == 0) {
+                        float *sp = g.S + ((int64_t)t * g.m + row[nt]) * g.d;
+#pragma unroll
+                        for (int k = 0; k < DS; ++k)
+                            if (k < g.d) sp[k] = st[nt][k];  // dynamics_model.py:225
+                    }
+            }
+        } else {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float xs[KIN];
-            if (g.fwd_mode) {
+            if (fwd_mode) {
 #pragma unroll
                 for (int k = 0; k < KIN; ++k) xs[k] = (k < g.in) ? g.A[rowc[nt] * g.in + k] : 0.0f;
             } else {
@@ -467,10 +574,26 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 xf[nt][ks] = __builtin_bit_cast(bf16x8, w);
             }
         }
+        }
         SSC_STAMP(stamp_l)
         // ---- layer 1: D[unit][row] = W1^T x + b1 -> ReLU -> bf16 B fragments of the next layer ------
         bf16x8 h1f[2][UT];
         struct L1 { f32x4 d[2][2]; };  // [16-unit half][column tile]
+        // LAG: the weight fragments of a unit pair are requested kL1Ahead pairs before their MFMAs (the registers of the
+        // previous step's hidden fragments are free here): under the other wave's W2 stream an LDS read takes longer
+        // than the pair in front of it
+        constexpr int kL1Ahead = 4;
+        s16x4 a1q[LAG ? UT : 1][2];
+        auto l1_request = [&](int p) {
+            if constexpr (LAG) {
+                a1q[p][0] = *reinterpret_cast<const s16x4 *>(l_a1 + ((2 * p + 0) * 64 + lane) * 8);
+                a1q[p][1] = *reinterpret_cast<const s16x4 *>(l_a1 + ((2 * p + 1) * 64 + lane) * 8);
+            }
+        };
+        if constexpr (LAG) {
+#pragma unroll
+            for (int q = 0; q < kL1Ahead; ++q) l1_request(q);
+        }
         auto layer1_pair = [&](int p) {
             L1 o;
 #pragma unroll
@@ -479,9 +602,18 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 o.d[mh][1] = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < KS1; ++ks) {  // no runtime bound: a branch here would serialise every LDS read
-                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a1 + ((ks * MT + 2 * p + mh) * 64 + lane) * 16);
-                    o.d[mh][0] = mfma16(a, xf[0][ks], o.d[mh][0]);
-                    o.d[mh][1] = mfma16(a, xf[1][ks], o.d[mh][1]);
+                    if constexpr (LAG) {
+                        // compact image: 8 B per lane = the four k slots of this lane's k group, which is exactly the
+                        // operand of v_mfma_f32_16x16x16_bf16 (same 16 cycles as the K = 32 shape, same D layout, but
+                        // two-register operands: no zero padding to build)
+                        const s16x4 a = a1q[p][mh];
+                        o.d[mh][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, xc[0], o.d[mh][0], 0, 0, 0);
+                        o.d[mh][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, xc[1], o.d[mh][1], 0, 0, 0);
+                    } else {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a1 + ((ks * MT + 2 * p + mh) * 64 + lane) * 16);
+                        o.d[mh][0] = mfma16(a, xf[0][ks], o.d[mh][0]);
+                        o.d[mh][1] = mfma16(a, xf[1][ks], o.d[mh][1]);
+                    }
                 }
             }
             return o;
@@ -491,6 +623,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             pp[0] = layer1_pair(0);
 #pragma unroll
             for (int p = 0; p < UT; ++p) {
+                if (LAG && p + kL1Ahead < UT) l1_request(p + kL1Ahead);
                 if (p + 1 < UT) pp[(p + 1) & 1] = layer1_pair(p + 1);
                 h1f[0][p] = relu_to_frag(pp[p & 1].d[0][0], pp[p & 1].d[1][0]);
                 h1f[1][p] = relu_to_frag(pp[p & 1].d[0][1], pp[p & 1].d[1][1]);
@@ -499,11 +632,34 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 // fp32 accumulator tiles alive until then -> hundreds of spills.
                 asm volatile("" : "+v"(h1f[0][p]), "+v"(h1f[1][p]));
                 __builtin_amdgcn_sched_barrier(0);  // and one unit pair at a time in the machine scheduler
+                if constexpr (LAG) {
+                    // barrier #16 t: group 0 takes the barrier of this step's tile 0 HERE, about where group 1 (inside
+                    // tile 15 of the step before) reaches it; in step 0 group 1 takes its first one here as well and
+                    // then issues its pieces of tile 2 (later steps: in tile 15 of the step before)
+                    if (p == kLagBarrierPair && (group == 0 || t == 0)) {
+                        if (!(SSC_DYN_ABLATE & 2)) {
+                            SSC_STAMP(stamp_p0)
+                            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile 1 landed
+                            asm volatile("" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+                            SSC_STAMP(stamp_p1)
+                            ph[4] += stamp_p1 - stamp_p0;
+                        }
+                        if (group == 1) {
+#pragma unroll
+                            for (int q = 0; q < PPW; ++q)
+                                if (!(SSC_DYN_ABLATE & 1))
+                                    lds_dma_1k(a2_rsrc, lane * 16, 2 * A2_TILE + (wave + q * kNW) * 1024, l_a2 + 2 * A2_TILE + (wave + q * kNW) * 1024);
+                        }
+                    }
+                }
             }
         }
+        if constexpr (LAG) __builtin_amdgcn_s_setprio(0);
         // the actions of the next step: issued here, behind layer 1's scheduling fences, so that the loads fly
         // under the hidden tiles (hoisted to the top of the step they were waited for at once)
-        if (!g.fwd_mode && t + 1 < g.H) fetch_actions(t + 1);
+        if (!fwd_mode && t + 1 < g.H) fetch_actions(t + 1);
         // ---- hidden layer 2 (+ output layer fused per tile) -------------------------------------
         f32x4 acc3[2];
         acc3[0] = acc3[1] = *reinterpret_cast<const f32x4 *>(l_b3 + kg * 4);
@@ -523,17 +679,21 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             //    the slot of tile tl-1, a few fragments apart so that their issue cost hides under MFMAs.
             //    The issue is unconditional: past the last tile it re-loads a tile nobody reads, and group 0
             //    in tile 0 re-loads the (identical) bytes of tile 1.
-            auto tile_body = [&](auto group_tag, int jt) {
+            auto tile_body = [&](auto group_tag, auto first_tag, int jt) {
                 constexpr int GROUP = decltype(group_tag)::value;
+                constexpr bool FIRST = decltype(first_tag)::value == 1;   // LAG, group 0, tile 0: no barrier, nothing to issue
+                // LAG, group 0, tile 15: behind its barrier (#15) the pieces of the NEXT step's tile 1 go out as well --
+                // the phase that follows takes barrier #16, which wants them landed (step 0: loaded by the prologue)
+                constexpr bool LAST = decltype(first_tag)::value == 2;
                 constexpr int X0 = NF - RING - 1, X1 = X0 - NF / 2;   // barrier fragment of group 0 / group 1
                 static_assert(!STREAM || (UT == 16 && X1 + 2 + 4 * (PPW - 1) < NF), "LDS-DMA issue slots");
-                const int nsel = STREAM ? (bsel == 2 ? 0 : bsel + 1) : ((jt + 1) & (UT - 1));
-                const unsigned char *buf = l_a2 + (STREAM ? bsel : jt) * A2_TILE + lane * 16;
+                const int nsel = LAG ? ((jt + 1) & 3) : STREAM ? (bsel == 2 ? 0 : bsel + 1) : ((jt + 1) & (UT - 1));
+                const unsigned char *buf = l_a2 + (LAG ? (jt & 3) : STREAM ? bsel : jt) * A2_TILE + lane * 16;
                 const unsigned char *nbuf = l_a2 + nsel * A2_TILE + lane * 16;
                 // group 0 is past barrier tl-1 -> its pieces of tile tl+1; group 1 passes barrier tl at X1 ->
-                // pieces of tile tl+2
-                const int dma_jn = (jt + 1 + GROUP) & (UT - 1);
-                const int dma_slot = (bsel + 1 + GROUP) % 3;
+                // pieces of tile tl+2.  LAG: group 1 passes barrier jt+1 inside tile jt -> pieces of tile jt+3
+                const int dma_jn = (jt + 1 + (LAG ? 2 : 1) * GROUP) & (UT - 1);
+                const int dma_slot = LAG ? (dma_jn & 3) : (bsel + 1 + GROUP) % 3;
                 const int dma_src = dma_jn * A2_TILE + wave * 1024;
                 unsigned char *dma_dst = l_a2 + dma_slot * A2_TILE + wave * 1024;
                 f32x4 acc[2][2];  // [16-unit half][column tile]
@@ -552,12 +712,17 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                     acc[f & 1][1] = mfma16(a, h1f[1][f >> 1], acc[f & 1][1]);
                     if (STREAM) {
                         const int f0 = GROUP ? X1 + 2 : 1;  // first issue slot after this group's barrier
-                        if (f >= f0 && (f - f0) % 4 == 0 && (f - f0) / 4 < PPW) {
+                        if (!FIRST && f >= f0 && (f - f0) % 4 == 0 && (f - f0) / 4 < PPW) {
                             const int p = (f - f0) / 4;
                             if (!(SSC_DYN_ABLATE & 1))   // ablation 1: no W2 stream (wrong results; prices the LDS-DMA issue)
                                 lds_dma_1k(a2_rsrc, lane * 16, dma_src + p * kNW * 1024, dma_dst + p * kNW * 1024);
                         }
-                        if (!(SSC_DYN_ABLATE & 2) && f == (GROUP ? X1 : X0)) {  // barrier tl (ablation 2: none)
+                        if (LAST && f > X0 && f - X0 - 1 < PPW && !(SSC_DYN_ABLATE & 1)) {
+                            const int p = f - X0 - 1;
+                            lds_dma_1k(a2_rsrc, lane * 16, 1 * A2_TILE + (wave + p * kNW) * 1024, l_a2 + 1 * A2_TILE + (wave + p * kNW) * 1024);
+                        }
+                        if (!FIRST && !(SSC_DYN_ABLATE & 2) && f == (GROUP ? X1 : X0)) {  // barrier tl (ablation 2: none)
+                            SSC_STAMP(stamp_t0)
                             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tl+1 landed
 #if SSC_DYN_BARRIER_KEEP_LDS_READS
                             // A bare s_barrier: __syncthreads() also waits for lgkmcnt(0), i.e. drains the fragment ring
@@ -571,6 +736,8 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
 #else
                             __syncthreads();
 #endif
+                            SSC_STAMP(stamp_t1)
+                            ph[5] += stamp_t1 - stamp_t0;
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -583,12 +750,16 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             };
             SSC_STAMP(stamp_b)
             if (!STREAM || group == 0) {
+                if constexpr (LAG) tile_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0);
 #pragma unroll 1
-                for (int jt = 0; jt < UT; ++jt) tile_body(std::integral_constant<int, 0>{}, jt);
+                for (int jt = LAG ? 1 : 0; jt < (LAG ? UT - 1 : UT); ++jt) tile_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, jt);
+                if constexpr (LAG) tile_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, UT - 1);
             } else {
 #pragma unroll 1
-                for (int jt = 0; jt < UT; ++jt) tile_body(std::integral_constant<int, 1>{}, jt);
+                for (int jt = 0; jt < UT; ++jt) tile_body(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, jt);
             }
+            // the phase ahead (state update, input code, layer 1) is what the other wave of this SIMD has to bridge
+            if constexpr (LAG) __builtin_amdgcn_s_setprio(SSC_DYN_LAG_PRIO);
             SSC_STAMP(stamp_d)
             if (SSC_DYN_ABLATE & 16) { ph[0] += stamp_l - stamp_a; ph[1] += stamp_b - stamp_l; ph[2] += stamp_d - stamp_b; ph[3] -= stamp_d; }
         } else {
@@ -614,7 +785,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                     z[4 + r] = (kg & 1) ? acc3[nt][r] : other;
                 }
             }
-            if (g.fwd_mode) {
+            if (fwd_mode) {
                 if (valid[nt] && kg == 0) {
 #pragma unroll
                     for (int o = 0; o < DS; ++o)
@@ -627,7 +798,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         }
         if ((SSC_DYN_ABLATE & 16) && NFC == 2) { SSC_STAMP(stamp_e) ph[3] += stamp_e; }
     }
-    if (!g.fwd_mode) {
+    if (!fwd_mode) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
             if (valid[nt] && kg == 0) {
@@ -636,16 +807,22 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                     if (k < g.d) g.S[((int64_t)g.H * g.m + row[nt]) * g.d + k] = st[nt][k];  // :240
             }
     }
+    // LAG: group 1's last tile holds barrier #16 H; group 0 meets it here (no phase follows its last tile)
+    if (LAG && group == 0 && g.H > 0 && !(SSC_DYN_ABLATE & 2)) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+    }
     // group 1 issued LDS-DMA after its last barrier: it must land before this workgroup's LDS is released
     if (STREAM) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (SSC_DYN_ABLATE & 16) {
         const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c0, dr = __builtin_amdgcn_s_memrealtime() - stamp_r0;
-        if (lane == 0 && (wave == 0 || wave == 4)) {  // per block 2 x 16 dwords (wave 0, wave 4): {dc, dr}, 4 phase sums, entry and loop-start realtime
-            uint32_t *o = reinterpret_cast<uint32_t *>(g.S) + 32 * blockIdx.x + 16 * group;
+        if (lane == 0 && (wave == 0 || wave == 4)) {  // per block 2 x 24 dwords (wave 0, wave 4): {dc, dr}, 4 phase sums, entry and loop-start realtime, 2 barrier sums
+            uint32_t *o = reinterpret_cast<uint32_t *>(g.S) + 48 * blockIdx.x + 24 * group;
             o[0] = (uint32_t)dc; o[1] = (uint32_t)(dc >> 32); o[2] = (uint32_t)dr; o[3] = (uint32_t)(dr >> 32);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { o[4 + 2 * k] = (uint32_t)ph[k]; o[5 + 2 * k] = (uint32_t)(ph[k] >> 32); }
             o[12] = (uint32_t)stamp_entry; o[13] = (uint32_t)(stamp_entry >> 32); o[14] = (uint32_t)stamp_r0; o[15] = (uint32_t)(stamp_r0 >> 32);
+            o[16] = (uint32_t)ph[4]; o[17] = (uint32_t)(ph[4] >> 32); o[18] = (uint32_t)ph[5]; o[19] = (uint32_t)(ph[5] >> 32);
         }
     }
 }
@@ -670,11 +847,11 @@ size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp) {
     return make_pack(tiles_for(mlp->dims[1]), nfc).total;
 }
 
-template <int UT, int NFC, bool BIASK, int KIN>
+template <int UT, int NFC, bool BIASK, int KIN, bool LAG = false, int MODE = -1>
 static int launch_sim(const DynSimArgs &g, hipStream_t s) {
-    const size_t lds = (size_t)dyn_a2_bufs<UT, NFC>() * UT * 2048 + (size_t)l1_ksteps(KIN) * UT * 2048 + (size_t)UT * 512 +
-                       (size_t)UT * 128 + 64;
-    auto kern = dyn_mfma_sim_kernel<UT, NFC, BIASK, KIN>;
+    const size_t lds = (size_t)(LAG ? 4 : dyn_a2_bufs<UT, NFC>()) * UT * 2048 +
+                       (LAG ? (size_t)UT * 1024 : (size_t)l1_ksteps(KIN) * UT * 2048) + (size_t)UT * 512 + (size_t)UT * 128 + 64;
+    auto kern = dyn_mfma_sim_kernel<UT, NFC, BIASK, KIN, LAG, MODE>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -691,6 +868,7 @@ static DynNet make_net(const ssc_mlp_desc *mlp, int UT) {
     DynNet n;
     n.in = mlp->dims[0]; n.depth = mlp->dims[1]; n.out = mlp->dims[mlp->n_layers]; n.nfc = nfc;
     n.biask = (nfc == 2) && (n.depth + 2 <= 32 * UT);
+    n.compact1 = l1_compact(n.in, n.out, n.depth, nfc);
     n.W1 = mlp->W[0]; n.b1 = mlp->b[0];
     n.W2 = (nfc == 2) ? mlp->W[1] : nullptr; n.b2 = (nfc == 2) ? mlp->b[1] : nullptr;
     n.W3 = mlp->W[nfc]; n.b3 = mlp->b[nfc];
@@ -726,6 +904,14 @@ static int run_mfma(const ssc_mlp_desc *mlp, DynSimArgs &g, void *wsv, hipStream
 #define SSC_DYN_CASE(U, F, B)                                                                 \
     if (UT == U && nfc == F && n.biask == B)                                                  \
         return kin == 4 ? launch_sim<U, F, B, 4>(g, s) : kin == 10 ? launch_sim<U, F, B, 10>(g, s) : launch_sim<U, F, B, kMaxIn>(g, s)
+    if (n.compact1) {   // streamed W2, <= 4 inputs and outputs (the BASELINE shape): the 4-slot, 1.5-tile-lag kernel
+        const int mode = g.fwd_mode ? 2 : (g.sample ? 1 : 0);
+        if (n.biask)
+            return mode == 2 ? launch_sim<16, 2, true, 4, true, 2>(g, s) : mode == 1 ? launch_sim<16, 2, true, 4, true, 1>(g, s)
+                                                                                     : launch_sim<16, 2, true, 4, true, 0>(g, s);
+        return mode == 2 ? launch_sim<16, 2, false, 4, true, 2>(g, s) : mode == 1 ? launch_sim<16, 2, false, 4, true, 1>(g, s)
+                                                                                  : launch_sim<16, 2, false, 4, true, 0>(g, s);
+    }
     SSC_DYN_CASE(1, 1, false); SSC_DYN_CASE(4, 1, false); SSC_DYN_CASE(16, 1, false);
     SSC_DYN_CASE(1, 2, false); SSC_DYN_CASE(4, 2, false); SSC_DYN_CASE(16, 2, false);
     SSC_DYN_CASE(1, 2, true); SSC_DYN_CASE(4, 2, true); SSC_DYN_CASE(16, 2, true);

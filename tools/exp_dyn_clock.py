@@ -12,14 +12,22 @@ model, d, a = make(dims)
 A = torch.rand((M, H, a), device="cuda") * 2 - 1
 s0 = torch.randn((M, d), device="cuda") * 0.3
 S = torch.empty((H + 1, M, d), device="cuda")
+SAMPLE = len(sys.argv) > 3 and sys.argv[3] == "sample"      # the MPC step's form: candidate actions drawn in the kernel
+if SAMPLE:
+    from smartstartcontinuous_amd import navigator as nav
+    sp = nav.mpc_sampling(4096, [-1.0] * a, [1.0] * a, 1234, 0, 0)
+    s0p = s0[:16].contiguous()
+    run = lambda: model.do_forward_sim_sampled(s0p, sp, M, H, precision="bf16_mfma", out=S)
+else:
+    run = lambda: model.do_forward_sim(s0, A, precision="bf16_mfma", out=S)
 t0 = time.time()
 while time.time() - t0 < 2.0:
     for _ in range(50):
-        model.do_forward_sim(s0, A, precision="bf16_mfma", out=S)
+        run()
     torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); model.do_forward_sim(s0, A, precision="bf16_mfma", out=S); e1.record(); torch.cuda.synchronize()
-raw = S.view(torch.int32).flatten()[: 32 * (M // 256)].cpu().numpy().astype(np.uint32).reshape(-1, 2, 8, 2).astype(np.uint64)
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
+raw = S.view(torch.int32).flatten()[: 48 * (M // 256)].cpu().numpy().astype(np.uint32).reshape(-1, 2, 12, 2).astype(np.uint64)
 v = raw[..., 0] | (raw[..., 1] << np.uint64(32))       # [block][group][dc, dr, input, layer 1, hidden tiles, tail, entry_rt, loop_rt]
 dc, dr = v[:, 0, 0], v[:, 0, 1]
 clk = dc / dr * 100.0
@@ -28,7 +36,8 @@ print("launch %.4f ms; blocks %d; step-loop cycles median %.0f (%.0f per step); 
       % (e0.elapsed_time(e1), len(dc), np.median(dc), np.median(dc) / H, np.median(dr) / 100.0, np.median(clk), clk.min(), clk.max(), mf, 100.0 * mf / np.median(dc)))
 for gi in range(2):
     ph = np.median(v[:, gi, 2:6].astype(np.int64), axis=0) / H
-    print("group %d per step: input code %.0f, layer 1 %.0f, hidden tiles %.0f (%.0f each), step tail %.0f cycles" % (gi, ph[0], ph[1], ph[2], ph[2] / 16, ph[3]))
+    bw = np.median(v[:, gi, 8:10].astype(np.int64), axis=0) / H
+    print("group %d per step: input code %.0f, layer 1 %.0f (of which phase barrier %.0f), hidden tiles %.0f (%.0f each; barrier waits %.0f in all), step tail %.0f cycles" % (gi, ph[0], ph[1], bw[0], ph[2], ph[2] / 16, bw[1], ph[3]))
 entry, loop0 = v[:, 0, 6].astype(np.int64), v[:, 0, 7].astype(np.int64)
 exit_ = loop0 + v[:, 0, 1].astype(np.int64)
 # a block whose stamp dwords were overwritten by another block's late S[0] rows shows absurd values: drop it
