@@ -402,11 +402,23 @@ def next_rows(torch):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)
     learner_ms = timed(lambda: agent.train_on(s, a, r, t, s, idx, n_it))
+    # the multi-workgroup learner (csrc/ddpg_train_wide.hip) over the reference's own network grid
+    # (data/ddpg_baselines_summaries/hidden_layer_size_experiment/) at batch sizes that spread over 16..256 workgroups
+    wide = {}
+    for h1, h2, B in ((128, 64, 256), (200, 100, 256), (200, 100, 1024), (64, 32, 4096)):
+        ag = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, actor_h1=h1, actor_h2=h2, critic_h1=h1, critic_h2=h2,
+                                  lastLayerTanh=True, seed=1, training=False, batch_size=B)
+        n_w = 100
+        idx_w = torch.randint(0, cap, (n_w, B), dtype=torch.int32, device="cuda")
+        ms = timed(lambda: ag.train_on(s, a, r, t, s, idx_w, n_w))
+        wide["%d-%d/batch%d" % (h1, h2, B)] = {"us_per_iteration": ms / n_w * 1e3, "samples_per_s": B * n_w / (ms * 1e-3)}
     pts = s[torch.randint(0, cap, (2000,), device="cuda")]
     wh, norm = SS.kde_scott_bandwidth(s)
     kde_ms = timed(lambda: SS.kde_evaluate(s, pts, wh, norm), warm=3)
     return {"ddpg_learner_us_per_iteration": learner_ms / n_it * 1e3,
             "ddpg_learner_note": "ssc_ddpg_train, batch 64, actor/critic 64-32, %d iterations in one launch" % n_it,
+            "ddpg_learner_wide": wide,
+            "ddpg_learner_wide_note": "ssc_ddpg_train_ws on the multi-workgroup path (batch / 16 workgroups, two launches per iteration), 100 iterations per call",
             "kde_2000x100000_ms": kde_ms}
 
 

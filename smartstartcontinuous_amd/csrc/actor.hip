@@ -39,6 +39,22 @@ __global__ __launch_bounds__(kBlock) void actor_mfma_kernel(ActorWeights w, int6
     if (active) act[i] = a;
 }
 
+// wide shapes (h1 <= 224, h2 <= 128): W2 fragments staged in LDS
+template <int OBS, int UT, int JT>
+__global__ __launch_bounds__(kBlock) void actor_mfma_lds_kernel(ActorWeights w, int64_t m, const float *__restrict__ obs,
+                                                                float *__restrict__ act) {
+    const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = gi < m;
+    const int64_t i = active ? gi : m - 1;  // whole waves must run the collective forward
+    float o[OBS];
+#pragma unroll
+    for (int c = 0; c < OBS; ++c) o[c] = clip_obs(obs[i * OBS + c], w.obs_clip);
+    ActorMfmaLds<OBS, UT, JT> net;
+    net.init(w);
+    const float a = net.forward(o);
+    if (active) act[i] = a;
+}
+
 // any sizes (obs_dim <= SSC_MAX_STATE, act_dim <= SSC_MAX_ACT, h1 <= 512): one row per lane,
 // layer-1 activations parked in LDS as [unit][lane] (conflict-free), layer 2 folded into
 // layer 3 on the fly.  64-thread blocks; LDS = h1 * 256 B.
@@ -94,9 +110,14 @@ extern "C" int ssc_actor_forward(const ssc_actor_desc *a, int64_t m, const float
     hipStream_t s = as_stream(stream);
     const dim3 grid(blocks_for(m)), block(kBlock);
     if (a->precision == SSC_PREC_BF16_MFMA) {
-        if (a->act_dim != 1 || (a->obs_dim != 2 && a->obs_dim != 3) || a->h1 > 128 || a->h2 > 64)
+        if (a->act_dim != 1 || (a->obs_dim != 2 && a->obs_dim != 3) || a->h1 > 224 || a->h2 > 128)
             return set_error(SSC_EUNSUPPORTED,
-                             "ssc_actor_forward: MFMA path needs obs_dim 2|3, act_dim 1, h1 <= 128, h2 <= 64");
+                             "ssc_actor_forward: MFMA path needs obs_dim 2|3, act_dim 1, h1 <= 224, h2 <= 128");
+        if (a->h1 > 128 || a->h2 > 64) {
+            if (a->obs_dim == 2) hipLaunchKernelGGL((actor_mfma_lds_kernel<2, 7, 4>), grid, block, 0, s, w, m, d_obs, d_act);
+            else hipLaunchKernelGGL((actor_mfma_lds_kernel<3, 7, 4>), grid, block, 0, s, w, m, d_obs, d_act);
+            return check_launch("ssc_actor_forward(mfma, lds)");
+        }
         const bool small = a->h1 <= 64 && a->h2 <= 32;
         if (a->obs_dim == 2) {
             if (small) hipLaunchKernelGGL((actor_mfma_kernel<2, 2, 1>), grid, block, 0, s, w, m, d_obs, d_act);

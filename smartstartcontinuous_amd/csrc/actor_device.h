@@ -250,6 +250,146 @@ struct ActorMfma {
 };
 
 // ---------------------------------------------------------------------------------------
+// ActorMfmaLds<OBS,UT,JT>: the same network for the wide shapes of the reference's grid (actor 200-100 of
+// data/ddpg_baselines_summaries/hidden_layer_size_experiment/; anything up to 32 UT x 32 JT units).  ActorMfma keeps the
+// W2^T fragments in registers (JT * UT * 8 VGPRs: 224 for 200-100, beside 128 accumulator registers); here they are
+// STAGED ONCE PER BLOCK IN LDS as ready-made bf16 A fragments -- [jt][ut][s][lane] x 16 B, one conflict-free
+// ds_read_b128 per fragment, each feeding the MFMAs of both 32-env tiles of the wave (56 KB for 200-100; the four waves
+// of a block share it) -- together with b1, b2 and W3 in accumulator order.  Layer 1 stays on the exact-f32 MFMA with its
+// K <= 4 weights in registers; the data flow from there on is ActorMfma's (accumulator tile -> ReLU -> bf16 -> B operand).
+template <int OBS, int UT, int JT>
+struct ActorMfmaLds {
+    static constexpr int kLanesPerEnv = 1;
+    static constexpr int ET = 2;
+    static constexpr int KS1 = (OBS + 1) / 2;
+    float a1[UT][KS1];
+    const unsigned char *l_a2;   // bf16 [JT][UT][2][64 lanes][8]
+    const float *l_b1, *l_b2, *l_w3;   // [UT * 32], [JT * 32] (x cs), [JT * 32] (x -2 when last_tanh)
+    float b3;
+    int last_tanh;
+
+    // block-cooperative: every thread of the block must call it
+    __device__ void init(const ActorWeights &w) {
+        __shared__ __attribute__((aligned(16))) unsigned char s_a2[JT * UT * 2 * 1024];
+        __shared__ __attribute__((aligned(16))) float s_b1[UT * 32], s_b2[JT * 32], s_w3[JT * 32];
+        const int lane = threadIdx.x & 63;
+        const int r = lane & 31, half = lane >> 5;
+        const int H1 = w.h1, H2 = w.h2;
+        last_tanh = w.last_layer_tanh;
+        const float cs = last_tanh ? 2.88539008177792681472f : 1.0f;   // see ActorMfma::init
+        for (int e = threadIdx.x; e < JT * UT * 2 * 64 * 8; e += blockDim.x) {
+            const int j = e & 7, ln = (e >> 3) & 63, sq = (e >> 9) & 1, ut = (e >> 10) % UT, jt = (e >> 10) / UT;
+            const int col = jt * 32 + (ln & 31);
+            const int u = ut * 32 + 16 * sq + 8 * (j >> 2) + 4 * (ln >> 5) + (j & 3);   // k slot -> hidden unit (ActorMfma::init)
+            const float v = (u < H1 && col < H2) ? w.W2[u * H2 + col] * cs : 0.0f;
+            reinterpret_cast<__bf16 *>(s_a2)[e] = (__bf16)v;
+        }
+        for (int e = threadIdx.x; e < UT * 32; e += blockDim.x) s_b1[e] = (e < H1) ? w.b1[e] : 0.0f;
+        for (int e = threadIdx.x; e < JT * 32; e += blockDim.x) {
+            s_b2[e] = (e < H2) ? w.b2[e] * cs : 0.0f;
+            s_w3[e] = (e < H2) ? w.W3[e] * (last_tanh ? -2.0f : 1.0f) : 0.0f;
+        }
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            const int unit = ut * 32 + r;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int k = 2 * ks + half;
+                a1[ut][ks] = (k < OBS && unit < H1) ? w.W1[k * H1 + unit] : 0.0f;
+            }
+        }
+        b3 = w.b3[0];
+        if (last_tanh)
+            for (int j = 0; j < H2; ++j) b3 += w.W3[j];
+        __syncthreads();
+        l_a2 = s_a2 + lane * 16;
+        l_b1 = s_b1 + 4 * half;
+        l_b2 = s_b2 + 4 * half;
+        l_w3 = s_w3 + 4 * half;
+    }
+
+    // 16 consecutive accumulator registers of unit tile `tile` from an LDS vector in unit order: register reg holds unit
+    // tile * 32 + acc_row(reg, half) = 4 floats at tile * 32 + 8 * (reg >> 2) (+ 4 * half, folded into the pointer)
+    static __device__ __forceinline__ f32x16 acc_layout(const float *v, int tile) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f32x16 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f4 x = *reinterpret_cast<const f4 *>(v + tile * 32 + 8 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[4 * q + i] = x[i];
+        }
+        return o;
+    }
+
+    __device__ float forward(const float (&obs)[OBS]) const {
+        float bop[ET][KS1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const float v0 = obs[2 * ks];
+            const float v1 = (2 * ks + 1 < OBS) ? obs[2 * ks + 1] : 0.0f;
+            half_swap(v0, v1, bop[0][ks], bop[1][ks]);
+        }
+        f32x16 acc2[JT][ET];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            acc2[jt][0] = acc_layout(l_b2, jt);
+            acc2[jt][1] = acc2[jt][0];
+        }
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            bf16x8 frag[ET][2];
+            const f32x16 c1 = acc_layout(l_b1, ut);
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+                f32x16 d = c1;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks)
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[ut][ks], bop[et][ks], d, 0, 0, 0);
+#pragma unroll
+                for (int sq = 0; sq < 2; ++sq) {
+                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+                    i32x4 packed;  // relu (models_editted.py:47) + bf16 convert
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) packed[j] = relu_pack_bf16(d[8 * sq + 2 * j], d[8 * sq + 2 * j + 1]);
+                    frag[et][sq] = __builtin_bit_cast(bf16x8, packed);
+                }
+            }
+#pragma unroll
+            for (int sq = 0; sq < 2; ++sq)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a2 + ((jt * UT + ut) * 2 + sq) * 1024);
+                    acc2[jt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[0][sq], acc2[jt][0], 0, 0, 0);
+                    acc2[jt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[1][sq], acc2[jt][1], 0, 0, 0);
+                }
+        }
+        float part[ET] = {0.0f, 0.0f};
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const f32x16 w3 = acc_layout(l_w3, jt);
+            if (last_tanh) {   // wave-uniform
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+                    for (int et = 0; et < ET; ++et) {
+                        const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc2[jt][et][reg]) + 1.0f);
+                        part[et] = fmaf(rr, w3[reg], part[et]);
+                    }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+                    for (int et = 0; et < ET; ++et) part[et] = fmaf(fmaxf(acc2[jt][et][reg], 0.0f), w3[reg], part[et]);
+            }
+        }
+        float s_lo, s_hi;
+        half_swap(part[0], part[1], s_lo, s_hi);
+        return tanh_fast(s_lo + s_hi + b3);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
 // ActorMfma2<LAST_TANH>: the shipped shape (obs_dim 2, h1 <= 64, h2 <= 32; BASELINE config 3) with BOTH
 // contractions on the bf16 MFMA and no lane movement on the way in.
 //

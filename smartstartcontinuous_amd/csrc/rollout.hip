@@ -566,7 +566,10 @@ static int dispatch_policy(const typename EnvT::Const &ec, const ssc_policy_desc
             return launch_rollout<EnvT, ActorPolicy<ActorMfma<OBS, 2, 1, 2>, OBS>>(ec, pa, ra, stream);
         if (a.h1 <= 128 && a.h2 <= 64)
             return launch_rollout<EnvT, ActorPolicy<ActorMfma<OBS, 4, 2, 2>, OBS>>(ec, pa, ra, stream);
-        return set_error(SSC_EUNSUPPORTED, "ssc_rollout: MFMA actor supports h1 <= 128, h2 <= 64 (got %d-%d)",
+        // the wide shapes of the reference's grid (200-100): W2 fragments staged in LDS (ActorMfmaLds)
+        if (a.h1 <= 224 && a.h2 <= 128)
+            return launch_rollout<EnvT, ActorPolicy<ActorMfmaLds<OBS, 7, 4>, OBS>>(ec, pa, ra, stream);
+        return set_error(SSC_EUNSUPPORTED, "ssc_rollout: MFMA actor supports h1 <= 224, h2 <= 128 (got %d-%d)",
                          a.h1, a.h2);
     }
     return set_error(SSC_EINVAL, "ssc_rollout: unknown precision %d", a.precision);

@@ -46,7 +46,7 @@ def _actor_forward_gpu(ssc, w, obs, precision, last_layer_tanh=True, act_dim=1):
 def test_actor_forward_f32_and_mfma(ssc, obs_dim, llt):
     ffi = ssc._ffi
     rng = np.random.default_rng(10 + obs_dim)
-    for (h1, h2) in [(64, 32), (128, 64), (48, 24)]:
+    for (h1, h2) in [(64, 32), (128, 64), (48, 24), (200, 100), (160, 96)]:   # 200-100: W2 fragments staged in LDS
         w = actor_weights(obs_dim, h1, h2, seed=h1 + obs_dim, w3_scale=0.3)
         for m in (1, 63, 1000, 4096 + 17):
             obs = rng.uniform(-1.2, 1.2, size=(m, obs_dim)).astype(np.float32)
@@ -122,6 +122,35 @@ def test_rollout_actor_mountaincar_teacher_forced(ssc, precision, tol):
         emu = O.OracleDDPGPolicy(w, seed, id0, n, bf16=True)
         res = O.replay_rollout("mc", _log(chunk), seed, id0, 3, 999, obs0, np.full(n, 970), emu)
         assert res["max_dact"] <= TOL_ACT_BF16_EMU, res
+
+
+@pytest.mark.parametrize("env_id,h1,h2", [("MountainCarContinuous-v0", 200, 100), ("MountainCarContinuous-v0", 128, 64),
+                                          ("Pendulum-v0", 200, 100)])
+def test_rollout_actor_wide_shapes_teacher_forced(ssc, env_id, h1, h2):
+    """The reference's actor grid beyond 64-32 (data/ddpg_baselines_summaries/hidden_layer_size_experiment/: 128-64 and
+    200-100) in the FUSED rollout: 128-64 keeps its W2 fragments in registers, 200-100 stages them in LDS (ActorMfmaLds)."""
+    n, K, seed, id0 = 700, 24, 99, 11
+    pend = env_id.startswith("Pendulum")
+    obs_dim = 3 if pend else 2
+    w = actor_weights(obs_dim, h1, h2, seed=h1, w3_scale=0.4)
+    env = ssc.VecEnv(env_id, n, seed=seed, env_id0=id0)
+    obs0 = env.reset().cpu().numpy()
+    start = 190 if pend else 990
+    env.steps.fill_(start)         # time-limit reset (and OU reset) inside the window
+    env.t = 5
+    pol = ssc.ActorPolicy({k: torch.as_tensor(v) for k, v in w.items()}, precision="bf16_mfma", obs_clip=5.0)
+    chunk = env.rollout(K, pol)
+    torch.cuda.synchronize()
+    low, high = (-2.0, 2.0) if pend else (-1.0, 1.0)
+    oracle_pol = O.OracleDDPGPolicy(w, seed, id0, n, bf16=False, low=low, high=high, obs_clip=5.0)
+    res = O.replay_rollout("pend" if pend else "mc", _log(chunk), seed, id0, 5, 200 if pend else 999, obs0,
+                           np.full(n, start), oracle_pol)
+    assert res["start_max_err"] == 0 and res["continuity_mismatch"] == 0 and res["done_mismatch"] == 0, res
+    assert res["max_dact"] <= TOL_ACT_BF16 * (high - low) / 2, res
+    emu = O.OracleDDPGPolicy(w, seed, id0, n, bf16=True, low=low, high=high, obs_clip=5.0)
+    res = O.replay_rollout("pend" if pend else "mc", _log(chunk), seed, id0, 5, 200 if pend else 999, obs0,
+                           np.full(n, start), emu)
+    assert res["max_dact"] <= TOL_ACT_BF16_EMU * (high - low) / 2 * 2, res
 
 
 @pytest.mark.parametrize("llt", [True, False])

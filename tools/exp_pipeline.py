@@ -6,12 +6,20 @@ import torch
 import smartstartcontinuous_amd as ssc
 from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
 
-for n_envs, chunk, iters, overlap in [(65536, 256, 50, False), (65536, 256, 50, True), (65536, 256, 500, False),
-                                      (65536, 256, 500, True), (4096, 64, 50, False), (4096, 64, 50, True), (256, 40, 50, False)]:
+# (envs, chunk steps, learner iterations per chunk, overlap, batch, actor/critic hidden sizes); batches != 64 and layers wider than
+# 64 run on the multi-workgroup learner (ddpg_train_wide.hip): batch / 16 workgroups per iteration
+CASES = [(65536, 256, 50, False, 64, (64, 32)), (65536, 256, 50, True, 64, (64, 32)), (65536, 256, 500, False, 64, (64, 32)),
+         (65536, 256, 500, True, 64, (64, 32)), (4096, 64, 50, False, 64, (64, 32)), (4096, 64, 50, True, 64, (64, 32)),
+         (256, 40, 50, False, 64, (64, 32)),
+         (65536, 256, 10, False, 1024, (64, 32)), (65536, 256, 10, False, 4096, (64, 32)), (65536, 256, 50, False, 4096, (64, 32)),
+         (65536, 256, 10, False, 1024, (200, 100)), (65536, 256, 10, False, 4096, (200, 100))]
+if len(sys.argv) > 1 and sys.argv[1] == "wide":
+    CASES = CASES[7:]
+for n_envs, chunk, iters, overlap, batch, (h1, h2) in CASES:
     env = ssc.VecEnv("MountainCarContinuous-v0", n_envs, seed=1)
     env.reset()
-    agent = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, batch_size=64, num_train_iterations=iters,
-                                 actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32, lastLayerTanh=True, seed=3)
+    agent = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, batch_size=batch, num_train_iterations=iters,
+                                 actor_h1=h1, actor_h2=h2, critic_h1=h1, critic_h2=h2, lastLayerTanh=True, seed=3)
     ssc.rl_train_vec_ddpg(env, agent, num_chunks=2, chunk_steps=chunk, replay_capacity=1 << 20, replay_last_steps=16,
                           overlap=overlap)
     torch.cuda.synchronize()
@@ -21,6 +29,7 @@ for n_envs, chunk, iters, overlap in [(65536, 256, 50, False), (65536, 256, 50, 
                                                     replay_capacity=1 << 20, replay_last_steps=16, overlap=overlap)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps(dict(n_envs=n_envs, chunk_steps=chunk, overlap=overlap, train_iters_per_chunk=iters, ms_per_chunk=dt / n_chunks * 1e3,
+    print(json.dumps(dict(n_envs=n_envs, chunk_steps=chunk, overlap=overlap, train_iters_per_chunk=iters, batch=batch, nets="%d-%d" % (h1, h2),
+                          samples_trained_per_env_step=iters * batch / float(n_envs * chunk), ms_per_chunk=dt / n_chunks * 1e3,
                           env_steps_per_s=n_envs * chunk * n_chunks / dt, learner_iters_per_s=iters * n_chunks / dt,
                           episodes=len(summary.episodes))), flush=True)
