@@ -355,14 +355,21 @@ struct ActorMfmaLds {
                     frag[et][sq] = __builtin_bit_cast(bf16x8, packed);
                 }
             }
+            // the 2 JT fragments of this unit tile, each read one fragment ahead of its two MFMAs (the scheduler otherwise
+            // puts every read right in front of its wait: an LDS round trip per fragment with an idle matrix pipe)
+            bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a2 + ((0 * UT + ut) * 2 + 0) * 1024);
+            __builtin_amdgcn_sched_barrier(0);   // the first read stays in front of the groups below
 #pragma unroll
-            for (int sq = 0; sq < 2; ++sq)
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(l_a2 + ((jt * UT + ut) * 2 + sq) * 1024);
-                    acc2[jt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[0][sq], acc2[jt][0], 0, 0, 0);
-                    acc2[jt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[1][sq], acc2[jt][1], 0, 0, 0);
-                }
+            for (int q = 0; q < 2 * JT; ++q) {
+                const int sq = q / JT, jt = q % JT;
+                const int qn = (q + 1 < 2 * JT) ? q + 1 : q;
+                const bf16x8 an = *reinterpret_cast<const bf16x8 *>(l_a2 + (((qn % JT) * UT + ut) * 2 + qn / JT) * 1024);
+                acc2[jt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[0][sq], acc2[jt][0], 0, 0, 0);
+                acc2[jt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[1][sq], acc2[jt][1], 0, 0, 0);
+                a = an;
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // ... then the two MFMAs of the fragment before it
+            }
         }
         float part[ET] = {0.0f, 0.0f};
 #pragma unroll
