@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSC_VERSION 100 /* 0.1.0 */
+#define SSC_VERSION 101 /* 0.1.1: plan pool in ssc_mpc_problems, ssc_smartstart_rollout_step */
 
 typedef void *ssc_stream_t; /* hipStream_t */
 
@@ -253,6 +253,11 @@ typedef struct ssc_mpc_problems {
     float theta, gamma, horizontal_penalty_factor; /* :143, :62 */
     int32_t per_row_projection; /* 0 = reference behaviour (batch-global np.sum, numerical.py:89-92);
                                    1 = corrected per-sample projection (NOT the reference) */
+    /* Optional plan POOL (the vectorised SmartStart loop: many envs follow one of a few stored plans).  Both NULL:
+     * problem p owns plan p, as described above.  Otherwise problem p follows plan q = plan_of[p]: its waypoints are
+     * rows wp_off[q] .. wp_off[q] + wp_len[q] - 1 of wp / left and its radii row q of radii; cur_idx stays per problem. */
+    const int32_t *plan_of; /* device [P] or NULL */
+    const int32_t *wp_len;  /* device [number of plans] or NULL (required with plan_of) */
 } ssc_mpc_problems;
 
 /* all_samples = npr.uniform(low, high, (N, H, act)) (NND_MB_agent.py:500-501) for P problems:
@@ -343,6 +348,40 @@ int ssc_mpc_rollout_step(const ssc_env_params *p, const ssc_mpc_problems *proble
                          uint64_t problem_id0, const ssc_rollout_state *state, const ssc_transition_log *log,
                          const ssc_episode_ring *ring, double *d_stats, uint64_t env_seed, uint64_t env_id0,
                          uint64_t *d_t, int32_t *d_k, int32_t *d_ticket, float *d_plan_state, ssc_stream_t stream);
+
+/* One step of the VECTORISED SmartStartContinuous loop (smartstart/smartexploration/smartexplorationcontinuous.py:
+ * 307-376) for P envs, everything after the scoring in ONE launch -- ssc_mpc_rollout_step with a per-env mode:
+ *   mode[p] = 1  "smart_start_pathing": the executed action is the navigator's (best_sequence[0] + noise, as above), the
+ *                waypoint bookkeeping runs on the new observation, and close_enough_to_goal hands the env over to
+ *                the base agent (mode 0) for the rest of the episode (:333-339);
+ *   mode[p] = 0  the base agent acts: d_actor_out[p] (Actor_Editted on the clipped planning state, ssc_actor_forward)
+ *                + epsilon * OU noise, clip, scale twice -- DDPG_Baselines_agent.get_action, the OU state advancing
+ *                only on these steps, stream and arithmetic of ssc_rollout's ACTOR policy.
+ * A finished episode (goal / TimeLimit) resets the env and the OU state and runs start_new_episode (:341-370): with
+ * probability *d_eta (uniform draw: word x of Philox(env_seed; env id, t, tag 8); plan: word y) the env takes a plan out of the pool
+ * -- slot (pool[0] + word % pool[1]) % pool[2] of the plan arrays behind problems->plan_of, if pool[1] > 0 -- starts it
+ * at waypoint 0 and navigates unless the reset state is already close enough to the plan's goal.
+ * d_eta, d_ou_epsilon (one float each) and d_pool (int32[3]: first slot, plans on offer, slots) are DEVICE values, so a
+ * captured HIP graph of the step keeps following the host's decay schedule and pool refreshes.  d_mode_log (may be
+ * NULL) receives the mode each env ACTED in, row *d_k of a [K][P] byte matrix.  problems->plan_of must be writable. */
+typedef struct ssc_smartstart_step {
+    uint8_t *mode;               /* [P] */
+    int32_t *plan_of;            /* [P] == problems->plan_of */
+    const float *d_actor_out;    /* [P] */
+    const float *d_eta, *d_ou_epsilon;
+    const int32_t *d_pool;       /* [3] */
+    ssc_ou_desc ou;              /* epsilon field unused (d_ou_epsilon) */
+    float act_low, act_high;
+    uint8_t *d_mode_log;         /* [K][P] or NULL */
+    int64_t mode_log_stride;     /* row stride of d_mode_log (0: P) */
+} ssc_smartstart_step;
+
+int ssc_smartstart_rollout_step(const ssc_env_params *p, const ssc_mpc_problems *problems, const ssc_mpc_nav_state *nav,
+                                const ssc_smartstart_step *ss, const float *d_A, const int32_t *d_best_idx,
+                                float noise_amount, uint64_t noise_seed, uint64_t problem_id0,
+                                const ssc_rollout_state *state, const ssc_transition_log *log, const ssc_episode_ring *ring,
+                                double *d_stats, uint64_t env_seed, uint64_t env_id0, uint64_t *d_t, int32_t *d_k,
+                                int32_t *d_ticket, float *d_plan_state, ssc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * SmartStart selection (smartstart/smartexploration/smartexplorationcontinuous.py:223-305)

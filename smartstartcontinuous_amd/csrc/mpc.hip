@@ -154,8 +154,9 @@ constexpr int kWinFloats = kWinMax * (SSC_MAX_STATE + 1) + SSC_MAX_STATE;   // w
 
 // lanes `lane` of `nl` cooperating lanes stage problem p's window; the caller synchronises them afterwards
 __device__ __forceinline__ void load_window(const MpcArgs &a, int p, int lane, int nl, float *win, int &W, int &idx0) {
-    const int off = a.wp_off[p];
-    const int Wabs = a.wp_off[p + 1] - off;
+    const int q = plan_index(a, p);     // == p unless the problems share a plan pool
+    const int off = a.wp_off[q];
+    const int Wabs = plan_len(a, q);
     const int iabs = a.cur_idx[p];
     const int wb = max(iabs - 1, 0);
     const int cnt = max(min(Wabs - wb, a.H + 4), 0);
@@ -163,7 +164,7 @@ __device__ __forceinline__ void load_window(const MpcArgs &a, int p, int lane, i
     const float *wsrc = a.wp + (int64_t)(off + wb) * a.d;
     for (int e = lane; e < cnt * a.d; e += nl) wps[e] = wsrc[e];
     for (int e = lane; e < cnt; e += nl) lefts[e] = a.left[off + wb + e];
-    if (lane < a.d) inv_r[lane] = 1.0f / a.radii[p * a.d + lane];
+    if (lane < a.d) inv_r[lane] = 1.0f / a.radii[q * a.d + lane];
     W = Wabs - wb;
     idx0 = iabs - wb;
 }
@@ -552,7 +553,7 @@ static int mpc_score_common(const char *who, const ssc_mpc_problems *pr, const f
     hipStream_t s = as_stream(stream);
     MpcArgs a;
     a.P = pr->n_problems; a.N = pr->n_samples; a.H = pr->horizon; a.d = pr->state_dim;
-    a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx;
+    a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx; a.plan_of = pr->plan_of; a.wp_len = pr->wp_len;
     a.theta = pr->theta; a.gamma = pr->gamma; a.hpf = pr->horizontal_penalty_factor;
     a.per_row = pr->per_row_projection;
     a.nblk = (a.N + kMpcBlock - 1) / kMpcBlock;
@@ -631,7 +632,7 @@ int ssc_mpc_observe(const ssc_mpc_problems *pr, const float *d_new_state, int32_
                 "ssc_mpc_observe: NULL device pointer");
     MpcArgs a{};
     a.P = pr->n_problems; a.d = pr->state_dim;
-    a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx;
+    a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx; a.plan_of = pr->plan_of; a.wp_len = pr->wp_len;
     a.theta = pr->theta;
     hipLaunchKernelGGL(mpc_observe_kernel, dim3((a.P + 63) / 64), dim3(64), 0, as_stream(stream), a, d_new_state,
                        d_cur_idx, d_actions_done, give_up_after, final_steps, d_at_goal);

@@ -9,10 +9,17 @@ struct MpcArgs {
     int32_t P, N, H, d;
     const float *wp, *left, *radii;
     const int32_t *wp_off, *cur_idx;
+    const int32_t *plan_of, *wp_len;   // optional plan pool (ssc_mpc_problems): problem p follows plan plan_of[p]
     float theta, gamma, hpf;
     int32_t per_row;
     int32_t nblk;  // blocks per problem
 };
+
+// the plan problem p follows, and that plan's waypoint count
+__device__ __forceinline__ int plan_index(const MpcArgs &a, int p) { return a.plan_of != nullptr ? a.plan_of[p] : p; }
+__device__ __forceinline__ int plan_len(const MpcArgs &a, int q) {
+    return a.plan_of != nullptr ? a.wp_len[q] : a.wp_off[q + 1] - a.wp_off[q];
+}
 
 // distance_func of numerical.py:116-124: || (x - y) / radii ||
 __device__ __forceinline__ float ell_dist(const float *x, const float *y, const float *inv_r, int d) {
@@ -30,10 +37,11 @@ __device__ __forceinline__ float ell_dist(const float *x, const float *y, const 
 // advances idx / done_act in place, returns the at-goal flag.
 __device__ __forceinline__ bool nav_observe_one(const MpcArgs &a, int p, const float *x, int &idx, int &done_act,
                                                 int give_up, int final_steps) {
-    const int off = a.wp_off[p], W = a.wp_off[p + 1] - off, d = a.d;
+    const int q = plan_index(a, p);
+    const int off = a.wp_off[q], W = plan_len(a, q), d = a.d;
     float inv_r[SSC_MAX_STATE];
 #pragma unroll
-    for (int k = 0; k < SSC_MAX_STATE; ++k) inv_r[k] = (k < d) ? 1.0f / a.radii[p * d + k] : 0.0f;
+    for (int k = 0; k < SSC_MAX_STATE; ++k) inv_r[k] = (k < d) ? 1.0f / a.radii[q * d + k] : 0.0f;
     const float *wp = a.wp + (int64_t)off * d;
     const float dc = ell_dist(x, wp + idx * d, inv_r, d);                        // :364
     const float dn = ell_dist(x, wp + min(idx + 1, W - 1) * d, inv_r, d);        // :365

@@ -597,8 +597,19 @@ struct MpcStepArgs {
     float *plan_state;
 };
 
-template <class EnvT>
-__global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT::Const ec, RolloutArgs ra, MpcStepArgs ma) {
+// the vectorised SmartStartContinuous step (ssc_smartstart_rollout_step): per-env mode on top of the MPC step
+struct SsStepArgs {
+    uint8_t *mode;
+    int32_t *plan_of;
+    const float *actor_out, *d_eta, *d_eps;
+    const int32_t *d_pool;
+    float ou_mu, ou_sig_sqrt_dt, ou_theta_dt, act_low, act_high;
+    uint8_t *mode_log;
+    int64_t mode_log_stride;
+};
+
+template <class EnvT, bool SS = false>
+__global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT::Const ec, RolloutArgs ra, MpcStepArgs ma, SsStepArgs sa) {
     constexpr int OBS = EnvT::OBS;
     const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = gi < ra.n;
@@ -614,12 +625,42 @@ __global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT:
         float ep_ret = ra.st.ep_ret[i];
         float obs[OBS], obs2[OBS];
         env.observe(obs);
-        // action = best_sequence[0] + noise * N(0,1), no clip (NND_MB_agent.py:353-356; ssc_mpc_select_action's draw)
-        const int64_t row = i * ma.nav.N + ma.best_idx[i];
-        float a = ma.A[row * ma.nav.H];   // act_dim == 1 (the envs of this engine)
-        if (ma.noise != 0.0f) {
-            const u32x4 w = rng_words(ma.noise_seed, ma.problem_id0 + (uint64_t)i, t, TAG_MPC_NOISE);
-            a += ma.noise * gaussian_f32(w.x, w.y);
+        // SmartStartContinuous.get_action (smartexplorationcontinuous.py:307-317): the navigator while smart_start_pathing,
+        // the base agent otherwise
+        bool navigating = true;
+        float ou_x = 0.0f;
+        if (SS) {
+            navigating = sa.mode[i] != 0;
+            ou_x = ra.st.ou_x[i];
+            if (sa.mode_log != nullptr) sa.mode_log[(int64_t)k * sa.mode_log_stride + i] = navigating ? 1 : 0;
+        }
+        float a;
+        if (navigating) {
+            // action = best_sequence[0] + noise * N(0,1), no clip (NND_MB_agent.py:353-356; ssc_mpc_select_action's draw)
+            const int64_t row = i * ma.nav.N + ma.best_idx[i];
+            a = ma.A[row * ma.nav.H];   // act_dim == 1 (the envs of this engine)
+            if (ma.noise != 0.0f) {
+                const u32x4 w = rng_words(ma.noise_seed, ma.problem_id0 + (uint64_t)i, t, TAG_MPC_NOISE);
+                a += ma.noise * gaussian_f32(w.x, w.y);
+            }
+        } else {
+            // DDPG_Baselines_agent.get_action (:206-240): actor + epsilon * OU, clip, scale twice -- ActorPolicy::act's
+            // arithmetic and noise stream; the OU state moves on these steps only (the agent is not asked while navigating)
+            a = sa.actor_out[i];
+            const float eps = fmaxf(*sa.d_eps, 0.0f);
+            if (eps > 0.0f) {
+                const u32x4 w = rng_words(ra.seed, ra.env_id0 + (uint64_t)i, t >> 2, TAG_OU);
+                const float g = ou_gaussian_from_words(w, t);
+                ou_x = fmaf(sa.ou_sig_sqrt_dt, g, fmaf(sa.ou_theta_dt, sa.ou_mu - ou_x, ou_x));
+                a = fmaf(ou_x, eps, a);
+            }
+            a = fminf(fmaxf(a, -1.0f), 1.0f);
+            const bool identity = sa.act_low == -1.0f && sa.act_high == 1.0f;
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                a = fminf(fmaxf(a, -1.0f), 1.0f);
+                a = identity ? a : fmaf((a + 1.0f) * 0.5f, sa.act_high - sa.act_low, sa.act_low);
+            }
         }
         env.step(ec, a, rew, goal);
         env.observe(obs2);
@@ -642,9 +683,14 @@ __global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT:
 #pragma unroll
         for (int c = 0; c < SSC_MAX_STATE; ++c) x[c] = (c < OBS) ? obs2[c < OBS ? c : 0] : 0.0f;
         int idx = ma.cur_idx[i];
-        int done_act = ma.actions_done[i] + 1;
-        const bool at_goal = nav_observe_one(ma.nav, (int)i, x, idx, done_act, ma.give_up, ma.final_steps);
+        int done_act = ma.actions_done[i];
+        bool at_goal = false;
+        if (navigating) {
+            done_act += 1;
+            at_goal = nav_observe_one(ma.nav, (int)i, x, idx, done_act, ma.give_up, ma.final_steps);
+        }
         if (ma.at_goal != nullptr) ma.at_goal[i] = at_goal ? 1 : 0;
+        if (SS && navigating && at_goal) navigating = false;     // :336-339: the base agent takes over
         if (done) {
             if (ra.has_ring) {
                 const uint32_t slot = atomicAdd(ra.ring.cursor, 1u);
@@ -659,7 +705,34 @@ __global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT:
             ep_ret = 0.0f;
             idx = ma.start_idx[i];    // start_new_episode_plan (:383-384)
             done_act = 0;
-            if (ra.st.ou_x != nullptr) ra.st.ou_x[i] = 0.0f;
+            if (!SS && ra.st.ou_x != nullptr) ra.st.ou_x[i] = 0.0f;
+            if (SS) {
+                ou_x = 0.0f;              // DDPG_Baselines_agent.end_episode: noise reset (:255-258)
+                // SmartStartContinuous.start_new_episode (:341-370) on the reset state
+                navigating = false;
+                const u32x4 w = rng_words(ra.seed, ra.env_id0 + (uint64_t)i, t, TAG_SS_EPISODE);
+                const int first = sa.d_pool[0], count = sa.d_pool[1], slots = sa.d_pool[2];
+                if (count > 0 && (float)(w.x >> 8) * (1.0f / 16777216.0f) <= *sa.d_eta) {   // np.random.rand() <= eta (:350)
+                    const int q = (first + (int)(w.y % (uint32_t)count)) % slots;
+                    sa.plan_of[i] = q;    // read by the scorer of the next step (same stream)
+                    idx = 0;
+                    // close_enough_to_goal(state) with a fresh plan (:425-432): the goal test alone
+                    float xr[SSC_MAX_STATE], obs_r[OBS];
+                    env.observe(obs_r);
+#pragma unroll
+                    for (int c = 0; c < SSC_MAX_STATE; ++c) xr[c] = (c < OBS) ? obs_r[c < OBS ? c : 0] : 0.0f;
+                    const int W = ma.nav.wp_len[q], d = ma.nav.d;
+                    float inv_r[SSC_MAX_STATE];
+#pragma unroll
+                    for (int c = 0; c < SSC_MAX_STATE; ++c) inv_r[c] = (c < d) ? 1.0f / ma.nav.radii[q * d + c] : 0.0f;
+                    const float *goal_wp = ma.nav.wp + ((int64_t)ma.nav.wp_off[q] + W - 1) * d;
+                    navigating = !(ell_dist(xr, goal_wp, inv_r, d) <= ma.nav.theta);
+                }
+            }
+        }
+        if (SS) {
+            sa.mode[i] = navigating ? 1 : 0;
+            ra.st.ou_x[i] = ou_x;
         }
         ra.st.s0[i] = env.s0();
         ra.st.s1[i] = env.s1();
@@ -775,24 +848,23 @@ extern "C" int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *polic
     return set_error(SSC_EINVAL, "ssc_rollout: unknown env kind %d", p->kind);
 }
 
-extern "C" int ssc_mpc_rollout_step(const ssc_env_params *p, const ssc_mpc_problems *pr, const ssc_mpc_nav_state *nav,
-                                    const float *d_A, const int32_t *d_best_idx, float noise_amount, uint64_t noise_seed,
-                                    uint64_t problem_id0, const ssc_rollout_state *state, const ssc_transition_log *log,
-                                    const ssc_episode_ring *ring, double *d_stats, uint64_t env_seed, uint64_t env_id0,
-                                    uint64_t *d_t, int32_t *d_k, int32_t *d_ticket, float *d_plan_state,
-                                    ssc_stream_t stream) {
-    SSC_REQUIRE(p && pr && nav && state, "ssc_mpc_rollout_step: NULL descriptor");
+// argument checks and packing shared by ssc_mpc_rollout_step and ssc_smartstart_rollout_step
+static int build_mpc_step_args(const char *fn, const ssc_env_params *p, const ssc_mpc_problems *pr, const ssc_mpc_nav_state *nav,
+                               const float *d_A, const int32_t *d_best_idx, float noise_amount, uint64_t noise_seed,
+                               uint64_t problem_id0, const ssc_rollout_state *state, const ssc_transition_log *log,
+                               const ssc_episode_ring *ring, double *d_stats, uint64_t env_seed, uint64_t env_id0,
+                               uint64_t *d_t, int32_t *d_k, int32_t *d_ticket, float *d_plan_state, RolloutArgs &ra, MpcStepArgs &ma) {
+    SSC_REQUIRE(p && pr && nav && state, "%s: NULL descriptor", fn);
     const int64_t n = pr->n_problems;
-    SSC_REQUIRE(n >= 0 && pr->n_samples >= 1 && pr->horizon >= 1, "ssc_mpc_rollout_step: bad problem sizes");
-    if (n == 0) return SSC_OK;
+    SSC_REQUIRE(n >= 0 && pr->n_samples >= 1 && pr->horizon >= 1, "%s: bad problem sizes", fn);
     const int obs_dim = (p->kind == SSC_ENV_MOUNTAINCAR) ? 2 : 3;
-    SSC_REQUIRE(pr->state_dim == obs_dim, "ssc_mpc_rollout_step: the navigator plans in observation space (%d dims), "
-                                          "problems have %d", obs_dim, pr->state_dim);
+    SSC_REQUIRE(pr->state_dim == obs_dim, "%s: the navigator plans in observation space (%d dims), "
+                                          "problems have %d", fn, obs_dim, pr->state_dim);
     SSC_REQUIRE(pr->wp && pr->wp_off && pr->radii && nav->cur_idx && nav->start_idx && nav->actions_done,
-                "ssc_mpc_rollout_step: NULL navigator pointer");
-    SSC_REQUIRE(state->s0 && state->s1 && state->steps && state->ep_ret, "ssc_mpc_rollout_step: NULL state column");
-    SSC_REQUIRE(d_A && d_best_idx && d_t && d_k && d_ticket && d_plan_state, "ssc_mpc_rollout_step: NULL device pointer");
-    RolloutArgs ra;
+                "%s: NULL navigator pointer", fn);
+    SSC_REQUIRE((pr->plan_of == nullptr) == (pr->wp_len == nullptr), "%s: plan_of and wp_len go together", fn);
+    SSC_REQUIRE(state->s0 && state->s1 && state->steps && state->ep_ret, "%s: NULL state column", fn);
+    SSC_REQUIRE(d_A && d_best_idx && d_t && d_k && d_ticket && d_plan_state, "%s: NULL device pointer", fn);
     ra.n = n;
     ra.K = 1;
     ra.st = *state;
@@ -802,18 +874,18 @@ extern "C" int ssc_mpc_rollout_step(const ssc_env_params *p, const ssc_mpc_probl
     if (log) {
         ra.log = *log;
         for (int c = 0; c < obs_dim; ++c)
-            SSC_REQUIRE(log->obs[c] && log->obs2[c], "ssc_mpc_rollout_step: NULL log obs column %d", c);
-        SSC_REQUIRE(log->act && log->rew && log->done, "ssc_mpc_rollout_step: NULL log column");
+            SSC_REQUIRE(log->obs[c] && log->obs2[c], "%s: NULL log obs column %d", fn, c);
+        SSC_REQUIRE(log->act && log->rew && log->done, "%s: NULL log column", fn);
         if (ra.log.row_stride == 0) ra.log.row_stride = n;
         if (ra.log.done_row_stride == 0) ra.log.done_row_stride = n;
-        SSC_REQUIRE(ra.log.row_stride >= n && ra.log.done_row_stride >= n, "ssc_mpc_rollout_step: row stride < n");
+        SSC_REQUIRE(ra.log.row_stride >= n && ra.log.done_row_stride >= n, "%s: row stride < n", fn);
     } else {
         ra.log = ssc_transition_log{};
     }
     if (ring) {
         ra.ring = *ring;
         SSC_REQUIRE(ring->env_id && ring->length && ring->ret && ring->cursor && ring->capacity >= 0,
-                    "ssc_mpc_rollout_step: bad episode ring");
+                    "%s: bad episode ring", fn);
     } else {
         ra.ring = ssc_episode_ring{};
     }
@@ -821,22 +893,78 @@ extern "C" int ssc_mpc_rollout_step(const ssc_env_params *p, const ssc_mpc_probl
     ra.seed = env_seed;
     ra.env_id0 = env_id0;
     ra.step0 = 0;
-    MpcStepArgs ma{};
+    ma = MpcStepArgs{};
     ma.nav.P = pr->n_problems; ma.nav.N = pr->n_samples; ma.nav.H = pr->horizon; ma.nav.d = pr->state_dim;
     ma.nav.wp = pr->wp; ma.nav.left = pr->left; ma.nav.radii = pr->radii; ma.nav.wp_off = pr->wp_off;
-    ma.nav.cur_idx = pr->cur_idx; ma.nav.theta = pr->theta;
+    ma.nav.cur_idx = pr->cur_idx; ma.nav.theta = pr->theta; ma.nav.plan_of = pr->plan_of; ma.nav.wp_len = pr->wp_len;
     ma.cur_idx = nav->cur_idx; ma.start_idx = nav->start_idx; ma.actions_done = nav->actions_done; ma.at_goal = nav->at_goal;
     ma.give_up = nav->give_up_after; ma.final_steps = nav->final_steps;
     ma.A = d_A; ma.best_idx = d_best_idx; ma.noise = noise_amount; ma.noise_seed = noise_seed; ma.problem_id0 = problem_id0;
     ma.d_t = d_t; ma.d_k = d_k; ma.ticket = d_ticket; ma.plan_state = d_plan_state;
+    return SSC_OK;
+}
+
+extern "C" int ssc_mpc_rollout_step(const ssc_env_params *p, const ssc_mpc_problems *pr, const ssc_mpc_nav_state *nav,
+                                    const float *d_A, const int32_t *d_best_idx, float noise_amount, uint64_t noise_seed,
+                                    uint64_t problem_id0, const ssc_rollout_state *state, const ssc_transition_log *log,
+                                    const ssc_episode_ring *ring, double *d_stats, uint64_t env_seed, uint64_t env_id0,
+                                    uint64_t *d_t, int32_t *d_k, int32_t *d_ticket, float *d_plan_state,
+                                    ssc_stream_t stream) {
+    RolloutArgs ra;
+    MpcStepArgs ma;
+    if (int rc = build_mpc_step_args("ssc_mpc_rollout_step", p, pr, nav, d_A, d_best_idx, noise_amount, noise_seed, problem_id0, state,
+                                     log, ring, d_stats, env_seed, env_id0, d_t, d_k, d_ticket, d_plan_state, ra, ma))
+        return rc;
+    const int64_t n = ra.n;
+    if (n == 0) return SSC_OK;
     hipStream_t s = as_stream(stream);
     if (p->kind == SSC_ENV_MOUNTAINCAR) {
         if (int rc = validate_mc_params(p, "ssc_mpc_rollout_step")) return rc;
-        hipLaunchKernelGGL(mpc_rollout_step_kernel<McEnv>, dim3(blocks_for(n)), dim3(kBlock), 0, s, make_mc_const(*p), ra, ma);
+        hipLaunchKernelGGL(mpc_rollout_step_kernel<McEnv>, dim3(blocks_for(n)), dim3(kBlock), 0, s, make_mc_const(*p), ra, ma, SsStepArgs{});
     } else if (p->kind == SSC_ENV_PENDULUM) {
-        hipLaunchKernelGGL(mpc_rollout_step_kernel<PendEnv>, dim3(blocks_for(n)), dim3(kBlock), 0, s, make_pend_const(*p), ra, ma);
+        hipLaunchKernelGGL(mpc_rollout_step_kernel<PendEnv>, dim3(blocks_for(n)), dim3(kBlock), 0, s, make_pend_const(*p), ra, ma, SsStepArgs{});
     } else {
         return set_error(SSC_EINVAL, "ssc_mpc_rollout_step: unknown env kind %d", p->kind);
     }
     return check_launch("ssc_mpc_rollout_step");
+}
+
+extern "C" int ssc_smartstart_rollout_step(const ssc_env_params *p, const ssc_mpc_problems *pr, const ssc_mpc_nav_state *nav,
+                                           const ssc_smartstart_step *ss, const float *d_A, const int32_t *d_best_idx,
+                                           float noise_amount, uint64_t noise_seed, uint64_t problem_id0,
+                                           const ssc_rollout_state *state, const ssc_transition_log *log,
+                                           const ssc_episode_ring *ring, double *d_stats, uint64_t env_seed, uint64_t env_id0,
+                                           uint64_t *d_t, int32_t *d_k, int32_t *d_ticket, float *d_plan_state,
+                                           ssc_stream_t stream) {
+    RolloutArgs ra;
+    MpcStepArgs ma;
+    if (int rc = build_mpc_step_args("ssc_smartstart_rollout_step", p, pr, nav, d_A, d_best_idx, noise_amount, noise_seed, problem_id0,
+                                     state, log, ring, d_stats, env_seed, env_id0, d_t, d_k, d_ticket, d_plan_state, ra, ma))
+        return rc;
+    SSC_REQUIRE(ss != nullptr, "ssc_smartstart_rollout_step: NULL step descriptor");
+    SSC_REQUIRE(ss->mode && ss->plan_of && ss->d_actor_out && ss->d_eta && ss->d_ou_epsilon && ss->d_pool,
+                "ssc_smartstart_rollout_step: NULL device pointer in the step descriptor");
+    SSC_REQUIRE(pr->plan_of != nullptr && pr->plan_of == ss->plan_of && pr->wp_len != nullptr,
+                "ssc_smartstart_rollout_step: the problem set must use the plan pool (plan_of == ss->plan_of, wp_len)");
+    SSC_REQUIRE(state->ou_x != nullptr, "ssc_smartstart_rollout_step: the base agent's OU noise needs state->ou_x");
+    SSC_REQUIRE(ss->act_low <= ss->act_high && ss->mode_log_stride >= 0, "ssc_smartstart_rollout_step: bad action bounds / stride");
+    const int64_t n = ra.n;
+    if (n == 0) return SSC_OK;
+    SsStepArgs sa{};
+    sa.mode = ss->mode; sa.plan_of = ss->plan_of; sa.actor_out = ss->d_actor_out; sa.d_eta = ss->d_eta; sa.d_eps = ss->d_ou_epsilon;
+    sa.d_pool = ss->d_pool;
+    sa.ou_mu = ss->ou.mu; sa.ou_sig_sqrt_dt = ss->ou.sigma * sqrtf(ss->ou.dt); sa.ou_theta_dt = ss->ou.theta * ss->ou.dt;
+    sa.act_low = ss->act_low; sa.act_high = ss->act_high;
+    sa.mode_log = ss->d_mode_log; sa.mode_log_stride = ss->mode_log_stride ? ss->mode_log_stride : n;
+    SSC_REQUIRE(sa.mode_log_stride >= n, "ssc_smartstart_rollout_step: mode log stride < n");
+    hipStream_t s = as_stream(stream);
+    if (p->kind == SSC_ENV_MOUNTAINCAR) {
+        if (int rc = validate_mc_params(p, "ssc_smartstart_rollout_step")) return rc;
+        hipLaunchKernelGGL((mpc_rollout_step_kernel<McEnv, true>), dim3(blocks_for(n)), dim3(kBlock), 0, s, make_mc_const(*p), ra, ma, sa);
+    } else if (p->kind == SSC_ENV_PENDULUM) {
+        hipLaunchKernelGGL((mpc_rollout_step_kernel<PendEnv, true>), dim3(blocks_for(n)), dim3(kBlock), 0, s, make_pend_const(*p), ra, ma, sa);
+    } else {
+        return set_error(SSC_EINVAL, "ssc_smartstart_rollout_step: unknown env kind %d", p->kind);
+    }
+    return check_launch("ssc_smartstart_rollout_step");
 }

@@ -41,7 +41,7 @@ SSC_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
 }
 
 // stream tags -- oracle/ssc_oracle.py TAG_*
-enum : uint32_t { TAG_ACTION = 0, TAG_RESET = 1, TAG_OU = 2, TAG_MPC = 3, TAG_MPC_NOISE = 4 };
+enum : uint32_t { TAG_ACTION = 0, TAG_RESET = 1, TAG_OU = 2, TAG_MPC = 3, TAG_MPC_NOISE = 4, TAG_SS_EPISODE = 8 };
 
 // key = (seed lo, seed hi); counter = (env lo, env hi, t lo, (t hi << 8) | tag)
 SSC_HD u32x4 rng_words(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t tag) {

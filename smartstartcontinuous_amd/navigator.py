@@ -349,6 +349,73 @@ class MpcProblemSet:
         return s
 
 
+class PlanPool:
+    """The problem set of the vectorised SmartStart loop: ``n_envs`` envs, each following ONE OF A FEW stored plans.
+    ``n_slots`` plan slots of up to ``w_max`` waypoints live in fixed device arrays (``wp``, ``left``, ``wp_len``,
+    ``radii``); ``plan_of[p]`` names the slot env p follows and ``cur_idx[p]`` its waypoint.  New plans (one smart-start
+    selection = ``n_plans`` of them) are written round-robin into the slots, so a plan stays intact for
+    ``n_slots / n_plans`` refreshes -- size the pool so that this covers an episode.  ``pool`` (int32[3] on the device:
+    first slot on offer, number on offer, slots) is what the step kernel draws a finished env's next plan from.
+    Duck-types :class:`MpcProblemSet` for :class:`NavigatorBatch` and the scorer."""
+
+    def __init__(self, n_envs, n_slots, w_max, d, device="cuda", theta=1.0, gamma=0.75, horizontal_penalty_factor=0.5,
+                 per_row_projection=False):
+        self.device = torch.device(device)
+        self.P, self.d, self.n_slots, self.w_max = int(n_envs), int(d), int(n_slots), int(w_max)
+        dev = self.device
+        self.wp = torch.zeros((self.n_slots * self.w_max, d), dtype=torch.float32, device=dev)
+        self.left = torch.zeros(self.n_slots * self.w_max, dtype=torch.float32, device=dev)
+        self.wp_off = (torch.arange(self.n_slots + 1, dtype=torch.int32) * self.w_max).to(dev)
+        # every slot starts as a harmless two-waypoint plan (the scorer runs for every env, navigating or not)
+        self.wp.view(self.n_slots, self.w_max, d)[:, 1, :] = 1.0
+        self.left.view(self.n_slots, self.w_max)[:, 0] = float(np.sqrt(d))
+        self.wp_len = torch.full((self.n_slots,), 2, dtype=torch.int32, device=dev)
+        self.radii = torch.ones((self.n_slots, d), dtype=torch.float32, device=dev)
+        self.plan_of = torch.zeros(self.P, dtype=torch.int32, device=dev)
+        self.cur_idx = torch.zeros(self.P, dtype=torch.int32, device=dev)
+        self.pool = torch.tensor([0, 0, self.n_slots], dtype=torch.int32, device=dev)
+        self.theta, self.gamma, self.hpf = float(theta), float(gamma), float(horizontal_penalty_factor)
+        self.per_row = bool(per_row_projection)
+        self._next = 0
+        self.published = 0
+
+    def publish(self, plans):
+        """``plans``: list of (waypoints [W, d], distances_left [W], radii [d]) -- the per-episode quantities of
+        NND_MB_agent.start_new_episode_plan (NND_MB_agent.py:375-423).  They go into the next slots and become the
+        plans on offer; the slots they replace were offered ``n_slots / len(plans)`` refreshes ago."""
+        if not plans:
+            return
+        if len(plans) > self.n_slots:
+            raise ValueError("more plans than slots")
+        first = self._next
+        wpv, lv = self.wp.view(self.n_slots, self.w_max, self.d), self.left.view(self.n_slots, self.w_max)
+        for j, (w, l, r) in enumerate(plans):
+            w = np.asarray(w, np.float32)
+            l = np.asarray(l, np.float32)
+            if len(w) < 2:                      # the reference indexes desired_states[b + 1]
+                w, l = np.concatenate([w, w], axis=0), np.zeros(2, np.float32)
+            if len(w) > self.w_max:
+                raise ValueError("plan of %d waypoints > w_max %d" % (len(w), self.w_max))
+            q = (first + j) % self.n_slots
+            wpv[q, :len(w)] = torch.as_tensor(w, device=self.device)
+            lv[q, :len(w)] = torch.as_tensor(l, device=self.device)
+            self.wp_len[q] = len(w)
+            self.radii[q] = torch.as_tensor(np.asarray(r, np.float32), device=self.device)
+        self.pool.copy_(torch.tensor([first, len(plans), self.n_slots], dtype=torch.int32))
+        self._next = (first + len(plans)) % self.n_slots
+        self.published += len(plans)
+
+    def as_struct(self, n_samples, horizon):
+        s = _ffi.MpcProblems()
+        s.n_problems, s.n_samples, s.horizon, s.state_dim = self.P, n_samples, horizon, self.d
+        s.wp, s.left, s.wp_off = self.wp.data_ptr(), self.left.data_ptr(), self.wp_off.data_ptr()
+        s.cur_idx, s.radii = self.cur_idx.data_ptr(), self.radii.data_ptr()
+        s.theta, s.gamma, s.horizontal_penalty_factor = self.theta, self.gamma, self.hpf
+        s.per_row_projection = int(self.per_row)
+        s.plan_of, s.wp_len = self.plan_of.data_ptr(), self.wp_len.data_ptr()
+        return s
+
+
 def mpc_sample_actions(P, N, H, low, high, seed, problem_id0=0, t=0, device="cuda", out=None, t_base=None):
     """``npr.uniform(low, high, (N, H, act))`` per problem (NND_MB_agent.py:500-501) -> [P*N, H, act].
     ``t_base``: a one-element int64 device tensor added to ``t`` on the device (HIP-graph replay)."""

@@ -331,3 +331,44 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
         summary.extend_records(lens, rets)
         decay(len(lens))
     return summary, losses, replay
+
+
+def rl_train_vec_smartstart(env, smart, num_chunks, chunk_steps=64, replay_capacity=1 << 20, train_iters=None,
+                            replay_last_steps=None, seed=0, ring_capacity=1 << 20, refresh_every=1, graph=True,
+                            on_chunk=None):
+    """The vectorised SmartStart loop: rlTrain (rlTrain.py:63-114) with ``SmartStartContinuous(DDPG_Baselines_agent)``
+    (smartexplorationcontinuous.py:307-376) for all envs of ``env`` at once, everything in HBM.  Per chunk:
+    smart-start selection on the device replay ring -> plans on offer (``smart.refresh_plans``, every ``refresh_every``
+    chunks), ``chunk_steps`` steps of every env in its own mode (``smart.rollout``), the chunk appended to the ring
+    (episode index kept on the device), ``train_iters`` DDPG iterations, and the finished episodes read back for the
+    epsilon / eta decay (once per episode per env, like DDPG_Baselines_agent.end_episode :255-258 and
+    SmartStartContinuous.end_episode :372-376).  ``smart``: :class:`smartstart.VecSmartStart`.
+    Returns (Summary, losses per chunk, replay)."""
+    import torch
+    from .replay_buffer import DeviceReplayBuffer
+    from .vec_env import EpisodeRing, TransitionChunk
+    agent = smart.agent
+    summary = Summary("vec_smartstart_" + env.spec.id)
+    ring = EpisodeRing(ring_capacity, env.device)
+    chunk = TransitionChunk(env.obs_dim, chunk_steps, env.n, env.device)
+    replay = DeviceReplayBuffer(replay_capacity, env.obs_dim, 1, env.device, seed=seed, track_episodes=True,
+                                n_envs=env.n, max_path_len=(env.spec.max_episode_steps or 1000) + 1)
+    losses, generations = [], 0.0
+    for c in range(num_chunks):
+        if c % refresh_every == 0:
+            smart.refresh_plans(replay)
+        out = smart.rollout(chunk_steps, chunk, ring=ring, graph=graph)
+        replay.append_chunk(out, reward_scale=agent.reward_scale, last_steps=replay_last_steps)
+        l = agent.train_from(replay, train_iters)
+        if l is not None:
+            losses.append(l)
+        if on_chunk is not None:
+            on_chunk(c, out, smart)
+        (ids, lens, rets), _d = ring.drain()
+        summary.extend_records(lens, rets)
+        generations += len(lens) / float(env.n)
+        while generations >= 1.0:
+            agent.decaying_ou_action_noise.reduce_epsilon()
+            smart.end_of_generation()
+            generations -= 1.0
+    return summary, losses, replay

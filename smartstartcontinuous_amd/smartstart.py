@@ -198,3 +198,206 @@ class SmartStartContinuous(RLAgent):
 
     def render(self, env, **kwargs):
         return env.render()
+
+
+class VecSmartStart:
+    """``SmartStartContinuous`` for the N envs of a :class:`VecEnv` at once (smartexplorationcontinuous.py:307-376,
+    vectorised): every env is either navigating to a smart-start state (per-env mode 1: the NND_MB MPC picks its
+    action) or handed over to the base DDPG agent (mode 0: actor + OU noise); an env that finishes an episode starts
+    the next one -- inside the step kernel, without the host -- with a smart start with probability ``eta``.
+
+    What one env does is what the scalar agent does: ``get_action`` by mode (:307-317), waypoint bookkeeping and the
+    hand-over test after every navigated step (:319-339), ``start_new_episode`` on the reset state (:341-370).  What is
+    batched is the smart-start SELECTION (:223-305): instead of one selection per finished episode, ``refresh_plans``
+    runs it once per rollout chunk on the device replay ring (candidates, Q(s, pi(s)), Gaussian KDE, UCB1), turns the
+    ``n_plans`` best candidates' episodic paths into plans (radii, optional shortcutting, waypoints, distances_left --
+    NND_MB_agent.start_new_episode_plan's host geometry) and publishes them in a :class:`navigator.PlanPool`; the envs
+    finishing during the chunk draw from those.  ``n_plans = 1`` is the reference's argmax for every episode that starts
+    before the next refresh.  One step = five launches (actor forward, forward simulation drawing its own candidates,
+    scoring x 2, ``ssc_smartstart_rollout_step``), captured once as a HIP graph and replayed K times per chunk.
+    """
+
+    def __init__(self, env, agent, dyn_model, eta=0.5, eta_decay_factor=1.0, n_ss=1000, exploitation_param=1.,
+                 exploration_param=2., n_plans=1, n_slots=None, w_max=None, num_control_samples=64, horizon=4,
+                 noise_amount=0.005, steps_before_giving_up_on_waypoint=5, final_steps=10, theta=1.0, gamma=0.75,
+                 horizontal_penalty_factor=0.5, path_shortcutting=True, mean_per_stepsize=1, std_per_stepsize=1,
+                 stepsizes_in_waypoint_radii=1, steps_per_waypoint=1, chunk_steps=64, seed=1234, log_modes=False):
+        from . import navigator as nav
+        self.env, self.agent, self.model = env, agent, dyn_model
+        self.eta, self.eta_decay_factor = float(eta), float(eta_decay_factor)
+        self.n_ss, self.n_plans = int(n_ss), int(n_plans)
+        self.exploitation_param, self.exploration_param = exploitation_param, exploration_param
+        self.path_shortcutting, self.steps_per_waypoint = path_shortcutting, steps_per_waypoint
+        self.mean_per_stepsize, self.std_per_stepsize = mean_per_stepsize, std_per_stepsize
+        self.stepsizes_in_waypoint_radii = stepsizes_in_waypoint_radii
+        dev = env.device
+        max_steps = env.spec.max_episode_steps or 1000
+        w_max = int(w_max) if w_max is not None else max_steps + 1
+        if n_slots is None:        # a published plan must outlive every episode that started on it
+            n_slots = self.n_plans * (-(-max_steps // max(int(chunk_steps), 1)) + 2)
+        self.pool = nav.PlanPool(env.n, n_slots, w_max, env.obs_dim, dev, theta=theta, gamma=gamma,
+                                 horizontal_penalty_factor=horizontal_penalty_factor)
+        self.nav = nav.NavigatorBatch(dyn_model, self.pool, num_control_samples=num_control_samples, horizon=horizon,
+                                      action_low=env.action_space.low, action_high=env.action_space.high,
+                                      noise_amount=noise_amount,
+                                      steps_before_giving_up_on_waypoint=steps_before_giving_up_on_waypoint,
+                                      final_steps=final_steps, seed=seed, problem_id0=env.env_id0)
+        self.nav.start_idx.zero_()
+        self.mode = torch.zeros(env.n, dtype=torch.uint8, device=dev)
+        self.actor_out = torch.zeros((env.n, 1), dtype=torch.float32, device=dev)
+        self.d_eta = torch.tensor([self.eta], dtype=torch.float32, device=dev)
+        self.d_eps = torch.tensor([0.0], dtype=torch.float32, device=dev)
+        self.log_modes = bool(log_modes)
+        self.mode_log = None
+        self.last_radii = None
+        self._graphs = {}
+        self.selections = 0
+
+    # ------------------------------------------------------------------------- selection --
+    def plan_from_path(self, path):
+        """NND_MB_agent.start_new_episode_plan's geometry (NND_MB_agent.py:385-418) -> (waypoints, distances_left, radii)."""
+        from .numerical import (distances_left, elliptical_euclidean_distance_function_generator,
+                                get_start_waypoints_final_states_steps, path_deltas_stds_and_means_per_dim,
+                                path_shortcutter, radii_calc)
+        path = np.asarray(path, np.float64)
+        stds, means = path_deltas_stds_and_means_per_dim(path)
+        radii = radii_calc(means, stds, self.mean_per_stepsize, self.std_per_stepsize, self.stepsizes_in_waypoint_radii)
+        dist = elliptical_euclidean_distance_function_generator(radii)
+        if self.path_shortcutting:
+            path = path_shortcutter(path, dist, self.pool.theta)
+        wp = np.asarray(get_start_waypoints_final_states_steps(path, self.steps_per_waypoint))
+        return wp, distances_left(wp, dist), radii
+
+    def refresh_plans(self, replay):
+        """One smart-start selection on the device ring (get_smart_start_path, :223-305) -> ``n_plans`` plans on offer.
+        Returns the chosen buffer indices (device tensor) or None when the ring holds no complete episode start yet."""
+        if len(replay) == 0:
+            return None
+        idx = replay.get_possible_smart_start_indices(self.n_ss)                                  # :243-246
+        if idx is None:
+            return None
+        all_states = replay.get_all_states()                                                      # :258
+        wh, norm = kde_scott_bandwidth(all_states)                                                # :260
+        volume = volume_of_n_dimensional_hyperellipsoid(self.last_radii) if self.last_radii is not None else 1   # :262-268
+        cand = replay.s2[replay.physical(idx)]                                                    # :272-273
+        values = self.agent.state_value_device(cand)                                              # :274
+        pdf = kde_evaluate(all_states, cand, wh, norm)                                            # :275
+        ucb, best = ucb_argmax(values, pdf, len(replay), volume, self.exploitation_param, self.exploration_param)
+        if self.n_plans == 1:
+            chosen = idx[best.long()]
+        else:
+            chosen = idx[torch.topk(ucb, min(self.n_plans, ucb.numel())).indices]
+        plans = []
+        for c in chosen.reshape(-1):
+            path = replay.get_episodic_path_to_buffer_index(c.reshape(1))
+            if path is None or path.shape[0] < 2:
+                continue
+            plans.append(self.plan_from_path(path.double().cpu().numpy()))
+        if plans:
+            self.pool.publish(plans)
+            self.last_radii = plans[0][2]
+            self.selections += 1
+        return chosen
+
+    # ------------------------------------------------------------------------------ steps --
+    def _step_struct(self, chunk_k):
+        e, a = self.env, self.agent
+        ss = _ffi.SmartStartStep()
+        ss.mode, ss.plan_of = self.mode.data_ptr(), self.pool.plan_of.data_ptr()
+        ss.d_actor_out, ss.d_eta, ss.d_ou_epsilon = self.actor_out.data_ptr(), self.d_eta.data_ptr(), self.d_eps.data_ptr()
+        ss.d_pool = self.pool.pool.data_ptr()
+        n = a.decaying_ou_action_noise
+        ss.ou.mu, ss.ou.sigma, ss.ou.theta, ss.ou.dt = float(a.ou["mu"]), float(a.ou["sigma"]), float(a.ou["theta"]), float(n.dt)
+        ss.act_low, ss.act_high = float(e.action_space.low[0]), float(e.action_space.high[0])
+        if self.log_modes:
+            if self.mode_log is None or self.mode_log.shape != (chunk_k, e.n):
+                self.mode_log = torch.zeros((chunk_k, e.n), dtype=torch.uint8, device=e.device)
+            ss.d_mode_log, ss.mode_log_stride = self.mode_log.data_ptr(), e.n
+        return ss
+
+    def fused_step(self, chunk, ring):
+        """Enqueue ONE step for every env (five launches); step index and log row are device counters."""
+        from . import navigator as nav
+        env, b, lib = self.env, self.nav, _ffi.lib()
+        fb = b._fused_buffers(env.device)
+        with torch.cuda.device(env.device):
+            _ffi.check(lib.ssc_actor_forward(ctypes.byref(self.agent._desc), env.n, _ffi.ptr(fb["plan"]),
+                                             _ffi.ptr(self.actor_out), _stream()))
+        sp = nav.mpc_sampling(b.N, b.low, b.high, b.seed, b.problem_id0, 0, t_base=fb["t"])
+        S = self.model.do_forward_sim_sampled(fb["plan"], sp, b.P * b.N, b.H, out=b._S, A_out=fb["A"])
+        st = self.pool.as_struct(b.N, b.H)
+        navs = _ffi.MpcNavState(self.pool.cur_idx.data_ptr(), b.start_idx.data_ptr(), b.actions_done.data_ptr(),
+                                b.at_goal.data_ptr(), b.give_up, b.final_steps)
+        rs = _ffi.RolloutState(env.s0.data_ptr(), env.s1.data_ptr(), env.steps.data_ptr(), env.ep_ret.data_ptr(),
+                               env.ou_x.data_ptr())
+        log_s = chunk.as_struct() if chunk is not None else None
+        ring_s = ring.as_struct() if ring is not None else None
+        ss = self._step_struct(chunk.K if chunk is not None else 1)
+        with torch.cuda.device(env.device):
+            _ffi.check(lib.ssc_mpc_score(ctypes.byref(st), _ffi.ptr(S), _ffi.ptr(fb["scores"]), _ffi.ptr(fb["best"]),
+                                         _ffi.ptr(fb["best_score"]), _ffi.ptr(fb["ws"]), fb["ws"].numel(), _stream()))
+            _ffi.check(lib.ssc_smartstart_rollout_step(
+                ctypes.byref(env.params), ctypes.byref(st), ctypes.byref(navs), ctypes.byref(ss), _ffi.ptr(fb["A"]),
+                _ffi.ptr(fb["best"]), float(b.noise_amount), b.seed, b.problem_id0, ctypes.byref(rs),
+                ctypes.byref(log_s) if log_s is not None else None,
+                ctypes.byref(ring_s) if ring_s is not None else None,
+                _ffi.ptr(env.stats), env._seed, env.env_id0, _ffi.ptr(fb["t"]), _ffi.ptr(fb["k"]), _ffi.ptr(fb["ticket"]),
+                _ffi.ptr(fb["plan"]), _stream()))
+
+    def _state_tensors(self):
+        e, b = self.env, self.nav
+        fb = b._fused_buffers(e.device)
+        return [e.s0, e.s1, e.steps, e.ep_ret, e.ou_x, e.stats, self.pool.cur_idx, self.pool.plan_of, b.actions_done,
+                b.at_goal, self.mode, fb["plan"], fb["t"], fb["k"]]
+
+    def rollout(self, K, out, ring=None, graph=True):
+        """K steps of every env into the TransitionChunk ``out`` (one graph replay per step when ``graph``)."""
+        env, b = self.env, self.nav
+        if env._needs_reset:
+            env.reset()
+        if (out.K, out.N, out.obs_dim) != (K, env.n, env.obs_dim):
+            raise ValueError("out chunk has the wrong shape")
+        out.step0, out.env_id0 = env.t, env.env_id0
+        fb = b._fused_buffers(env.device)
+        fb["t"].fill_(env.t)
+        fb["k"].zero_()
+        fb["plan"].copy_(env.observe())
+        self.d_eps.fill_(float(max(self.agent.decaying_ou_action_noise.epsilon, 0.0)))
+        self.d_eta.fill_(self.eta)
+        self.model.refresh_prepared_image()
+        if not graph:
+            for _ in range(K):
+                self.fused_step(out, ring)
+            env.t += K
+            return out
+        key = (K, out.obs.data_ptr(), None if ring is None else ring.cursor.data_ptr(), self.agent.actor_flat.data_ptr(),
+               tuple(w.data_ptr() for w in self.model.W), None if self.model._image is None else self.model._image.data_ptr(),
+               self.log_modes)
+        if key not in self._graphs:
+            snap = [x.clone() for x in self._state_tensors()]
+            ring_snap = None if ring is None else ring.cursor.clone()
+            side = torch.cuda.Stream(env.device)
+            side.wait_stream(torch.cuda.current_stream(env.device))
+            with torch.cuda.stream(side):
+                self.fused_step(out, ring)           # lazy allocations, weight image, LDS opt-ins outside the capture
+            torch.cuda.current_stream(env.device).wait_stream(side)
+            for dst, src in zip(self._state_tensors(), snap):
+                dst.copy_(src)
+            if ring is not None:
+                ring.cursor.copy_(ring_snap)
+            key = key[:5] + (None if self.model._image is None else self.model._image.data_ptr(),) + key[6:]
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.fused_step(out, ring)
+            for k_old in list(self._graphs)[:max(0, len(self._graphs) - 3)]:
+                del self._graphs[k_old]
+            self._graphs[key] = g
+        g = self._graphs[key]
+        for _ in range(K):
+            g.replay()
+        env.t += K
+        return out
+
+    def end_of_generation(self):
+        """SmartStartContinuous.end_episode (:372-376) once per episode PER ENV: eta decays."""
+        self.eta *= self.eta_decay_factor

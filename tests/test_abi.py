@@ -34,7 +34,7 @@ def test_header_symbols_exported_and_bound(built):
 def test_version_and_defaults(built):
     from smartstartcontinuous_amd import _ffi
     lib = _ffi.lib()
-    assert lib.ssc_version() == 100
+    assert lib.ssc_version() == 101
     p = _ffi.default_params(_ffi.SSC_ENV_MOUNTAINCAR, 0.4, 1000)
     assert abs(p.power - 0.0006) < 1e-9 and p.max_episode_steps == 1000
     assert abs(p.goal_position - 0.45) < 1e-7 and abs(p.min_position + 1.2) < 1e-7
@@ -98,17 +98,17 @@ def test_struct_layouts_match_header(built, tmp_path):
     import subprocess
     from smartstartcontinuous_amd import _ffi
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "ssc.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "ssc.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(ssc_env_params),sizeof(ssc_actor_desc),sizeof(ssc_ou_desc),sizeof(ssc_policy_desc),'
                    'sizeof(ssc_rollout_state),sizeof(ssc_transition_log),sizeof(ssc_episode_ring),'
-                   'sizeof(ssc_mlp_desc),sizeof(ssc_norm),sizeof(ssc_mpc_problems),sizeof(ssc_critic_desc),sizeof(ssc_ddpg_desc),sizeof(ssc_replay_view),sizeof(ssc_mlp_train_desc),sizeof(ssc_replay_ring));return 0;}\n')
+                   'sizeof(ssc_mlp_desc),sizeof(ssc_norm),sizeof(ssc_mpc_problems),sizeof(ssc_critic_desc),sizeof(ssc_ddpg_desc),sizeof(ssc_replay_view),sizeof(ssc_mlp_train_desc),sizeof(ssc_replay_ring),sizeof(ssc_smartstart_step));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     expect = [ctypes.sizeof(c) for c in (_ffi.EnvParams, _ffi.ActorDesc, _ffi.OuDesc, _ffi.PolicyDesc,
                                          _ffi.RolloutState, _ffi.TransitionLog, _ffi.EpisodeRing, _ffi.MlpDesc,
                                          _ffi.Norm, _ffi.MpcProblems, _ffi.CriticDesc,
-                                         _ffi.DdpgDesc, _ffi.ReplayView, _ffi.MlpTrainDesc, _ffi.ReplayRing)]
+                                         _ffi.DdpgDesc, _ffi.ReplayView, _ffi.MlpTrainDesc, _ffi.ReplayRing, _ffi.SmartStartStep)]
     assert sizes == expect
 
 

@@ -1,0 +1,201 @@
+"""GPU tests of the vectorised SmartStart loop (smartexplorationcontinuous.py:307-376 for N envs at once):
+``ssc_smartstart_rollout_step`` / ``VecSmartStart`` / ``rl_train_vec_smartstart``.  Every logged step is re-derived by the
+oracle from the state the env was in -- who acted (navigator or base agent), the action, the env transition, the waypoint
+bookkeeping, the hand-over, and what a finished episode starts next."""
+import numpy as np
+import pytest
+
+from oracle import ssc_oracle as O
+from tests.gpu_util import actor_weights
+from tests.test_gpu_navigator import make_mlp, make_norm
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ssc():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no fallback")
+    import smartstartcontinuous_amd as pkg
+    pkg._ffi.lib()
+    return pkg
+
+
+def _setup(ssc, n, max_steps, eta, seed, N=96, H=3, give_up=2, log_modes=True, n_plans=3, chunk=16, env_id0=40):
+    from smartstartcontinuous_amd import navigator as nav
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    rng = np.random.default_rng(seed)
+    env = ssc.VecEnv("MountainCarContinuous-v0", n, seed=seed, max_episode_steps=max_steps, env_id0=env_id0)
+    env.reset()
+    agent = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32,
+                                 lastLayerTanh=True, seed=5, training=False, ou_mu=0.4, ou_sigma=0.6, precision="f32")
+    w = actor_weights(2, 64, 32, seed=77, w3_scale=0.5)
+    agent.set_weights({k: torch.as_tensor(v) for k, v in w.items()})
+    Ws, bs = make_mlp(rng, (3, 32, 2))
+    norm = make_norm(rng, 2, 1)
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=2, act_dim=1, precision="f32")
+    smart = ssc.VecSmartStart(env, agent, model, eta=eta, n_plans=n_plans, num_control_samples=N, horizon=H,
+                              steps_before_giving_up_on_waypoint=give_up, final_steps=4, chunk_steps=chunk, seed=seed + 1,
+                              log_modes=log_modes, w_max=max(max_steps + 1, 16))
+    return env, agent, w, (Ws, bs, norm), smart
+
+
+def _plans(rng, n, near_reset):
+    """Hand-made plans: random walks that start in the reset region; ``near_reset`` ones also END there, so that
+    close_enough_to_goal(reset state) is true for some envs and they never navigate."""
+    out = []
+    for j in range(n):
+        L = int(rng.integers(6, 14))
+        path = np.stack([np.cumsum(rng.normal(scale=0.02, size=L)) - 0.5, np.cumsum(rng.normal(scale=0.004, size=L))], 1)
+        if j < near_reset:
+            path[-1] = [-0.5, 0.0]
+        stds, means = O.path_deltas_stds_and_means_per_dim(path)
+        r = O.radii_calc(means, stds, 1, 1, 1) + 1e-3
+        if j < near_reset:
+            r = r + np.array([0.2, 0.05])      # a goal region as wide as the reset interval
+        out.append((path, O.distances_left(path, O.distance_func(r)), r))
+    return out
+
+
+def test_vec_smartstart_every_step_against_the_scalar_logic(ssc):
+    n, K, max_steps, eta, seed = 40, 48, 17, 0.7, 9
+    env, agent, w, (Ws, bs, norm), smart = _setup(ssc, n, max_steps, eta, seed, chunk=K)
+    rng = np.random.default_rng(3)
+    plans = _plans(rng, 3, near_reset=1)
+    smart.pool.publish(plans)
+    first, count, slots = smart.pool.pool.cpu().tolist()
+    assert (first, count) == (0, 3)
+    agent.decaying_ou_action_noise.epsilon = 0.8
+    chunk = ssc.TransitionChunk(2, K, n, env.device)
+    obs_start = env.observe().cpu().numpy().copy()
+    t0 = 5
+    env.t = t0
+    smart.rollout(K, chunk, graph=False)
+    torch.cuda.synchronize()
+    obs, act, rew = chunk.obs.cpu().numpy(), chunk.act.cpu().numpy(), chunk.rew.cpu().numpy()
+    done, obs2 = chunk.done.cpu().numpy().astype(bool), chunk.obs2.cpu().numpy()
+    modes = smart.mode_log.cpu().numpy()
+    final_obs = env.observe().cpu().numpy()
+    nm32 = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in norm.items()}
+    N, H, nav_seed = smart.nav.N, smart.nav.H, smart.nav.seed
+    mode = np.zeros(n, bool); plan = np.zeros(n, int); idx = np.zeros(n, int); dact = np.zeros(n, int); ou = np.zeros(n)
+    ids = np.uint64(env.env_id0) + np.arange(n, dtype=np.uint64)
+    n_nav = n_agent = n_handover = n_new_nav = n_close = 0
+    assert np.array_equal(obs[:, 0, :].T, obs_start)
+    for k in range(K):
+        t = t0 + k
+        g = O.ou_gaussian(env._seed, ids, np.uint64(t))
+        a_net = O.actor_forward(obs[:, k, :].T, **w, obs_clip=5.0)[:, 0]
+        for i in range(n):
+            s = obs[:, k, i]
+            assert modes[k, i] == mode[i], (k, i)
+            if mode[i]:
+                n_nav += 1
+                wp, left, r = plans[plan[i]]
+                A = O.mpc_action_samples(nav_seed, int(ids[i]), N, H, 1, t, [-1.0], [1.0])
+                S = O.dyn_forward_sim(s, A, nm32, Ws, bs)
+                scores, best_score, _, _ = O.mpc_scores_add_delta(S, np.asarray(wp, np.float32), np.asarray(left, np.float32),
+                                                              np.asarray(r, np.float32), idx[i])
+                noise = 0.005 * O.mpc_noise_gaussian(nav_seed, np.array([ids[i]], np.uint64), t, 0)[0]
+                cand = np.argmin(np.abs(A[:, 0, 0] + noise - act[k, i]))
+                assert abs(A[cand, 0, 0] + noise - act[k, i]) <= 1e-6, (k, i)
+                assert scores[cand] >= best_score - 1e-3 * max(1.0, abs(best_score)), (k, i)
+            else:
+                n_agent += 1
+                ou[i] = O.ou_step(ou[i], g[i], 0.4, 0.6)
+                expect = O.ddpg_action(a_net[i], ou[i], 0.8)
+                assert abs(expect - act[k, i]) <= 2e-5, (k, i, expect, act[k, i])
+            p2, v2, r_, d_ = O.mc_step(s[0], s[1], act[k, i])
+            assert abs(p2 - obs2[0, k, i]) <= 2.4e-7 and abs(v2 - obs2[1, k, i]) <= 1e-8
+            assert abs(r_ - rew[k, i]) <= 1e-6 * max(1.0, abs(r_))
+            if mode[i]:
+                dact[i] += 1
+                wp, left, r = plans[plan[i]]
+                idx[i], dact[i], at_goal = O.nav_observe(obs2[:, k, i], wp, r, idx[i], dact[i], give_up=2, final_steps=4)
+                if at_goal:
+                    mode[i] = False
+                    n_handover += 1
+            if done[k, i]:
+                ou[i], idx[i], dact[i], mode[i] = 0.0, 0, 0, False
+                q = O.smartstart_new_episode(env._seed, int(ids[i]), t, eta, first, count, slots)
+                if q >= 0:
+                    plan[i] = q
+                    reset_obs = obs[:, k + 1, i] if k + 1 < K else final_obs[i]
+                    wp, left, r = plans[q]
+                    close = O.distance_func(r)(reset_obs, wp[-1]) <= 1.0
+                    mode[i] = not close
+                    n_new_nav += int(not close)
+                    n_close += int(close)
+    # the loop exercised every branch
+    assert n_nav > 50 and n_agent > 50 and n_handover > 0 and n_new_nav > 5 and n_close > 0, (n_nav, n_agent, n_handover, n_new_nav, n_close)
+    assert np.array_equal(smart.mode.cpu().numpy().astype(bool), mode)
+    assert np.array_equal(smart.pool.cur_idx.cpu().numpy(), idx) and np.array_equal(smart.nav.actions_done.cpu().numpy(), dact)
+    nav_now = mode
+    assert np.array_equal(smart.pool.plan_of.cpu().numpy()[nav_now], plan[nav_now])
+    assert np.max(np.abs(env.ou_x.cpu().numpy() - ou)) < 2e-5
+    assert env.stats.cpu().numpy()[2] == n * K and env.t == t0 + K
+
+
+def test_vec_smartstart_graph_replay_equals_step_by_step(ssc):
+    """The captured five-launch step replayed K times == the same launches enqueued one by one, over two chunks with a
+    pool refresh in between (log, modes, env / navigator / OU state, statistics, episode records)."""
+    res = []
+    for graph in (True, False):
+        n, K = 300, 12
+        env, agent, w, _, smart = _setup(ssc, n, 9, 0.6, 4, N=32, H=2, chunk=K)
+        rng = np.random.default_rng(1)
+        smart.pool.publish(_plans(rng, 3, near_reset=1))
+        ring = ssc.EpisodeRing(8192, "cuda")
+        chunk = ssc.TransitionChunk(2, K, n, env.device)
+        logs = []
+        for c in range(2):
+            smart.rollout(K, chunk, ring=ring, graph=graph)
+            torch.cuda.synchronize()
+            logs.append([getattr(chunk, col).clone() for col in ("obs", "act", "rew", "done", "obs2")] + [smart.mode_log.clone()])
+            smart.pool.publish(_plans(rng, 3, near_reset=0))
+        res.append((env, smart, logs, ring))
+    (eg, sg, lg, rg), (ee, se, le, re_) = res
+    for c in range(2):
+        for a, b in zip(lg[c], le[c]):
+            assert torch.equal(a, b), c
+    assert int(lg[0][5].sum()) > 0 and int(lg[1][5].sum()) > 0                     # somebody navigated
+    for a, b in ((eg.s0, ee.s0), (eg.s1, ee.s1), (eg.steps, ee.steps), (eg.ou_x, ee.ou_x), (sg.mode, se.mode),
+                 (sg.pool.plan_of, se.pool.plan_of), (sg.pool.cur_idx, se.pool.cur_idx), (sg.nav.actions_done, se.nav.actions_done)):
+        assert torch.equal(a, b)
+    a, b = eg.stats.cpu().numpy(), ee.stats.cpu().numpy()
+    assert a[2] == b[2] == 2 * 12 * 300 and a[3] == b[3] and abs(a[0] - b[0]) <= 1e-6 * max(1.0, abs(b[0]))
+    (ig, lg_, _), dg = rg.drain()
+    (ie, le_, _), de = re_.drain()
+    assert dg == de == 0 and sorted(zip(ig.tolist(), lg_.tolist())) == sorted(zip(ie.tolist(), le_.tolist()))
+
+
+def test_rl_train_vec_smartstart_end_to_end(ssc):
+    """rl_train_vec_smartstart: selection on the device ring -> plans on offer -> envs navigate and hand over -> replay ->
+    learner, for a few chunks.  Checks the plumbing end to end (selections happen, plans come from recorded episodes,
+    some envs navigate and some of them hand over, the learner runs, eta / epsilon decay once per generation)."""
+    n, K, chunks = 256, 16, 14
+    env, agent, w, _, smart = _setup(ssc, n, 24, 0.9, 2, N=32, H=3, chunk=K, n_plans=2)
+    agent.training_enabled = True
+    agent.batch_size, agent.num_train_iterations = 64, 3
+    smart.eta_decay_factor = 0.9
+    nav_steps, seen = [], []
+
+    def on_chunk(c, out, sm):
+        nav_steps.append(int(sm.mode_log.sum()))
+        seen.append(sm.pool.published)
+    summary, losses, replay = ssc.rl_train_vec_smartstart(env, smart, chunks, chunk_steps=K, replay_capacity=1 << 15,
+                                                          train_iters=3, on_chunk=on_chunk)
+    torch.cuda.synchronize()
+    assert len(summary.episodes) >= n                               # 24-step time limit: every env finished episodes
+    assert smart.selections >= 5 and seen[-1] >= 10                 # a selection per chunk once the ring holds episodes
+    assert sum(nav_steps) > 200, nav_steps                          # envs really navigated ...
+    assert nav_steps[0] == 0                                        # ... but not before the first plans existed
+    assert len(losses) >= chunks - 2 and all(bool(torch.isfinite(l).all()) for l in losses)
+    assert smart.eta < 0.9 and agent.decaying_ou_action_noise.epsilon < 1.0
+    # the plans on offer are recorded episodes: waypoints inside the env's state box
+    wp = smart.pool.wp.view(smart.pool.n_slots, smart.pool.w_max, 2)
+    first, count, slots = smart.pool.pool.cpu().tolist()
+    L = int(smart.pool.wp_len[first])
+    pts = wp[first, :L].cpu().numpy()
+    assert count >= 1 and L >= 2 and pts[:, 0].min() >= -1.2001 and pts[:, 0].max() <= 0.6001 and np.abs(pts[:, 1]).max() <= 0.0701
