@@ -272,3 +272,20 @@ def test_replay_buffer_save_load_roundtrip(tmp_path):
             assert np.array_equal(np.asarray(x), np.asarray(y))
     small = ReplayBuffer(agent, 8)          # a smaller buffer keeps the newest records
     assert small.load(path) and len(small) == 8 and small.buffer[-1][0][0] == 26 and small.buffer[0][0][0] == 19
+
+
+def test_vectorised_activity_solver_equals_the_reference_loop():
+    """length_weighted_activities_solver fills the reference's table one end time at a time (one vectorised max per row);
+    on random interval sets -- unsorted and in np.where order, with and without sub_extra -- it returns exactly what the
+    interval-by-interval loop of numerical.py:189-222 returns (weight AND chosen intervals, i.e. the same tie-breaking)."""
+    from smartstartcontinuous_amd import numerical as N
+    rng = np.random.default_rng(0)
+    for trial in range(120):
+        L, n = int(rng.integers(10, 120)), int(rng.integers(65, 700))
+        s = rng.integers(0, L - 2, n)
+        e = s + rng.integers(1, L - s)
+        acts = np.stack([s, e], 1)
+        if trial % 3 == 0:
+            acts = acts[np.lexsort((acts[:, 1], acts[:, 0]))]
+        for sub_extra in (0, 1):
+            assert N.length_weighted_activities_solver(acts, sub_extra) == N._length_weighted_activities_loop(acts.tolist(), sub_extra)
