@@ -518,6 +518,7 @@ def main():
     ap.add_argument("--no-single-step", action="store_true", help="skip the single-step-API (ssc_mc_step) line")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="config 2, one GPU: skip the BASELINE configs[2] / configs[3] lines attached as `other_configs`")
+    ap.add_argument("--no-per-env", action="store_true", help="--config 4: skip the one-navigator-per-env leg")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
                     help="BASELINE.json config (1-based): 2 = headline random-policy rollout (default), "
                          "3 = + DDPG actor MFMA, 4 = NND_MB 2x500 forward sim + MPC")
@@ -557,6 +558,8 @@ def main():
             sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
         if args.config == 4:
             bench_config4(args, torch)
+            if args.no_per_env:          # profiling runs: keep the kernel statistics to the 65 536-row workload
+                return 0
             return bench_config4_envs(args, torch) and 0
         return bench_config3(args, torch) and 0
 

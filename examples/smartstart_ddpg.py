@@ -81,6 +81,8 @@ def vec(args, dyn_model):
                                 ou_epsilon=1.0, ou_min_epsilon=0.01, ou_epsilon_decay_factor=.99, ou_mu=0.4, ou_sigma=0.6,
                                 ou_theta=.15, actor_lr=0.001, actor_h1=64, actor_h2=32, critic_lr=0.001, critic_h1=64,
                                 critic_h2=32, lastLayerTanh=True, seed=args.seed, precision="bf16_mfma")
+    dyn_model.precision = "bf16_mfma"     # the fused forward-simulation kernel (the scalar example runs the fp32 parity path)
+    dyn_model.invalidate()
     smart = ssc.VecSmartStart(env, ddpg, dyn_model, eta=0.5, eta_decay_factor=1., n_ss=2000, n_plans=args.plans,
                               num_control_samples=args.samples, horizon=4, final_steps=10, chunk_steps=args.chunk_steps,
                               seed=args.seed, log_modes=True)

@@ -10,6 +10,19 @@ for cfg in ("c2", "c3", "c4", "train", "dataset"):
     os.makedirs(d, exist_ok=True)
     for f in glob.glob(os.path.join(s, "kt", "*", "*_kernel_stats.csv")):
         shutil.copy(f, os.path.join(d, "kernel_stats.csv"))
+    # settled launches of the dominant kernel from the full trace (kernel_stats.csv averages every launch of the run,
+    # the post-idle transient and the settling phase included)
+    for f in glob.glob(os.path.join(s, "kt", "*", "*_kernel_trace.csv")):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+        by = collections.defaultdict(list)
+        for r in rows:
+            by[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        name, dd = max(by.items(), key=lambda kv: sum(kv[1]))
+        tail = sorted(dd[len(dd) * 3 // 4:])
+        json.dump({"kernel": name, "launches": len(dd), "mean_us_all": sum(dd) / len(dd),
+                   "last_quarter": {"n": len(tail), "mean_us": sum(tail) / len(tail), "median_us": tail[len(tail) // 2],
+                                    "min_us": tail[0], "p90_us": tail[int(0.9 * len(tail))]}},
+                  open(os.path.join(d, "kernel_trace_settled.json"), "w"), indent=1)
     pmc = {}
     for f in glob.glob(os.path.join(s, "pmc_*", "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(list)
@@ -34,8 +47,13 @@ for cfg in ("c2", "c3", "c4", "train", "dataset"):
             w = k[0].get("WRITE_SIZE", {}).get("mean", 0) * 1024
             r = k[0].get("FETCH_SIZE", {}).get("mean", 0) * 1024 * 2
             alg = b["roofline"]["algorithmic_bytes_per_launch"]
+            # stamped with the sha of the kernel sources the box ran (= this tree: summarise right after the gpurun call
+            # that measured), so that bench.py can tell a stale figure from a current one
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench
             json.dump({"write_bytes": w, "fetch_bytes_corrected": r, "algorithmic_bytes": alg,
-                       "traffic_over_algorithmic": (w + r) / alg}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+                       "traffic_over_algorithmic": (w + r) / alg, "source_sha": bench.source_sha()},
+                      open(os.path.join(dst, "traffic.json"), "w"), indent=1)
             print("c2 traffic/algorithmic = %.4f" % ((w + r) / alg))
     st = os.path.join(d, "kernel_stats.csv")
     if os.path.exists(st):
