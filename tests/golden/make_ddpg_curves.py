@@ -29,3 +29,26 @@ for f in files:
 np.savez_compressed(os.path.join(OUT, "ddpg_good_params_curves.npz"), steps=np.stack(steps), returns=np.stack(returns),
                     param_dict=json.dumps(params, sort_keys=True))
 print(len(files), "runs;", params)
+
+# ---- the hidden-layer-size experiment (data/ddpg_baselines_summaries/hidden_layer_size_experiment/): 180 runs over
+# actor / critic in {64-32, 128-64, 200-100} x learning rates {1e-3, 5e-3}, 5 runs per combination -- the evidence the
+# reference holds for the WIDER networks (multi-workgroup learner, register- / LDS-staged MFMA actors)
+import re  # noqa: E402
+
+files = sorted(glob.glob(os.path.join(REF, "data/ddpg_baselines_summaries/hidden_layer_size_experiment/*.json")))
+steps, returns, labels = [], [], []
+for f in files:
+    m = re.search(r"_a-(\d+)-(\d+)\.0-0d(\d+)_c-(\d+)-(\d+)\.0-0d(\d+)_", os.path.basename(f))
+    d = json.load(open(f))
+    e = np.asarray(d["episodes"], np.float64)
+    assert e.shape == (1000, 2), (f, e.shape)
+    p = d["param_dict"]
+    a1, a2, alr, c1, c2, clr = (int(x) for x in m.groups())
+    assert (p["actor_h1"], p["actor_h2"], p["critic_h1"], p["critic_h2"]) == (a1, a2, c1, c2), f
+    assert abs(p["actor_lr"] - alr * 1e-3) < 1e-12 and abs(p["critic_lr"] - clr * 1e-3) < 1e-12, f
+    steps.append(e[:, 0].astype(np.int16))
+    returns.append(e[:, 1].astype(np.float32))
+    labels.append([a1, a2, alr, c1, c2, clr])          # learning rates in units of 1e-3
+np.savez_compressed(os.path.join(OUT, "ddpg_hidden_layer_curves.npz"), steps=np.stack(steps), returns=np.stack(returns),
+                    labels=np.asarray(labels, np.int32))
+print(len(files), "hidden-layer-size runs")

@@ -82,3 +82,64 @@ def test_scalar_rltrain_ddpg_learning_curves_fall_inside_the_reference_band(gold
     assert lb[0] <= np.median(lates) <= lb[1], (lates, lb)
     assert np.sum((firsts < fb[0]) | (firsts > fb[1])) <= N_SEEDS // 4, (firsts, fb)
     assert np.sum((lates < lb[0]) | (lates > lb[1])) <= N_SEEDS // 4, (lates, lb)
+
+
+# ---- the wider networks of the reference's grid (hidden_layer_size_experiment): multi-workgroup learner + generic actor --
+def wide_reference_bands(golden_dir, min_units=128):
+    """The runs whose actor AND critic are at least ``min_units``-wide with both learning rates 1e-3 (4 combinations x 5
+    runs): inter-decile band of the late-window median return, and the largest first-goal episode."""
+    g = np.load(f"{golden_dir}/ddpg_hidden_layer_curves.npz")
+    lab, steps, rets = g["labels"], g["steps"].astype(np.int64), g["returns"].astype(np.float64)
+    sel = (lab[:, 0] >= min_units) & (lab[:, 3] >= min_units) & (lab[:, 2] == 1) & (lab[:, 5] == 1)
+    goal = steps[sel] < 999
+    first = np.array([int(np.argmax(r)) if r.any() else steps.shape[1] for r in goal])
+    late = np.median(rets[sel][:, LATE[0]:LATE[1]], axis=1)
+    return dict(n=int(sel.sum()), first=first, late=late, late_band=np.percentile(late, [10, 90]))
+
+
+def test_wide_reference_curve_fixture(golden_dir):
+    """(CPU) 180 runs, 5 per combination; the wide ones converge to the same 88-95 band as the canonical shape."""
+    g = np.load(f"{golden_dir}/ddpg_hidden_layer_curves.npz")
+    assert g["steps"].shape == (180, 1000) and g["labels"].shape == (180, 6)
+    combos, counts = np.unique(g["labels"], axis=0, return_counts=True)
+    assert len(combos) == 36 and (counts == 5).all()
+    b = wide_reference_bands(golden_dir)
+    assert b["n"] == 20 and b["first"].max() <= 10
+    assert 85.0 <= b["late_band"][0] <= 91.0 and 93.0 <= b["late_band"][1] <= 96.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h1,h2,n_seeds", [(200, 100, 3), (128, 64, 2)])
+def test_wide_ddpg_learning_curves_fall_inside_the_reference_band(golden_dir, h1, h2, n_seeds):
+    """The same loop with actor = critic = h1-h2 (learner: ddpg_train_wide.hip, batch 64 over 4 workgroups; actor: generic /
+    MFMA forward): late-window median returns inside the band of the reference's wide runs, first goal no later than theirs."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no fallback")
+    import random
+
+    import smartstartcontinuous_amd as ssc
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
+    p = reference_bands(golden_dir)["params"]
+    b = wide_reference_bands(golden_dir)
+    firsts, lates, t0 = [], [], time.time()
+    for seed in range(n_seeds):
+        np.random.seed(2000 + seed)
+        random.seed(2000 + seed)
+        env = ssc.make("MountainCarContinuous-v0", seed=2000 + seed)
+        agent = DDPG_Baselines_agent(env, None, buffer_size=p["buffer_size"], batch_size=p["batch_size"],
+                                     num_train_iterations=p["num_train_iterations"], num_steps_before_train=p["num_steps_before_train"],
+                                     ou_epsilon=p["ou_epsilon"], ou_min_epsilon=p["ou_min_epsilon"],
+                                     ou_epsilon_decay_factor=p["ou_epsilon_decay_factor"], ou_mu=p["ou_mu"], ou_sigma=p["ou_sigma"],
+                                     ou_theta=p["ou_theta"], actor_lr=1e-3, actor_h1=h1, actor_h2=h2, critic_lr=1e-3, critic_h1=h1,
+                                     critic_h2=h2, gamma=p["gamma"], tau=p["tau"], lastLayerTanh=True, seed=2000 + seed)
+        summary = ssc.rlTrain(agent, env, print_results=False, print_steps=False, num_episodes=E_TOTAL, max_steps=1000)
+        ep = np.asarray(summary.episodes, np.float64)
+        goal = ep[:, 0] < 999
+        firsts.append(int(np.argmax(goal)) if goal.any() else E_TOTAL)
+        lates.append(float(np.median(ep[LATE[0]:LATE[1], 1])))
+        print("%d-%d seed %d: first goal episode %d, late median return %.2f (%.0f s so far)" % (h1, h2, seed, firsts[-1], lates[-1], time.time() - t0), flush=True)
+    lb = b["late_band"]
+    print("reference (20 wide runs): late median band", lb, "first goal <=", b["first"].max(), "| ours:", firsts, lates)
+    assert lb[0] - 1.0 <= np.median(lates) <= lb[1] + 1.0, (lates, lb)
+    assert max(firsts) <= max(int(b["first"].max()), 10) + 5, (firsts, b["first"])
+    assert sum(1 for x in lates if x < lb[0] - 5.0) <= n_seeds // 3, (lates, lb)     # the reference itself has a rare diverged run
