@@ -92,6 +92,40 @@ __global__ __launch_bounds__(64) void actor_generic_kernel(ActorWeights w, int a
             if (a < act_dim) act[i * act_dim + a] = tanh_fast(out[a]);
 }
 
+// The same arithmetic for A FEW rows (the scalar RLAgent.get_action path: m = 1): one 256-thread block per row, hidden
+// units across the threads.  actor_generic_kernel gives a row to ONE lane -- h1 x h2 dependent FMAs in a single thread,
+// 0.3-0.5 ms for a 200-100 actor, which was most of a scalar rlTrain step with the wide networks.  Every output unit still
+// sums its inputs in index order with fused multiply-adds, so the two kernels return identical bits.
+__global__ __launch_bounds__(256) void actor_row_kernel(ActorWeights w, int act_dim, const float *__restrict__ obs,
+                                                        float *__restrict__ act) {
+    extern __shared__ float rs[];   // h1 activations | h2 activations
+    float *h1s = rs, *h2s = rs + w.h1;
+    const int64_t i = blockIdx.x;
+    float o[SSC_MAX_STATE];
+#pragma unroll
+    for (int c = 0; c < SSC_MAX_STATE; ++c) o[c] = (c < w.obs_dim) ? clip_obs(obs[i * w.obs_dim + c], w.obs_clip) : 0.0f;
+    for (int j = threadIdx.x; j < w.h1; j += blockDim.x) {
+        float acc = w.b1[j];
+#pragma unroll
+        for (int c = 0; c < SSC_MAX_STATE; ++c)
+            if (c < w.obs_dim) acc = fmaf(o[c], w.W1[c * w.h1 + j], acc);
+        h1s[j] = fmaxf(acc, 0.0f);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < w.h2; j += blockDim.x) {
+        float acc = w.b2[j];
+        for (int k = 0; k < w.h1; ++k) acc = fmaf(h1s[k], w.W2[k * w.h2 + j], acc);
+        h2s[j] = w.last_layer_tanh ? tanh_fast(acc) : fmaxf(acc, 0.0f);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < act_dim) {
+        const int a = threadIdx.x;
+        float out = w.b3[a];
+        for (int j = 0; j < w.h2; ++j) out = fmaf(h2s[j], w.W3[j * act_dim + a], out);
+        act[i * act_dim + a] = tanh_fast(out);
+    }
+}
+
 }  // namespace ssc
 
 using namespace ssc;
@@ -135,6 +169,11 @@ extern "C" int ssc_actor_forward(const ssc_actor_desc *a, int64_t m, const float
         return check_launch("ssc_actor_forward(f32)");
     }
     if (a->h1 > 512) return set_error(SSC_EUNSUPPORTED, "ssc_actor_forward: h1 %d > 512", a->h1);
+    if (m <= 32 && a->h2 <= 4096) {   // a handful of rows (scalar get_action): hidden units across a block's threads
+        hipLaunchKernelGGL(actor_row_kernel, dim3((unsigned)m), dim3(256), (size_t)(a->h1 + a->h2) * sizeof(float), s, w,
+                           a->act_dim, d_obs, d_act);
+        return check_launch("ssc_actor_forward(row)");
+    }
     const size_t lds = (size_t)a->h1 * 64 * sizeof(float);
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(actor_generic_kernel),

@@ -67,6 +67,9 @@ def test_actor_forward_generic_sizes(ssc):
     obs = rng.uniform(-1, 1, size=(777, 2)).astype(np.float32)
     got = _actor_forward_gpu(ssc, w, obs, ffi.SSC_PREC_F32)
     assert np.max(np.abs(got - O.actor_forward(obs, **w))) <= TOL_ACT_F32
+    # a handful of rows (the scalar get_action path) run one block per row: same sums in the same order, identical bits
+    few = _actor_forward_gpu(ssc, w, obs[:20], ffi.SSC_PREC_F32)
+    assert np.array_equal(few, got[:20])
     w = actor_weights(4, 64, 32, seed=4, w3_scale=0.2)
     w["W3"] = rng.uniform(-0.2, 0.2, size=(32, 3)).astype(np.float32)
     w["b3"] = rng.uniform(-0.1, 0.1, size=3).astype(np.float32)
