@@ -52,6 +52,9 @@ constexpr int kMaxKS1 = 2;        // layer-1 k-steps of 32 slots: 2 bias slots +
 #ifndef SSC_DYN_LAG_BARRIER_PAIR
 #define SSC_DYN_LAG_BARRIER_PAIR 1
 #endif
+#ifndef SSC_DYN_LAG_X1
+#define SSC_DYN_LAG_X1 11
+#endif
 #ifndef SSC_DYN_LAG_PRIO
 #define SSC_DYN_LAG_PRIO 3
 #endif
@@ -685,7 +688,8 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 // LAG, group 0, tile 15: behind its barrier (#15) the pieces of the NEXT step's tile 1 go out as well --
                 // the phase that follows takes barrier #16, which wants them landed (step 0: loaded by the prologue)
                 constexpr bool LAST = decltype(first_tag)::value == 2;
-                constexpr int X0 = NF - RING - 1, X1 = X0 - NF / 2;   // barrier fragment of group 0 / group 1
+                // barrier fragment of group 0 / group 1 (LAG: group 1's may sit anywhere behind the end of the tile before)
+                constexpr int X0 = NF - RING - 1, X1 = LAG ? SSC_DYN_LAG_X1 : X0 - NF / 2;
                 static_assert(!STREAM || (UT == 16 && X1 + 2 + 4 * (PPW - 1) < NF), "LDS-DMA issue slots");
                 const int nsel = LAG ? ((jt + 1) & 3) : STREAM ? (bsel == 2 ? 0 : bsel + 1) : ((jt + 1) & (UT - 1));
                 const unsigned char *buf = l_a2 + (LAG ? (jt & 3) : STREAM ? bsel : jt) * A2_TILE + lane * 16;

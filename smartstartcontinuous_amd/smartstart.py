@@ -221,7 +221,8 @@ class VecSmartStart:
                  exploration_param=2., n_plans=1, n_slots=None, w_max=None, num_control_samples=64, horizon=4,
                  noise_amount=0.005, steps_before_giving_up_on_waypoint=5, final_steps=10, theta=1.0, gamma=0.75,
                  horizontal_penalty_factor=0.5, path_shortcutting=True, mean_per_stepsize=1, std_per_stepsize=1,
-                 stepsizes_in_waypoint_radii=1, steps_per_waypoint=1, chunk_steps=64, seed=1234, log_modes=False):
+                 stepsizes_in_waypoint_radii=1, steps_per_waypoint=1, chunk_steps=64, seed=1234, log_modes=False,
+                 kde_max_states=None):
         from . import navigator as nav
         self.env, self.agent, self.model = env, agent, dyn_model
         self.eta, self.eta_decay_factor = float(eta), float(eta_decay_factor)
@@ -248,6 +249,11 @@ class VecSmartStart:
         self.d_eta = torch.tensor([self.eta], dtype=torch.float32, device=dev)
         self.d_eps = torch.tensor([0.0], dtype=torch.float32, device=dev)
         self.log_modes = bool(log_modes)
+        # The reference estimates the visitation density from EVERY state in its buffer (<= 100 000 there, :258-260); a
+        # device ring sized for 65 536 envs holds tens of millions, and the n_ss x |D| kernel then is most of a selection.
+        # kde_max_states bounds |D| by an evenly strided subsample of the ring (a density estimate does not depend on the
+        # sample count); None = all states, the reference's behaviour.
+        self.kde_max_states = kde_max_states
         self.mode_log = None
         self.last_radii = None
         self._graphs = {}
@@ -277,6 +283,9 @@ class VecSmartStart:
         if idx is None:
             return None
         all_states = replay.get_all_states()                                                      # :258
+        if self.kde_max_states is not None and all_states.shape[0] > self.kde_max_states:
+            stride = -(-all_states.shape[0] // int(self.kde_max_states))
+            all_states = all_states[::stride].contiguous()
         wh, norm = kde_scott_bandwidth(all_states)                                                # :260
         volume = volume_of_n_dimensional_hyperellipsoid(self.last_radii) if self.last_radii is not None else 1   # :262-268
         cand = replay.s2[replay.physical(idx)]                                                    # :272-273
