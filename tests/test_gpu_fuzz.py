@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("tool,cases,expect", [
     ("fuzz_rollout.py", 16, "Pendulum random-policy rollout: 8 random configurations ok"),
     ("fuzz_actor_rollout.py", 14, "actor rollout: 14 random configurations ok"),
+    ("fuzz_actor_wide.py", 12, "wide actor rollout: 12 random configurations ok"),
     ("fuzz_dyn_shapes.py", 12, "forward simulation: 12 random shapes ok"),
     ("fuzz_dyn_train.py", 10, "dynamics-model training step: 10 random shapes ok"),
     ("fuzz_mpc_score.py", 10, "MPC scoring: 10 random configurations ok"),
