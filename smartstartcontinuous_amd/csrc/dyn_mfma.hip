@@ -121,18 +121,16 @@ struct DynNet {
     const float *W1, *b1, *W2, *b2, *W3, *b3;  // W3/b3 = output layer; W2/b2 unused when nfc == 1
     int in, depth, out, nfc;
     bool biask;  // b2 in the spare k slots depth, depth+1 of the hidden contraction (needs depth + 2 <= 32*UT)
-    bool compact1;  // layer-1 fragments in the compact lane-group layout of the LAG kernel (see l1_compact below)
+    bool compact1;  // layer-1 fragments in the compact lane-group layout of the KIN = 4 kernels (see l1_compact below)
 };
 
-// Compact layer-1 layout (networks with <= 4 inputs on the streamed-W2 kernel): k group g = lane >> 4 of the MFMA carries
+// Compact layer-1 layout (networks with <= 4 inputs and outputs, i.e. every kernel compiled with KIN = 4): k group g = lane >> 4 of the MFMA carries
 // INPUT g alone -- slots 8g + {0, 1, 2} = {xh * wh, xl * wh, xh * wl}, slot 8g + 3 = 1 * (bf16 head of b1 in group 0, its
 // residual in group 1), slots 8g + 4..7 unused.  A lane then splits ONE input per step instead of selecting its eight
 // slots out of all of them (the per-step input code drops from ~120 to ~16 VALU ops per 16 rows), and a weight fragment
 // is 8 bytes per lane instead of 16: the layer-1 image is 16 KB instead of 32 KB, which is what buys the W2 ring its
 // fourth 32 KB slot.
-__host__ __device__ __forceinline__ bool l1_compact(int in, int out, int depth, int nfc) {
-    return nfc == 2 && depth > 128 && in <= 4 && out <= 4;
-}
+__host__ __device__ __forceinline__ bool l1_compact(int in, int out) { return in <= 4 && out <= 4; }   // == the KIN = 4 kernels
 
 __device__ __forceinline__ __bf16 bf16_head(float v) { return (__bf16)v; }
 __device__ __forceinline__ __bf16 bf16_resid(float v) { return (__bf16)(v - (float)(__bf16)v); }
@@ -323,7 +321,8 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     constexpr int A2_TILE = UT * 2048;  // W2^T fragments of one 32-unit output tile: NF fragments of 1 KiB
     constexpr int NBUF = LAG ? 4 : dyn_a2_bufs<UT, NFC>();
     constexpr bool STREAM = (NFC == 2) && (UT > 4);
-    constexpr int A1_BYTES = LAG ? MT * 512 : KS1 * MT * 1024;   // layer-1 fragments: 8 B per lane when compact
+    constexpr bool CMP = (KIN == 4);                            // compact lane-group layer 1 (l1_compact)
+    constexpr int A1_BYTES = CMP ? MT * 512 : KS1 * MT * 1024;   // layer-1 fragments: 8 B per lane when compact
     constexpr int A2_CHUNKS = A2_TILE / 1024;           // LDS-DMA pieces per tile
     constexpr int PPW = (A2_CHUNKS + kNW - 1) / kNW;    // pieces per wave per tile
     unsigned char *l_a2 = lds;
@@ -378,20 +377,11 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     constexpr int a3_step = 512;
 
     // ---- this lane's rows: one per 16-row column tile; the 4 k-group lanes of a row carry it redundantly ----
+    // A block of a kernel whose weights are RESIDENT in LDS (no W2 stream) can walk over row tiles tile, tile + gridDim.x, ...
+    // (setup_rows below); the launcher gives every tile its own block, see launch_sim.
     int64_t row[2], rowc[2];
     bool valid[2];
     float st[2][DS];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        row[nt] = (int64_t)blockIdx.x * kDynRows + wave * 32 + nt * 16 + c;
-        valid[nt] = row[nt] < g.m;
-        rowc[nt] = valid[nt] ? row[nt] : g.m - 1;
-        if (!fwd_mode) {
-#pragma unroll
-            for (int k = 0; k < DS; ++k)
-                st[nt][k] = (k < g.d) ? g.s0[(rowc[nt] / g.s0_rows) * g.d + k] : 0.0f;   // s0_rows: rows per start state
-        }
-    }
 
     // the actions of step t+1 are fetched during step t (a global load costs ~1-2 k cycles even from L2) -- or, in
     // sampling mode, drawn from Philox here: candidate sequence of sample n of problem p = words of
@@ -404,13 +394,8 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     u32x4 wcache[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
     int wc = -1;  // Philox call the cached words belong to (block-uniform)
     uint64_t tt = 0;
-    if (sample) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            sid[nt] = ((g.pid0 + (uint64_t)(rowc[nt] / g.N)) << 32) + (uint64_t)(rowc[nt] % g.N);
-        tt = (g.t + (g.t_base != nullptr ? *g.t_base : 0)) * (uint64_t)((g.H * g.a + 3) / 4);
-    }
-    auto fetch_actions = [&](int ts) {
+    if (sample) tt = (g.t + (g.t_base != nullptr ? *g.t_base : 0)) * (uint64_t)((g.H * g.a + 3) / 4);
+    auto fetch_actions = [&](int ts) __attribute__((always_inline)) {
         if (sample) {
 #pragma unroll
             for (int ai = 0; ai < AMAX; ++ai)
@@ -437,11 +422,26 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             }
         }
     };
+    auto setup_rows = [&](int64_t tile) __attribute__((always_inline)) {   // (a call would put the row state in scratch memory)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt) {
+            row[nt] = tile * kDynRows + wave * 32 + nt * 16 + c;
+            valid[nt] = row[nt] < g.m;
+            rowc[nt] = valid[nt] ? row[nt] : g.m - 1;
+            if (!fwd_mode) {
 #pragma unroll
-        for (int ai = 0; ai < AMAX; ++ai) act[nt][ai] = 0.0f;
-    if (!fwd_mode && g.H > 0) fetch_actions(0);
+                for (int k = 0; k < DS; ++k)
+                    st[nt][k] = (k < g.d) ? g.s0[(rowc[nt] / g.s0_rows) * g.d + k] : 0.0f;   // s0_rows: rows per start state
+            }
+            if (sample) sid[nt] = ((g.pid0 + (uint64_t)(rowc[nt] / g.N)) << 32) + (uint64_t)(rowc[nt] % g.N);
+#pragma unroll
+            for (int ai = 0; ai < AMAX; ++ai) act[nt][ai] = 0.0f;
+        }
+        wc = -1;
+        if (!fwd_mode && g.H > 0) fetch_actions(0);
+    };
+    int64_t tile = blockIdx.x;
+    setup_rows(tile);
 
     // Normalisation constants per network input (input k = state k for k < d, else action k-d) and per state
     // delta, read once through scalar loads: block-uniform, so they live in SGPRs and the per-step input code
@@ -459,11 +459,11 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         z_mean[k] = (k < g.d) ? uniform_f32(g.nm[4 * 8 + k]) : 0.0f;
         z_std[k] = (k < g.d) ? uniform_f32(g.nm[5 * 8 + k]) : 0.0f;
     }
-    // LAG: this lane's k group carries network input kg alone (l1_compact): its mean / 1/std, and the constant-1 slot
+    // CMP: this lane's k group carries network input kg alone (l1_compact): its mean / 1/std, and the constant-1 slot
     // (bias carrier) in k groups 0 and 1
     float my_mean = 0.0f, my_inv = 0.0f;
     uint32_t my_one = 0;
-    if (LAG) {
+    if (CMP) {
 #pragma unroll
         for (int k = 0; k < KIN; ++k) {
             my_mean = (kg == k) ? n_mean[k] : my_mean;
@@ -487,15 +487,16 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     const uint64_t stamp_r0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
     uint64_t ph[6] = {0, 0, 0, 0, 0, 0};  // diagnostic: cycles in input code / layer 1 / hidden tiles / step tail / phase barrier / tile barriers
 #define SSC_STAMP(var) uint64_t var = 0; if (SSC_DYN_ABLATE & 16) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    for (;;) {   // row tiles of this block (one pass when W2 is streamed)
     for (int t = 0; t < g.H; ++t) {
         SSC_STAMP(stamp_a)
         // ---- inputs: record S[t]; layer-1 B fragments of x = normalised (state, action) ---------------
         bf16x8 xf[2][KS1];
-        s16x4 xc[2];   // LAG: the compact layer-1 B fragments (four k slots per lane)
-        if constexpr (LAG) {
+        s16x4 xc[2];   // CMP: the compact layer-1 B fragments (four k slots per lane)
+        if constexpr (CMP) {
             // The phase is what the other wave of this SIMD has to bridge with W2 tiles: it runs at raised issue priority
             // (set behind the last hidden tile, dropped again in front of the first one) ...
-            if (t == 0) __builtin_amdgcn_s_setprio(SSC_DYN_LAG_PRIO);
+            if (LAG && t == 0) __builtin_amdgcn_s_setprio(SSC_DYN_LAG_PRIO);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 float xv;
@@ -586,16 +587,16 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         // previous step's hidden fragments are free here): under the other wave's W2 stream an LDS read takes longer
         // than the pair in front of it
         constexpr int kL1Ahead = 4;
-        s16x4 a1q[LAG ? UT : 1][2];
+        s16x4 a1q[CMP ? UT : 1][2];
         auto l1_request = [&](int p) {
-            if constexpr (LAG) {
+            if constexpr (CMP) {
                 a1q[p][0] = *reinterpret_cast<const s16x4 *>(l_a1 + ((2 * p + 0) * 64 + lane) * 8);
                 a1q[p][1] = *reinterpret_cast<const s16x4 *>(l_a1 + ((2 * p + 1) * 64 + lane) * 8);
             }
         };
-        if constexpr (LAG) {
+        if constexpr (CMP) {
 #pragma unroll
-            for (int q = 0; q < kL1Ahead; ++q) l1_request(q);
+            for (int q = 0; q < (kL1Ahead < UT ? kL1Ahead : UT); ++q) l1_request(q);
         }
         auto layer1_pair = [&](int p) {
             L1 o;
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 o.d[mh][1] = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < KS1; ++ks) {  // no runtime bound: a branch here would serialise every LDS read
-                    if constexpr (LAG) {
+                    if constexpr (CMP) {
                         // compact image: 8 B per lane = the four k slots of this lane's k group, which is exactly the
                         // operand of v_mfma_f32_16x16x16_bf16 (same 16 cycles as the K = 32 shape, same D layout, but
                         // two-register operands: no zero padding to build)
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             pp[0] = layer1_pair(0);
 #pragma unroll
             for (int p = 0; p < UT; ++p) {
-                if (LAG && p + kL1Ahead < UT) l1_request(p + kL1Ahead);
+                if (CMP && p + kL1Ahead < UT) l1_request(p + kL1Ahead);
                 if (p + 1 < UT) pp[(p + 1) & 1] = layer1_pair(p + 1);
                 h1f[0][p] = relu_to_frag(pp[p & 1].d[0][0], pp[p & 1].d[1][0]);
                 h1f[1][p] = relu_to_frag(pp[p & 1].d[0][1], pp[p & 1].d[1][1]);
@@ -811,6 +812,11 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                     if (k < g.d) g.S[((int64_t)g.H * g.m + row[nt]) * g.d + k] = st[nt][k];  // :240
             }
     }
+    if (STREAM) break;
+    tile += gridDim.x;
+    if (tile * kDynRows >= g.m) break;
+    setup_rows(tile);
+    }
     // LAG: group 1's last tile holds barrier #16 H; group 0 meets it here (no phase follows its last tile)
     if (LAG && group == 0 && g.H > 0 && !(SSC_DYN_ABLATE & 2)) {
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -854,7 +860,7 @@ size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp) {
 template <int UT, int NFC, bool BIASK, int KIN, bool LAG = false, int MODE = -1>
 static int launch_sim(const DynSimArgs &g, hipStream_t s) {
     const size_t lds = (size_t)(LAG ? 4 : dyn_a2_bufs<UT, NFC>()) * UT * 2048 +
-                       (LAG ? (size_t)UT * 1024 : (size_t)l1_ksteps(KIN) * UT * 2048) + (size_t)UT * 512 + (size_t)UT * 128 + 64;
+                       (KIN == 4 ? (size_t)UT * 1024 : (size_t)l1_ksteps(KIN) * UT * 2048) + (size_t)UT * 512 + (size_t)UT * 128 + 64;
     auto kern = dyn_mfma_sim_kernel<UT, NFC, BIASK, KIN, LAG, MODE>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -862,6 +868,9 @@ static int launch_sim(const DynSimArgs &g, hipStream_t s) {
                            "hipFuncSetAttribute(dyn_mfma_sim_kernel)");
         if (rc) return rc;
     }
+    // One block per 256-row tile.  (The kernel can walk a block over several tiles -- grid < tiles -- so that the prologue
+    // is paid once per block; measured for the 1 x 32 network at 1 M rows x 4 steps: 96 us against 81 us with one tile
+    // per block, the per-tile row loads no longer overlap across blocks.  Not used.)
     const unsigned grid = (unsigned)((g.m + kDynRows - 1) / kDynRows);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kDynThreads), lds, s, g);
     return check_launch("dyn_mfma_sim_kernel");
@@ -872,7 +881,7 @@ static DynNet make_net(const ssc_mlp_desc *mlp, int UT) {
     DynNet n;
     n.in = mlp->dims[0]; n.depth = mlp->dims[1]; n.out = mlp->dims[mlp->n_layers]; n.nfc = nfc;
     n.biask = (nfc == 2) && (n.depth + 2 <= 32 * UT);
-    n.compact1 = l1_compact(n.in, n.out, n.depth, nfc);
+    n.compact1 = l1_compact(n.in, n.out);
     n.W1 = mlp->W[0]; n.b1 = mlp->b[0];
     n.W2 = (nfc == 2) ? mlp->W[1] : nullptr; n.b2 = (nfc == 2) ? mlp->b[1] : nullptr;
     n.W3 = mlp->W[nfc]; n.b3 = mlp->b[nfc];
@@ -908,7 +917,7 @@ static int run_mfma(const ssc_mlp_desc *mlp, DynSimArgs &g, void *wsv, hipStream
 #define SSC_DYN_CASE(U, F, B)                                                                 \
     if (UT == U && nfc == F && n.biask == B)                                                  \
         return kin == 4 ? launch_sim<U, F, B, 4>(g, s) : kin == 10 ? launch_sim<U, F, B, 10>(g, s) : launch_sim<U, F, B, kMaxIn>(g, s)
-    if (n.compact1) {   // streamed W2, <= 4 inputs and outputs (the BASELINE shape): the 4-slot, 1.5-tile-lag kernel
+    if (n.compact1 && UT == 16 && nfc == 2) {   // streamed W2, <= 4 inputs and outputs (the BASELINE shape): the 4-slot, 1.5-tile-lag kernel
         const int mode = g.fwd_mode ? 2 : (g.sample ? 1 : 0);
         if (n.biask)
             return mode == 2 ? launch_sim<16, 2, true, 4, true, 2>(g, s) : mode == 1 ? launch_sim<16, 2, true, 4, true, 1>(g, s)

@@ -12,9 +12,12 @@ CASES = [(65536, 256, 50, False, 64, (64, 32)), (65536, 256, 50, True, 64, (64, 
          (65536, 256, 500, True, 64, (64, 32)), (4096, 64, 50, False, 64, (64, 32)), (4096, 64, 50, True, 64, (64, 32)),
          (256, 40, 50, False, 64, (64, 32)),
          (65536, 256, 10, False, 1024, (64, 32)), (65536, 256, 10, False, 4096, (64, 32)), (65536, 256, 50, False, 4096, (64, 32)),
-         (65536, 256, 10, False, 1024, (200, 100)), (65536, 256, 10, False, 4096, (200, 100))]
+         (65536, 256, 10, False, 1024, (200, 100)), (65536, 256, 10, False, 4096, (200, 100)),
+         (65536, 256, 10, True, 1024, (64, 32)), (65536, 256, 25, True, 1024, (64, 32)), (65536, 256, 25, False, 1024, (64, 32))]
 if len(sys.argv) > 1 and sys.argv[1] == "wide":
     CASES = CASES[7:]
+if len(sys.argv) > 1 and sys.argv[1] == "overlap":
+    CASES = [CASES[7]] + CASES[12:]
 for n_envs, chunk, iters, overlap, batch, (h1, h2) in CASES:
     env = ssc.VecEnv("MountainCarContinuous-v0", n_envs, seed=1)
     env.reset()
