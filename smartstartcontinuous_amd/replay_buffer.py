@@ -8,6 +8,7 @@ reference's O(|buffer|) list copy per step (replay_buffer.py:79-83).
 """
 from __future__ import annotations
 
+import bisect
 import random
 from collections import deque
 
@@ -15,15 +16,37 @@ import numpy as np
 
 
 class ReplayBuffer:
+    """Host replay ring.  Records live in preallocated numpy arrays (``_head`` / ``_len`` ring); episode starts are kept
+    as ABSOLUTE record numbers (``_starts``: how many records had been added when the episode began) beside the count of
+    records ever added (``_added``).  The reference's bookkeeping (replay_buffer.py:33-44,57-72: relative
+    ``episode_starting_indices`` that are re-based, element by element, whenever the oldest start is evicted, and a
+    ``next_episode_number`` that moves with them) is a VIEW of that state -- ``index = start - _base``,
+    ``next_episode_number = _added - _base`` -- where ``_base`` is the absolute number the reference currently calls 0;
+    an eviction is then O(1) (pop the start, move ``_base``).  The values read through the two properties are pinned by
+    traces of the reference's own buffer (tests/golden/replay_buffer_kats.npz)."""
+
     def __init__(self, main_agent, max_buffer_size):
         self.main_agent = main_agent
         self.max_buffer_size = int(max_buffer_size)
-        # episode numbering exactly as in the reference (replay_buffer.py:33-44)
-        self.next_episode_number = 0
-        self.episode_starting_indices = deque()
+        self._starts = deque()     # absolute record numbers at which the episodes still (partly) in the ring began
+        self._added = 0            # records ever added
+        self._base = 0             # absolute record number of the reference's episode number 0
         self._s = self._a = self._r = self._t = self._s2 = None
         self._head = 0     # ring index of the oldest record
         self._len = 0
+
+    @property
+    def episode_starting_indices(self):
+        """The reference's list (replay_buffer.py:33-44), derived: a fresh list -- mutate through ``start_new_episode``."""
+        return [a - self._base for a in self._starts]
+
+    @property
+    def next_episode_number(self):
+        return self._added - self._base
+
+    @next_episode_number.setter
+    def next_episode_number(self, value):
+        self._base = self._added - int(value)
 
     # ------------------------------------------------------------------ storage helpers --
     def _alloc(self, s, a):
@@ -58,16 +81,11 @@ class ReplayBuffer:
             p = (self._head + self._len) % self.max_buffer_size
             self._len += 1
         else:
-            if len(self.episode_starting_indices) > 0 and \
-                    self.episode_starting_indices[0] == self.next_episode_number - self.max_buffer_size:
-                self.episode_starting_indices.popleft()
-                if len(self.episode_starting_indices) > 0:
-                    first = self.episode_starting_indices[0]
-                    for i in range(len(self.episode_starting_indices)):
-                        self.episode_starting_indices[i] -= first
-                    self.next_episode_number -= first
-                else:
-                    self.next_episode_number = 0
+            # the oldest record leaves.  If an episode began exactly there, that start is forgotten and numbering restarts
+            # at the oldest start still known -- or from scratch when none is (replay_buffer.py:57-72)
+            if self._starts and self._starts[0] == self._added - self.max_buffer_size:
+                self._starts.popleft()
+                self._base = self._starts[0] if self._starts else self._added
             p = self._head
             self._head = (self._head + 1) % self.max_buffer_size
         self._s[p] = np.asarray(s, dtype=np.float64).reshape(-1)
@@ -75,7 +93,7 @@ class ReplayBuffer:
         self._r[p] = float(r)
         self._t[p] = bool(t)
         self._s2[p] = np.asarray(s2, dtype=np.float64).reshape(-1)
-        self.next_episode_number += 1
+        self._added += 1
 
     def add_chunk(self, observing_agent, chunk, env_index=0, last_steps=None):
         """Ingest one env's column of a TransitionChunk (device SoA log) in step order, opening a new
@@ -120,16 +138,16 @@ class ReplayBuffer:
 
     def clear(self):
         self._head = self._len = 0
-        self.next_episode_number = 0
+        self._base = self._added      # next_episode_number = 0; the starts are kept, like the reference's clear()
 
     # ------------------------------------------------------------------------ episodes --
     def start_new_episode(self, observing_agent):
         """replay_buffer.py:109-115"""
         if observing_agent is not self.main_agent:
             return
-        if len(self.episode_starting_indices) > 0 and self.episode_starting_indices[-1] == self.next_episode_number:
+        if self._starts and self._starts[-1] == self._added:
             return  # the reference prints a warning and ignores the duplicate
-        self.episode_starting_indices.append(self.next_episode_number)
+        self._starts.append(self._added)
 
     def episode_number_to_buffer_index(self, episode_number):
         return self._len - (self.next_episode_number - episode_number)
@@ -139,27 +157,24 @@ class ReplayBuffer:
 
     def get_possible_smart_start_indices(self, n_ss):
         """replay_buffer.py:136-152"""
-        if len(self.episode_starting_indices) == 0:
+        if not self._starts:
             return None
-        first = self.episode_number_to_buffer_index(self.episode_starting_indices[0])
+        first = self.episode_number_to_buffer_index(self._starts[0] - self._base)
         number_of_states = min(n_ss, self._len - first)
         return np.array(random.sample(range(first, self._len), number_of_states))
 
     def get_episodic_path_to_buffer_index(self, buffer_index):
         """replay_buffer.py:154-176: states of the episode containing ``buffer_index`` up to and
         including its s2."""
-        if len(self.episode_starting_indices) == 0:
+        if not self._starts:
             raise ValueError(": (   -   no episodes have been recorded")
-        episode_index = self.buffer_index_to_episode_number(buffer_index)
-        start = None
-        starts = self.episode_starting_indices
-        for i in range(len(starts) - 1):
-            if starts[i] <= episode_index < starts[i + 1]:
-                start = starts[i]
-                break
-        if start is None and starts[-1] <= episode_index:
-            start = starts[-1]
-        b0 = self.episode_number_to_buffer_index(start)
+        # the last start at or before the record (the starts are increasing: a bisection instead of the reference's scan)
+        record = self._added - self._len + int(buffer_index)             # absolute number of the record
+        starts = list(self._starts)
+        k = bisect.bisect_right(starts, record) - 1
+        if k < 0:
+            raise TypeError("buffer index %d precedes every recorded episode start" % int(buffer_index))   # the reference fails on start = None here
+        b0 = starts[k] - (self._added - self._len)
         idx = np.arange(b0, buffer_index + 1)
         s = self._s[self._phys(idx)]
         return [row for row in s] + [self._s2[self._phys(buffer_index)]]
@@ -184,8 +199,8 @@ class ReplayBuffer:
             return False
         self._head = self._len = 0
         self._s = None
-        self.episode_starting_indices.clear()
-        self.next_episode_number = 0
+        self._starts.clear()
+        self._added = self._base = 0
         agent = self.main_agent
         for (s, a, r, t, s2) in records[-self.max_buffer_size:]:
             self.add(agent, s, a, r, t, s2)
