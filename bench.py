@@ -353,6 +353,62 @@ def bench_config4_envs(args, torch, emit=True, P=N_ENVS_PER_GPU, N=16, H=4, K=40
     return res
 
 
+def bench_smartstart_vec(args, torch, emit=True, P=N_ENVS_PER_GPU, N=16, H=4, K=64):
+    """The vectorised SmartStart step (beyond SURVEY.md section 8; smartexplorationcontinuous.py:307-376 for all envs at once):
+    65 536 MountainCar envs, each either navigating to a smart start (NND_MB 1 x 32, the reference's shipped navigator
+    shape, N candidates, horizon H) or acting with the DDPG actor (64-32, bf16 MFMA) + OU noise; five launches per step
+    from a HIP graph (actor forward, forward simulation drawing its candidates, scoring, fused step with the per-env mode,
+    hand-over and new-episode logic).  Plans: recorded random-rollout paths published in the plan pool; eta 0.5."""
+    import numpy as np
+
+    from smartstartcontinuous_amd import RandomPolicy, TransitionChunk, VecEnv, VecSmartStart, make
+    from smartstartcontinuous_amd import collect_samples as cs
+    from smartstartcontinuous_amd import navigator as nav
+    from smartstartcontinuous_amd.agents import DDPG_Baselines_agent, init_dynamics_weights
+    d, a = 2, 1
+    denv = VecEnv("MountainCarContinuous-v0", 64, seed=1234)
+    dchunk = denv.rollout(150, RandomPolicy())
+    ts = cs.dataset_from_chunk(dchunk)
+    (mx, sx), (my, sy), (mz, sz) = (cs.column_stats(v) for v in (ts.dataX, ts.dataY, ts.dataZ))
+    host = lambda t: t.cpu().numpy()
+    norm = dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz))
+    Ws, bs = init_dynamics_weights(d + a, d, 1, 32, torch.Generator().manual_seed(1234))
+    model = nav.DynamicsModel(Ws, bs, norm, d, a, precision="bf16_mfma")
+    env = VecEnv("MountainCarContinuous-v0", P, seed=1234, max_episode_steps=300)
+    env.reset()
+    agent = DDPG_Baselines_agent(make("MountainCarContinuous-v0"), None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32,
+                                 lastLayerTanh=True, seed=1, training=False, ou_mu=0.4, ou_sigma=0.6, precision="bf16_mfma")
+    smart = VecSmartStart(env, agent, model, eta=0.5, n_plans=8, num_control_samples=N, horizon=H, chunk_steps=K, seed=1234,
+                          log_modes=True, path_shortcutting=False)
+    paths = dchunk.obs[:, :150, :8].permute(2, 1, 0).double().cpu().numpy()          # 8 recorded 150-state paths
+    smart.pool.publish([smart.plan_from_path(pth) for pth in paths])
+    chunk = TransitionChunk(d, K, P, env.device)
+    for _ in range(5):                                     # graph capture; 5 x 64 steps fill the envs' modes (300-step episodes)
+        smart.rollout(K, chunk)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps, nav_steps = max(1, args.steps // 4), 0
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        smart.rollout(K, chunk)
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    nav_frac = float(smart.mode_log.float().mean().item())
+    ms_step = el / (reps * K) * 1e3
+    res = {"metric": "env-steps/sec, vectorised SmartStart step (per-env navigate / explore mode), 65 536 MountainCar envs",
+           "value": P / (ms_step * 1e-3), "unit": "env-steps/s", "n_gpus": 1, "steps": reps * K, "ms_per_step": ms_step,
+           "gpu_ms_per_step": e0.elapsed_time(e1) / (reps * K), "navigated_fraction_last_chunk": nav_frac,
+           "higher_is_better": True, "dtype": "bf16 (MFMA), fp32 accumulate", "data": "synthetic",
+           "config": {"workload": "MountainCarContinuous-v0, %d envs, eta 0.5, 8 plans on offer (recorded 150-state paths), NND_MB 1x32 x %d "
+                                  "candidates x horizon %d, DDPG actor 64-32 + OU noise; 5 launches per env-step from a HIP graph; the "
+                                  "per-chunk smart-start selection is not part of this figure" % (P, N, H)}}
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
+
+
 def profiled_traffic():
     """HBM bytes per launch of the rollout kernel from the committed rocprofv3 PMC passes
     (profiles/<tag>/traffic.json: WRITE_SIZE*1024 + 2*FETCH_SIZE*1024, gfx950 correction) -- the counters cannot
@@ -794,10 +850,12 @@ def main():
             a2.no_cpu_baseline = True
             other = {}
             # (a failure in one of these legs must not cost the headline line: it is reported in place of the leg)
-            for name, fn in (("config3", bench_config3), ("config4", bench_config4), ("config4_per_env", bench_config4_envs)):
+            for name, fn in (("config3", bench_config3), ("config4", bench_config4), ("config4_per_env", bench_config4_envs),
+                             ("smartstart_vec", bench_smartstart_vec)):
                 try:
                     r = fn(a2, torch, emit=False)
-                    other[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline") if k in r}
+                    other[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline",
+                                                     "navigated_fraction_last_chunk") if k in r}
                     other[name]["workload"] = r["config"]["workload"]
                 except Exception as e:           # noqa: BLE001
                     other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
