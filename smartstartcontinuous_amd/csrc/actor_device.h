@@ -257,10 +257,11 @@ struct ActorMfma {
 // ds_read_b128 per fragment, each feeding the MFMAs of both 32-env tiles of the wave (56 KB for 200-100; the four waves
 // of a block share it) -- together with b1, b2 and W3 in accumulator order.  Layer 1 stays on the exact-f32 MFMA with its
 // K <= 4 weights in registers; the data flow from there on is ActorMfma's (accumulator tile -> ReLU -> bf16 -> B operand).
-template <int OBS, int UT, int JT>
+template <int OBS, int UT, int JT, int ET = 2>
 struct ActorMfmaLds {
-    static constexpr int kLanesPerEnv = 1;
-    static constexpr int ET = 2;
+    // ET = 2: one wave = 64 envs; ET = 1: one wave = 32 envs, each on lanes l and l + 32 (twice the waves: two per SIMD at
+    // 65 536 envs, so that one wave's tanh layer runs under the other's MFMAs -- see ActorMfma)
+    static constexpr int kLanesPerEnv = (ET == 1) ? 2 : 1;
     static constexpr int KS1 = (OBS + 1) / 2;
     float a1[UT][KS1];
     const unsigned char *l_a2;   // bf16 [JT][UT][2][64 lanes][8]
@@ -328,13 +329,14 @@ struct ActorMfmaLds {
         for (int ks = 0; ks < KS1; ++ks) {
             const float v0 = obs[2 * ks];
             const float v1 = (2 * ks + 1 < OBS) ? obs[2 * ks + 1] : 0.0f;
-            half_swap(v0, v1, bop[0][ks], bop[1][ks]);
+            if constexpr (ET == 2) half_swap(v0, v1, bop[0][ks], bop[1][ks]);
+            else bop[0][ks] = ((threadIdx.x & 63) >> 5) ? v1 : v0;   // both lane halves already hold the env's observation
         }
         f32x16 acc2[JT][ET];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             acc2[jt][0] = acc_layout(l_b2, jt);
-            acc2[jt][1] = acc2[jt][0];
+            if constexpr (ET == 2) acc2[jt][1] = acc2[jt][0];
         }
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
@@ -365,13 +367,15 @@ struct ActorMfmaLds {
                 const int qn = (q + 1 < 2 * JT) ? q + 1 : q;
                 const bf16x8 an = *reinterpret_cast<const bf16x8 *>(l_a2 + (((qn % JT) * UT + ut) * 2 + qn / JT) * 1024);
                 acc2[jt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[0][sq], acc2[jt][0], 0, 0, 0);
-                acc2[jt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[1][sq], acc2[jt][1], 0, 0, 0);
+                if constexpr (ET == 2) acc2[jt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[1][sq], acc2[jt][1], 0, 0, 0);
                 a = an;
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // ... then the two MFMAs of the fragment before it
+                __builtin_amdgcn_sched_group_barrier(0x008, ET, 0);  // ... then the MFMAs of the fragment before it
             }
         }
-        float part[ET] = {0.0f, 0.0f};
+        float part[ET];
+#pragma unroll
+        for (int et = 0; et < ET; ++et) part[et] = 0.0f;
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             const f32x16 w3 = acc_layout(l_w3, jt);
@@ -391,7 +395,7 @@ struct ActorMfmaLds {
             }
         }
         float s_lo, s_hi;
-        half_swap(part[0], part[1], s_lo, s_hi);
+        half_swap(part[0], part[ET - 1], s_lo, s_hi);
         return tanh_fast(s_lo + s_hi + b3);
     }
 };

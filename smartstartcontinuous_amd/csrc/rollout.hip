@@ -14,6 +14,9 @@
 // wave-aggregated atomic cursor; chunk statistics are reduced wave -> block -> one f64
 // atomic per block.
 #include "actor_device.h"
+#ifndef SSC_WIDE_ACTOR_ET
+#define SSC_WIDE_ACTOR_ET 2   // env tiles per wave of the LDS-staged wide actor (1: two waves per SIMD at 65 536 envs)
+#endif
 #include "mpc_device.h"
 #include "ssc_device.h"
 #include "ssc_host.h"
@@ -568,7 +571,7 @@ static int dispatch_policy(const typename EnvT::Const &ec, const ssc_policy_desc
             return launch_rollout<EnvT, ActorPolicy<ActorMfma<OBS, 4, 2, 2>, OBS>>(ec, pa, ra, stream);
         // the wide shapes of the reference's grid (200-100): W2 fragments staged in LDS (ActorMfmaLds)
         if (a.h1 <= 224 && a.h2 <= 128)
-            return launch_rollout<EnvT, ActorPolicy<ActorMfmaLds<OBS, 7, 4>, OBS>>(ec, pa, ra, stream);
+            return launch_rollout<EnvT, ActorPolicy<ActorMfmaLds<OBS, 7, 4, SSC_WIDE_ACTOR_ET>, OBS>>(ec, pa, ra, stream);
         return set_error(SSC_EUNSUPPORTED, "ssc_rollout: MFMA actor supports h1 <= 224, h2 <= 128 (got %d-%d)",
                          a.h1, a.h2);
     }
