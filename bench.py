@@ -97,7 +97,9 @@ def bench_config3(args, torch, emit=True):
 
     from smartstartcontinuous_amd import ActorPolicy, TransitionChunk, VecEnv
     from smartstartcontinuous_amd.agents import init_actor_weights
-    n, K = args.envs_per_gpu, 256
+    # the env stream of SURVEY.md section 8(d) config 2 ("same env stream"): K = --chunk env-steps per launch (1024).  Rounds 1-2 used
+    # 256-step launches here; every launch boundary costs ~20 us of stream time, which is 9 % of a 256-step launch of this kernel
+    n, K = args.envs_per_gpu, args.chunk
     w = init_actor_weights(2, 64, 32, 1, torch.Generator().manual_seed(1234))
     env = VecEnv("MountainCarContinuous-v0", n, seed=1234)
     env.reset()

@@ -335,14 +335,16 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
 
 def rl_train_vec_smartstart(env, smart, num_chunks, chunk_steps=64, replay_capacity=1 << 20, train_iters=None,
                             replay_last_steps=None, seed=0, ring_capacity=1 << 20, refresh_every=1, graph=True,
-                            on_chunk=None):
+                            on_chunk=None, aggregate_every=0, aggregate_kwargs=None):
     """The vectorised SmartStart loop: rlTrain (rlTrain.py:63-114) with ``SmartStartContinuous(DDPG_Baselines_agent)``
     (smartexplorationcontinuous.py:307-376) for all envs of ``env`` at once, everything in HBM.  Per chunk:
     smart-start selection on the device replay ring -> plans on offer (``smart.refresh_plans``, every ``refresh_every``
     chunks), ``chunk_steps`` steps of every env in its own mode (``smart.rollout``), the chunk appended to the ring
     (episode index kept on the device), ``train_iters`` DDPG iterations, and the finished episodes read back for the
     epsilon / eta decay (once per episode per env, like DDPG_Baselines_agent.end_episode :255-258 and
-    SmartStartContinuous.end_episode :372-376).  ``smart``: :class:`smartstart.VecSmartStart`.
+    SmartStartContinuous.end_episode :372-376).  ``aggregate_every`` > 0 retrains the navigator's dynamics model on the
+    ring every that many chunks (``smart.train_dynamics_model``: the reference does it every
+    ``num_episodes_for_aggregation`` planned episodes, NND_MB_agent.py:420-423).  ``smart``: :class:`smartstart.VecSmartStart`.
     Returns (Summary, losses per chunk, replay)."""
     import torch
     from .replay_buffer import DeviceReplayBuffer
@@ -355,6 +357,8 @@ def rl_train_vec_smartstart(env, smart, num_chunks, chunk_steps=64, replay_capac
                                 n_envs=env.n, max_path_len=(env.spec.max_episode_steps or 1000) + 1)
     losses, generations = [], 0.0
     for c in range(num_chunks):
+        if aggregate_every and c > 0 and c % aggregate_every == 0:
+            smart.train_dynamics_model(replay, **(aggregate_kwargs or {}))
         if c % refresh_every == 0:
             smart.refresh_plans(replay)
         out = smart.rollout(chunk_steps, chunk, ring=ring, graph=graph)

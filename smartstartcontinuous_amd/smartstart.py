@@ -407,6 +407,43 @@ class VecSmartStart:
         env.t += K
         return out
 
+    # ------------------------------------------------------------- dynamics-model aggregation --
+    def train_dynamics_model(self, replay, max_rows=65536, n_epoch=1, batchsize=512, lr=0.001, noise_to_signal=0.0):
+        """NND_MB_agent.train_dynamics_model (NND_MB_agent.py:437-480) for the vectorised loop: the navigator's model is
+        retrained on transitions the envs themselves produced -- an evenly strided sample of up to ``max_rows`` records of
+        the device replay ring as (s, a, s2 - s) rows (:442-449), optionally with ``add_noise`` (:451-453), z-scored with
+        the model's EXISTING statistics (:455-461) -- ``n_epoch`` passes of Adam steps on the device
+        (``DynamicsModel.train_steps``).  Nothing leaves HBM; the packed MFMA weight image is refreshed in place before
+        the next rollout, so the captured step graph keeps reading the right bytes.  Returns the mean loss of the last
+        epoch (a device -> host read) or None when the ring is still smaller than one batch."""
+        from .collect_samples import TrainingSet, add_noise_device
+        size = len(replay)
+        if size < batchsize:
+            return None
+        stride = max(1, -(-size // int(max_rows)))
+        sel = torch.arange(0, size, stride, device=replay.s.device)
+        s, a, s2 = replay.s[sel].contiguous(), replay.a[sel].contiguous(), replay.s2[sel].contiguous()
+        dz = (s2 - s).contiguous()
+        if noise_to_signal:
+            self._agg_calls = getattr(self, "_agg_calls", 0) + 1
+            add_noise_device(s, noise_to_signal, self.nav.seed, 2 * self._agg_calls)
+            add_noise_device(dz, noise_to_signal, self.nav.seed, 2 * self._agg_calls + 1)
+        nm, m = self.model.norm, self.model
+        norm = {k: [getattr(nm, k)[i] for i in range(n)] for k, n in (("mean_x", m.state_dim), ("std_x", m.state_dim),
+                                                                       ("mean_y", m.act_dim), ("std_y", m.act_dim),
+                                                                       ("mean_z", m.state_dim), ("std_z", m.state_dim))}
+        X, Z = TrainingSet(s, a, dz, None, None).normalised(norm)
+        rows = X.shape[0]
+        n_batches = rows // batchsize
+        gen = torch.Generator(device=X.device)
+        gen.manual_seed(int(self.nav.seed) + 7919 * getattr(self, "_trainings", 0))
+        losses = None
+        for _ in range(int(n_epoch)):
+            perm = torch.randperm(rows, generator=gen, device=X.device)[: n_batches * batchsize]
+            losses = self.model.train_steps(X, Z, perm.view(n_batches, batchsize).to(torch.int32), lr=lr)
+        self._trainings = getattr(self, "_trainings", 0) + 1
+        return None if losses is None else float(losses.mean().item())
+
     def end_of_generation(self):
         """SmartStartContinuous.end_episode (:372-376) once per episode PER ENV: eta decays."""
         self.eta *= self.eta_decay_factor

@@ -200,3 +200,35 @@ def test_rl_train_vec_smartstart_end_to_end(ssc):
     L = int(smart.pool.wp_len[first])
     pts = wp[first, :L].cpu().numpy()
     assert count >= 1 and L >= 2 and pts[:, 0].min() >= -1.2001 and pts[:, 0].max() <= 0.6001 and np.abs(pts[:, 1]).max() <= 0.0701
+
+
+def test_vec_smartstart_dynamics_model_aggregation(ssc):
+    """train_dynamics_model on the device ring (NND_MB_agent.py:437-480 vectorised): a model with random weights, retrained on
+    transitions the envs produced, predicts those transitions far better than before; the MFMA weight image follows; the
+    loop's ``aggregate_every`` hook runs it."""
+    from smartstartcontinuous_amd import navigator as nav
+    from smartstartcontinuous_amd.agents import NND_MB_agent
+    n, K = 512, 32
+    env, agent, w, (Ws, bs, _), smart = _setup(ssc, n, 60, 0.5, 6, N=16, H=3, chunk=K, n_plans=2, log_modes=False)
+    # statistics of real MountainCar transitions, random-policy data
+    denv = ssc.VecEnv("MountainCarContinuous-v0", 64, seed=3)
+    ch = denv.rollout(200, ssc.RandomPolicy())
+    ts = ssc.dataset_from_chunk(ch)
+    from smartstartcontinuous_amd import collect_samples as cs
+    (mx, sx), (my, sy), (mz, sz) = (cs.column_stats(v) for v in (ts.dataX, ts.dataY, ts.dataZ))
+    host = lambda t: t.cpu().numpy()
+    smart.model.set_norm(dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz)))
+    smart.model.precision = "bf16_mfma"
+    X, Z = ts.normalised(dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz)))
+    mse = lambda: float(((smart.model.forward(X, precision="f32") - Z) ** 2).mean().item())
+    before = mse()
+    summary, losses, replay = ssc.rl_train_vec_smartstart(env, smart, 6, chunk_steps=K, replay_capacity=1 << 16, train_iters=1,
+                                                          aggregate_every=2, aggregate_kwargs=dict(n_epoch=6, batchsize=256))
+    torch.cuda.synchronize()
+    assert getattr(smart, "_trainings", 0) == 2
+    after = mse()
+    assert after < 0.25 * before and np.isfinite(after), (before, after)
+    # the fused kernel reads the retrained weights (image refreshed in place)
+    y32 = smart.model.forward(X[:512], precision="f32")
+    y16 = smart.model.forward(X[:512], precision="bf16_mfma")
+    assert float((y32 - y16).abs().max()) < 5e-2 * max(1.0, float(y32.abs().max()))
