@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSC_VERSION 101 /* 0.1.1: plan pool in ssc_mpc_problems, ssc_smartstart_rollout_step */
+#define SSC_VERSION 102 /* 0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step */
 
 typedef void *ssc_stream_t; /* hipStream_t */
 
@@ -258,6 +258,9 @@ typedef struct ssc_mpc_problems {
      * rows wp_off[q] .. wp_off[q] + wp_len[q] - 1 of wp / left and its radii row q of radii; cur_idx stays per problem. */
     const int32_t *plan_of; /* device [P] or NULL */
     const int32_t *wp_len;  /* device [number of plans] or NULL (required with plan_of) */
+    /* Optional: device [P] bytes; a problem whose byte is 0 is not scored by the one-launch scorer (n_samples <= 64): its
+     * scores / best_idx entries are left untouched.  NULL: every problem is scored. */
+    const uint8_t *active;
 } ssc_mpc_problems;
 
 /* all_samples = npr.uniform(low, high, (N, H, act)) (NND_MB_agent.py:500-501) for P problems:
@@ -276,6 +279,10 @@ typedef struct ssc_mpc_sampling {
     float low[SSC_MAX_ACT], high[SSC_MAX_ACT];
     uint64_t seed, problem_id0, t;
     const uint64_t *d_t_base;                /* device step counter added to t (HIP-graph replay); may be NULL */
+    /* Optional: device [number of problems] bytes; the rows of a problem whose byte is 0 need not be simulated (their part of
+     * d_S / d_A_out is then left untouched).  The kernels with LDS-resident weights (depth <= 128, or one hidden layer) skip
+     * a wave whose rows all belong to such problems; the streamed-W2 kernel ignores the mask.  NULL: every problem is live. */
+    const uint8_t *d_problem_active;
 } ssc_mpc_sampling;
 
 /* ssc_mpc_sample_actions + ssc_dyn_forward_sim in ONE launch (Dyn_Model.do_forward_sim fed by get_best_sim_actions,

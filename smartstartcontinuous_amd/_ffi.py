@@ -89,7 +89,7 @@ class MpcProblems(Structure):
                 ("wp", c_void_p), ("left", c_void_p), ("wp_off", c_void_p), ("cur_idx", c_void_p),
                 ("radii", c_void_p), ("theta", c_float), ("gamma", c_float),
                 ("horizontal_penalty_factor", c_float), ("per_row_projection", c_int32),
-                ("plan_of", c_void_p), ("wp_len", c_void_p)]
+                ("plan_of", c_void_p), ("wp_len", c_void_p), ("active", c_void_p)]
 
 
 class SmartStartStep(Structure):
@@ -100,7 +100,8 @@ class SmartStartStep(Structure):
 
 class MpcSampling(Structure):
     _fields_ = [("n_samples", c_int32), ("low", c_float * SSC_MAX_ACT), ("high", c_float * SSC_MAX_ACT),
-                ("seed", c_uint64), ("problem_id0", c_uint64), ("t", c_uint64), ("d_t_base", c_void_p)]
+                ("seed", c_uint64), ("problem_id0", c_uint64), ("t", c_uint64), ("d_t_base", c_void_p),
+                ("d_problem_active", c_void_p)]
 
 
 class CriticDesc(Structure):

@@ -245,6 +245,7 @@ struct DynSimArgs {
     const uint64_t *t_base;
     float low[SSC_MAX_ACT], span[SSC_MAX_ACT];
     float *A_out;
+    const uint8_t *active;   // sampling mode: problems (row / N) whose byte is 0 need not be simulated; may be NULL
 };
 
 // np.nan_to_num((x - mean) / std) (dynamics_model.py:228-229) with inv = 1/std: 0/0 = 0 * inf = NaN -> 0;
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             }
         }
     };
+    bool skip_tile = false;
     auto setup_rows = [&](int64_t tile) __attribute__((always_inline)) {   // (a call would put the row state in scratch memory)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -438,7 +440,14 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             for (int ai = 0; ai < AMAX; ++ai) act[nt][ai] = 0.0f;
         }
         wc = -1;
-        if (!fwd_mode && g.H > 0) fetch_actions(0);
+        // a wave none of whose rows belongs to a live problem (ssc_mpc_sampling.d_problem_active: e.g. the envs of the
+        // vectorised SmartStart loop that are not navigating) skips the tile -- only where no ring barrier needs it
+        skip_tile = false;
+        if (!STREAM && sample && g.active != nullptr) {
+            const bool mine = (valid[0] && g.active[rowc[0] / g.N] != 0) || (valid[1] && g.active[rowc[1] / g.N] != 0);
+            skip_tile = __builtin_amdgcn_ballot_w64(mine) == 0;
+        }
+        if (!fwd_mode && g.H > 0 && !skip_tile) fetch_actions(0);
     };
     int64_t tile = blockIdx.x;
     setup_rows(tile);
@@ -488,6 +497,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     uint64_t ph[6] = {0, 0, 0, 0, 0, 0};  // diagnostic: cycles in input code / layer 1 / hidden tiles / step tail / phase barrier / tile barriers
 #define SSC_STAMP(var) uint64_t var = 0; if (SSC_DYN_ABLATE & 16) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     for (;;) {   // row tiles of this block (one pass when W2 is streamed)
+    if (!skip_tile) {
     for (int t = 0; t < g.H; ++t) {
         SSC_STAMP(stamp_a)
         // ---- inputs: record S[t]; layer-1 B fragments of x = normalised (state, action) ---------------
@@ -812,6 +822,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                     if (k < g.d) g.S[((int64_t)g.H * g.m + row[nt]) * g.d + k] = st[nt][k];  // :240
             }
     }
+    }
     if (STREAM) break;
     tile += gridDim.x;
     if (tile * kDynRows >= g.m) break;
@@ -958,6 +969,7 @@ int dyn_mfma_forward_sim_sampled(const ssc_mlp_desc *mlp, const ssc_norm *norm, 
         g.span[a] = a < act_dim ? sp->high[a] - sp->low[a] : 0.0f;
     }
     g.A_out = d_A_out;
+    g.active = sp->d_problem_active;
     return run_mfma(mlp, g, ws, s);
 }
 

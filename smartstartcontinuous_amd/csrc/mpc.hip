@@ -392,18 +392,22 @@ __device__ __forceinline__ void mpc_small_body(MpcArgs a, const SelectArgs &sel,
     const int pq = blockIdx.x * kGroups + g;
     const bool has = pq < a.P;
     const int p = has ? pq : a.P - 1;            // a group past the last problem shadows it and writes nothing
-    const bool live = has && n < a.N;
+    // a problem masked out by a.active (an env that is not navigating) costs its group three barriers and nothing else
+    const bool scored = a.active == nullptr || a.active[p] != 0;    // group-uniform
+    const bool live = has && n < a.N && scored;
     const int64_t row = (int64_t)p * a.N + (n < a.N ? n : 0), M = (int64_t)a.P * a.N;
     PrePts pp;
-    if (mpc_can_prefetch(a)) mpc_fetch_pts(a, S, row, M, live, pp);
-    int W, idx0;
-    load_window(a, p, n, G, win[g], W, idx0);
+    if (scored && mpc_can_prefetch(a)) mpc_fetch_pts(a, S, row, M, live, pp);
+    int W = 2, idx0 = 0;
+    if (scored) load_window(a, p, n, G, win[g], W, idx0);
     __syncthreads();
     const float *wps = win[g], *lefts = win[g] + kWinMax * a.d, *inv_r = lefts + kWinMax;
-    mpc_walk_any<0, G>(a, pp, S, row, M, wps, lefts, W, idx0, inv_r, live, sums[g], nullptr);
+    if (scored) mpc_walk_any<0, G>(a, pp, S, row, M, wps, lefts, W, idx0, inv_r, live, sums[g], nullptr);
     __syncthreads();
-    for (int t = n; t <= a.H; t += G) cproj[g][t] = (float)(sums[g][t * 2 + 0] / sums[g][t * 2 + 1]);
+    if (scored)
+        for (int t = n; t <= a.H; t += G) cproj[g][t] = (float)(sums[g][t * 2 + 0] / sums[g][t * 2 + 1]);
     __syncthreads();
+    if (!scored) return;     // no barrier below
     float score = -INFINITY;
     int best = 0x7fffffff;
     if (n < a.N) {   // (a shadow group walks too: uniform control flow, no store)
@@ -553,7 +557,7 @@ static int mpc_score_common(const char *who, const ssc_mpc_problems *pr, const f
     hipStream_t s = as_stream(stream);
     MpcArgs a;
     a.P = pr->n_problems; a.N = pr->n_samples; a.H = pr->horizon; a.d = pr->state_dim;
-    a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx; a.plan_of = pr->plan_of; a.wp_len = pr->wp_len;
+    a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx; a.plan_of = pr->plan_of; a.wp_len = pr->wp_len; a.active = pr->active;
     a.theta = pr->theta; a.gamma = pr->gamma; a.hpf = pr->horizontal_penalty_factor;
     a.per_row = pr->per_row_projection;
     a.nblk = (a.N + kMpcBlock - 1) / kMpcBlock;
@@ -632,7 +636,7 @@ int ssc_mpc_observe(const ssc_mpc_problems *pr, const float *d_new_state, int32_
                 "ssc_mpc_observe: NULL device pointer");
     MpcArgs a{};
     a.P = pr->n_problems; a.d = pr->state_dim;
-    a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx; a.plan_of = pr->plan_of; a.wp_len = pr->wp_len;
+    a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx; a.plan_of = pr->plan_of; a.wp_len = pr->wp_len; a.active = pr->active;
     a.theta = pr->theta;
     hipLaunchKernelGGL(mpc_observe_kernel, dim3((a.P + 63) / 64), dim3(64), 0, as_stream(stream), a, d_new_state,
                        d_cur_idx, d_actions_done, give_up_after, final_steps, d_at_goal);

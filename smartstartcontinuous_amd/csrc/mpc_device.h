@@ -10,6 +10,7 @@ struct MpcArgs {
     const float *wp, *left, *radii;
     const int32_t *wp_off, *cur_idx;
     const int32_t *plan_of, *wp_len;   // optional plan pool (ssc_mpc_problems): problem p follows plan plan_of[p]
+    const uint8_t *active;             // optional: problems whose byte is 0 are not scored (one-launch scorer)
     float theta, gamma, hpf;
     int32_t per_row;
     int32_t nblk;  // blocks per problem

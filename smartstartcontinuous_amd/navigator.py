@@ -282,8 +282,9 @@ class DynamicsModel:
         return S
 
 
-def mpc_sampling(N, low, high, seed, problem_id0=0, t=0, t_base=None):
-    """``ssc_mpc_sampling``: the candidate action sequences of an MPC step as a specification (NND_MB_agent.py:500-501)."""
+def mpc_sampling(N, low, high, seed, problem_id0=0, t=0, t_base=None, active=None):
+    """``ssc_mpc_sampling``: the candidate action sequences of an MPC step as a specification (NND_MB_agent.py:500-501).
+    ``active``: optional uint8 device tensor, one byte per problem -- rows of problems marked 0 need not be simulated."""
     sp = _ffi.MpcSampling()
     low = np.asarray(low, np.float32).reshape(-1)
     high = np.asarray(high, np.float32).reshape(-1)
@@ -292,7 +293,8 @@ def mpc_sampling(N, low, high, seed, problem_id0=0, t=0, t_base=None):
         sp.low[i], sp.high[i] = float(low[i]), float(high[i])
     sp.seed, sp.problem_id0, sp.t = int(seed), int(problem_id0), int(t)
     sp.d_t_base = None if t_base is None else t_base.data_ptr()
-    sp._keep = t_base
+    sp.d_problem_active = None if active is None else active.data_ptr()
+    sp._keep = (t_base, active)
     return sp
 
 
@@ -378,6 +380,7 @@ class PlanPool:
         self.per_row = bool(per_row_projection)
         self._next = 0
         self.published = 0
+        self.active = None      # optional uint8 [n_envs]: only problems marked non-zero are simulated / scored
 
     def publish(self, plans):
         """``plans``: list of (waypoints [W, d], distances_left [W], radii [d]) -- the per-episode quantities of
@@ -413,6 +416,7 @@ class PlanPool:
         s.theta, s.gamma, s.horizontal_penalty_factor = self.theta, self.gamma, self.hpf
         s.per_row_projection = int(self.per_row)
         s.plan_of, s.wp_len = self.plan_of.data_ptr(), self.wp_len.data_ptr()
+        s.active = None if self.active is None else self.active.data_ptr()
         return s
 
 

@@ -245,6 +245,7 @@ class VecSmartStart:
                                       final_steps=final_steps, seed=seed, problem_id0=env.env_id0)
         self.nav.start_idx.zero_()
         self.mode = torch.zeros(env.n, dtype=torch.uint8, device=dev)
+        self.pool.active = self.mode     # the MPC launches skip the envs that are not navigating (where the kernels can)
         self.actor_out = torch.zeros((env.n, 1), dtype=torch.float32, device=dev)
         self.d_eta = torch.tensor([self.eta], dtype=torch.float32, device=dev)
         self.d_eps = torch.tensor([0.0], dtype=torch.float32, device=dev)
@@ -332,7 +333,7 @@ class VecSmartStart:
         with torch.cuda.device(env.device):
             _ffi.check(lib.ssc_actor_forward(ctypes.byref(self.agent._desc), env.n, _ffi.ptr(fb["plan"]),
                                              _ffi.ptr(self.actor_out), _stream()))
-        sp = nav.mpc_sampling(b.N, b.low, b.high, b.seed, b.problem_id0, 0, t_base=fb["t"])
+        sp = nav.mpc_sampling(b.N, b.low, b.high, b.seed, b.problem_id0, 0, t_base=fb["t"], active=self.mode)
         S = self.model.do_forward_sim_sampled(fb["plan"], sp, b.P * b.N, b.H, out=b._S, A_out=fb["A"])
         st = self.pool.as_struct(b.N, b.H)
         navs = _ffi.MpcNavState(self.pool.cur_idx.data_ptr(), b.start_idx.data_ptr(), b.actions_done.data_ptr(),
