@@ -375,7 +375,7 @@ def bench_smartstart_vec(args, torch, emit=True, P=N_ENVS_PER_GPU, N=16, H=4, K=
     host = lambda t: t.cpu().numpy()
     norm = dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz))
     Ws, bs = init_dynamics_weights(d + a, d, 1, 32, torch.Generator().manual_seed(1234))
-    model = nav.DynamicsModel(Ws, bs, norm, d, a, precision="bf16_mfma")
+    model = nav.DynamicsModel(Ws, bs, norm, d, a, precision="f32")      # one small hidden layer: the fused fp32 kernel (one launch)
     env = VecEnv("MountainCarContinuous-v0", P, seed=1234, max_episode_steps=300)
     env.reset()
     agent = DDPG_Baselines_agent(make("MountainCarContinuous-v0"), None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32,
@@ -402,7 +402,7 @@ def bench_smartstart_vec(args, torch, emit=True, P=N_ENVS_PER_GPU, N=16, H=4, K=
     res = {"metric": "env-steps/sec, vectorised SmartStart step (per-env navigate / explore mode), 65 536 MountainCar envs",
            "value": P / (ms_step * 1e-3), "unit": "env-steps/s", "n_gpus": 1, "steps": reps * K, "ms_per_step": ms_step,
            "gpu_ms_per_step": e0.elapsed_time(e1) / (reps * K), "navigated_fraction_last_chunk": nav_frac,
-           "higher_is_better": True, "dtype": "bf16 (MFMA), fp32 accumulate", "data": "synthetic",
+           "higher_is_better": True, "dtype": "f32 (navigator, fused VALU kernel), bf16 MFMA (actor)", "data": "synthetic",
            "config": {"workload": "MountainCarContinuous-v0, %d envs, eta 0.5, 8 plans on offer (recorded 150-state paths), NND_MB 1x32 x %d "
                                   "candidates x horizon %d, DDPG actor 64-32 + OU noise; 5 launches per env-step from a HIP graph; the "
                                   "per-chunk smart-start selection is not part of this figure" % (P, N, H)}}

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--train-iters", type=int, default=10)
     ap.add_argument("--refresh-every", type=int, default=1, help="chunks between smart-start selections (vec mode)")
+    ap.add_argument("--nav-precision", choices=("f32", "bf16_mfma"), default="f32", help="forward-simulation path of the navigator (vec mode; f32 = the fused VALU kernel for one small hidden layer)")
     ap.add_argument("--kde-max-states", type=int, default=None, help="bound the KDE's data set by a strided subsample of the ring (vec mode; default: every state, like the reference)")
     ap.add_argument("--replay-capacity", type=int, default=None, help="records in the device ring (default: two full episodes per env)")
     args = ap.parse_args()
@@ -82,7 +83,7 @@ def vec(args, dyn_model):
                                 ou_epsilon=1.0, ou_min_epsilon=0.01, ou_epsilon_decay_factor=.99, ou_mu=0.4, ou_sigma=0.6,
                                 ou_theta=.15, actor_lr=0.001, actor_h1=64, actor_h2=32, critic_lr=0.001, critic_h1=64,
                                 critic_h2=32, lastLayerTanh=True, seed=args.seed, precision="bf16_mfma")
-    dyn_model.precision = "bf16_mfma"     # the fused forward-simulation kernel (the scalar example runs the fp32 parity path)
+    dyn_model.precision = args.nav_precision     # fused kernels both: bf16 MFMA (any size) or fp32 VALU (one small hidden layer)
     dyn_model.invalidate()
     smart = ssc.VecSmartStart(env, ddpg, dyn_model, eta=0.5, eta_decay_factor=1., n_ss=2000, n_plans=args.plans,
                               num_control_samples=args.samples, horizon=4, final_steps=10, chunk_steps=args.chunk_steps,

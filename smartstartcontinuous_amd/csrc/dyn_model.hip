@@ -121,6 +121,137 @@ __global__ __launch_bounds__(256) void dyn_update_kernel(int64_t m, int d, ssc_n
     Sn[e] = St[e] + (z[e] * nm.std_z[k] + nm.mean_z[k]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused fp32 forward simulation for the SMALL networks the reference ships (one hidden layer, depth <= 128, <= 4 inputs
+// and outputs: the navigator's 1 x 32): ONE launch for all H steps instead of four launches per step (prepare, two
+// layers, update) plus the action-sampling launch.  One row per lane, the state in registers for the whole horizon;
+// the weights sit in LDS as one 8-float record per hidden unit {W1[0..3][j], b1[j], W2[j][0..2]} read as two broadcast
+// ds_read_b128 (every lane reads the same address: conflict-free); per hidden unit <= 4 FMAs in, ReLU, <= 3 FMAs out.
+// Arithmetic = the multi-launch path's: z-score by division (normalise_one), k-ordered fp32 FMA chains per unit,
+// S' = S + (z std + mean).  VALU-bound (~8 ops per row, unit and step).  Candidate actions come from memory or are drawn
+// in the kernel (the Philox stream of ssc_mpc_sample_actions); rows of problems masked out by d_problem_active are
+// skipped per lane.
+// ---------------------------------------------------------------------------------------------------------------
+struct SmallSimArgs {
+    int64_t m, rows_per_state;   // rows sharing one start state
+    int32_t H, d, a, depth;
+    const float *W1, *b1, *W2, *b2;   // [in][depth], [depth], [depth][d], [d]
+    ssc_norm nm;
+    const float *s0, *A;
+    float *S, *A_out;
+    int32_t sample, N;
+    uint64_t seed, pid0, t;
+    const uint64_t *t_base;
+    float low[SSC_MAX_ACT], span[SSC_MAX_ACT];
+    const uint8_t *active;
+};
+
+constexpr int kSmallMaxDepth = 128;
+
+__global__ __launch_bounds__(256) void dyn_small_sim_kernel(SmallSimArgs g) {
+    __shared__ __attribute__((aligned(16))) float rec[kSmallMaxDepth][8];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int in = g.d + g.a;
+    for (int e = threadIdx.x; e < g.depth * 8; e += 256) {
+        const int j = e >> 3, q = e & 7;
+        float v = 0.0f;
+        if (q < 4) v = (q < in) ? g.W1[q * g.depth + j] : 0.0f;
+        else if (q == 4) v = g.b1[j];
+        else v = (q - 5 < g.d) ? g.W2[j * g.d + (q - 5)] : 0.0f;
+        rec[j][q] = v;
+    }
+    __syncthreads();
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = gi < g.m;
+    const int64_t row = valid ? gi : g.m - 1;
+    if (!valid || (g.active != nullptr && g.active[row / g.N] == 0)) return;   // (no barrier below)
+    float st[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k < g.d) st[k] = g.s0[(row / g.rows_per_state) * g.d + k];
+    const uint64_t sid = g.sample ? ((g.pid0 + (uint64_t)(row / g.N)) << 32) + (uint64_t)(row % g.N) : 0;
+    const uint64_t tt = g.sample ? (g.t + (g.t_base != nullptr ? *g.t_base : 0)) * (uint64_t)((g.H * g.a + 3) / 4) : 0;
+    u32x4 wcache = u32x4{0, 0, 0, 0};
+    int wc = -1;
+    for (int t = 0; t < g.H; ++t) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < g.d) g.S[((int64_t)t * g.m + row) * g.d + k] = st[k];          // dynamics_model.py:225
+        float x[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < g.d) x[k] = normalise_one(st[k], g.nm.mean_x[k], g.nm.std_x[k]);
+#pragma unroll
+        for (int ai = 0; ai < 3; ++ai)
+            if (ai < g.a) {
+                float av;
+                if (g.sample) {
+                    const int f = t * g.a + ai, c4 = f >> 2;
+                    if (c4 != wc) {
+                        wc = c4;
+                        wcache = rng_words(g.seed, sid, tt + (uint64_t)c4, TAG_MPC);
+                    }
+                    av = uniform_f32(pick(wcache, (uint32_t)(f & 3)), g.low[ai], g.span[ai]);
+                    if (g.A_out != nullptr) g.A_out[(row * g.H + t) * g.a + ai] = av;
+                } else {
+                    av = g.A[(row * g.H + t) * g.a + ai];
+                }
+                const float xa = normalise_one(av, g.nm.mean_y[ai], g.nm.std_y[ai]);
+                // input g.d + ai (g.d + g.a <= 4)
+                if (g.d + ai == 1) x[1] = xa; else if (g.d + ai == 2) x[2] = xa; else if (g.d + ai == 3) x[3] = xa;
+            }
+        float z[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < g.d) z[k] = g.b2[k];
+#pragma unroll 4
+        for (int j = 0; j < g.depth; ++j) {
+            const f4 w = *reinterpret_cast<const f4 *>(&rec[j][0]);
+            const f4 u = *reinterpret_cast<const f4 *>(&rec[j][4]);
+            float h = u[0];
+            h = fmaf(x[0], w[0], h);
+            h = fmaf(x[1], w[1], h);
+            h = fmaf(x[2], w[2], h);
+            h = fmaf(x[3], w[3], h);
+            h = fmaxf(h, 0.0f);                                                      // feedforward_network.py:19
+            z[0] = fmaf(h, u[1], z[0]);
+            z[1] = fmaf(h, u[2], z[1]);
+            z[2] = fmaf(h, u[3], z[2]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < g.d) st[k] = st[k] + (z[k] * g.nm.std_z[k] + g.nm.mean_z[k]);    // :234-237
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k < g.d) g.S[((int64_t)g.H * g.m + row) * g.d + k] = st[k];              // :240
+}
+
+// the shapes the fused fp32 kernel takes
+static bool small_sim_shape(const ssc_mlp_desc *mlp, int state_dim, int act_dim) {
+    return mlp->n_layers == 2 && mlp->dims[1] <= kSmallMaxDepth && state_dim <= 3 && state_dim + act_dim <= 4 && act_dim <= 3;
+}
+
+static int launch_small_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, const ssc_mpc_sampling *sp, int64_t m, int32_t H,
+                            int state_dim, int act_dim, const float *d_s0, int64_t s0_rows, const float *d_A, float *d_A_out,
+                            float *d_S, hipStream_t s) {
+    SmallSimArgs g{};
+    g.m = m; g.rows_per_state = m / s0_rows; g.H = H; g.d = state_dim; g.a = act_dim; g.depth = mlp->dims[1];
+    g.W1 = mlp->W[0]; g.b1 = mlp->b[0]; g.W2 = mlp->W[1]; g.b2 = mlp->b[1];
+    g.nm = *norm; g.s0 = d_s0; g.A = d_A; g.S = d_S; g.A_out = d_A_out;
+    g.N = 1;
+    if (sp != nullptr) {
+        g.sample = 1; g.N = sp->n_samples; g.seed = sp->seed; g.pid0 = sp->problem_id0; g.t = sp->t; g.t_base = sp->d_t_base;
+        for (int a = 0; a < SSC_MAX_ACT; ++a) {
+            g.low[a] = a < act_dim ? sp->low[a] : 0.0f;
+            g.span[a] = a < act_dim ? sp->high[a] - sp->low[a] : 0.0f;
+        }
+        g.active = sp->d_problem_active;
+    }
+    hipLaunchKernelGGL(dyn_small_sim_kernel, dim3(blocks_for(m)), dim3(256), 0, s, g);
+    return check_launch("dyn_small_sim_kernel");
+}
+
 int validate_mlp(const ssc_mlp_desc *mlp, const char *who) {
     if (mlp == nullptr) return set_error(SSC_EINVAL, "%s: mlp NULL", who);
     if (mlp->n_layers < 1 || mlp->n_layers > SSC_MAX_LAYERS)
@@ -260,6 +391,8 @@ int ssc_dyn_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, int64_t m
                                     precision == SSC_PREC_BF16_MFMA_PREPARED, s);
     }
     SSC_REQUIRE(precision == SSC_PREC_F32, "ssc_dyn_forward_sim: unknown precision %d", precision);
+    if (H >= 1 && small_sim_shape(mlp, state_dim, act_dim))    // the shipped navigator shape: one fused launch
+        return launch_small_sim(mlp, norm, nullptr, m, H, state_dim, act_dim, d_s0, s0_rows, d_A, nullptr, d_S, s);
     char *w = static_cast<char *>(d_workspace);
     float *x = reinterpret_cast<float *>(w);
     w += align256((size_t)m * mlp->dims[0] * 4);
@@ -311,7 +444,10 @@ int ssc_mpc_forward_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, const ssc
         return dyn_mfma_forward_sim_sampled(mlp, norm, sp, m, H, state_dim, act_dim, d_s0, s0_rows, d_A_out, d_S,
                                             d_workspace, precision == SSC_PREC_BF16_MFMA_PREPARED, as_stream(stream));
     }
-    // fp32: the two-launch equivalent
+    SSC_REQUIRE(precision == SSC_PREC_F32, "ssc_mpc_forward_sim: unknown precision %d", precision);
+    if (small_sim_shape(mlp, state_dim, act_dim))    // one fused launch, candidates drawn in the kernel (d_A_out optional)
+        return launch_small_sim(mlp, norm, sp, m, H, state_dim, act_dim, d_s0, s0_rows, nullptr, d_A_out, d_S, as_stream(stream));
+    // other fp32 shapes: the two-launch equivalent
     SSC_REQUIRE(d_A_out != nullptr, "ssc_mpc_forward_sim: the fp32 path materialises the action matrix: d_A_out NULL");
     if (int rc = ssc_mpc_sample_actions((int32_t)(m / sp->n_samples), sp->n_samples, H, act_dim, sp->low, sp->high, sp->seed,
                                         sp->problem_id0, sp->t, sp->d_t_base, d_A_out, stream))
