@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--train-iters", type=int, default=10)
     ap.add_argument("--refresh-every", type=int, default=1, help="chunks between smart-start selections (vec mode)")
     ap.add_argument("--nav-precision", choices=("f32", "bf16_mfma"), default="f32", help="forward-simulation path of the navigator (vec mode; f32 = the fused VALU kernel for one small hidden layer)")
-    ap.add_argument("--kde-max-states", type=int, default=None, help="bound the KDE's data set by a strided subsample of the ring (vec mode; default: every state, like the reference)")
+    ap.add_argument("--kde-max-states", type=int, default=500000, help="bound the KDE's data set by a strided subsample of the ring (vec mode; default: the reference's replay capacity; 0 = every state)")
     ap.add_argument("--replay-capacity", type=int, default=None, help="records in the device ring (default: two full episodes per env)")
     args = ap.parse_args()
     np.random.seed(args.seed)
@@ -87,7 +87,7 @@ def vec(args, dyn_model):
     dyn_model.invalidate()
     smart = ssc.VecSmartStart(env, ddpg, dyn_model, eta=0.5, eta_decay_factor=1., n_ss=2000, n_plans=args.plans,
                               num_control_samples=args.samples, horizon=4, final_steps=10, chunk_steps=args.chunk_steps,
-                              seed=args.seed, log_modes=True, kde_max_states=args.kde_max_states)
+                              seed=args.seed, log_modes=True, kde_max_states=args.kde_max_states or None)
     nav_steps = []
     cap = args.replay_capacity or 2 * args.envs * args.max_steps     # a smart-start path needs its episode's start in the ring
     kw = dict(chunk_steps=args.chunk_steps, train_iters=args.train_iters, replay_capacity=cap, refresh_every=args.refresh_every)

@@ -222,7 +222,7 @@ class VecSmartStart:
                  noise_amount=0.005, steps_before_giving_up_on_waypoint=5, final_steps=10, theta=1.0, gamma=0.75,
                  horizontal_penalty_factor=0.5, path_shortcutting=True, mean_per_stepsize=1, std_per_stepsize=1,
                  stepsizes_in_waypoint_radii=1, steps_per_waypoint=1, chunk_steps=64, seed=1234, log_modes=False,
-                 kde_max_states=None):
+                 kde_max_states=500000):
         from . import navigator as nav
         self.env, self.agent, self.model = env, agent, dyn_model
         self.eta, self.eta_decay_factor = float(eta), float(eta_decay_factor)
@@ -253,7 +253,8 @@ class VecSmartStart:
         # The reference estimates the visitation density from EVERY state in its buffer (<= 100 000 there, :258-260); a
         # device ring sized for 65 536 envs holds tens of millions, and the n_ss x |D| kernel then is most of a selection.
         # kde_max_states bounds |D| by an evenly strided subsample of the ring (a density estimate does not depend on the
-        # sample count); None = all states, the reference's behaviour.
+        # sample count).  Default 500 000 = the reference's own replay capacity (SmartStartContinuous(buffer_size=500000),
+        # :55), i.e. the most states its KDE can ever see; None = every state in the ring.
         self.kde_max_states = kde_max_states
         self.mode_log = None
         self.last_radii = None
