@@ -820,3 +820,45 @@ def test_mpc_rollout_baseline_config4_one_navigator_per_env(nav):
         if ((dc <= 1 or dn <= dc) and i0 != W - 1) or (da > 2 and i0 != W - 1):
             i0, da = i0 + 1, 0
         assert int(pg.cur_idx[p]) == i0 and int(bg.actions_done[p]) == da, p
+
+
+@pytest.mark.parametrize("prec,dims", [("f32", (3, 32, 2)), ("f32", (4, 100, 3)), ("bf16_mfma", (3, 32, 2)), ("bf16_mfma", (4, 64, 64, 3))])
+def test_forward_sim_skips_masked_problems(nav, prec, dims):
+    """ssc_mpc_sampling.d_problem_active: the rows of live problems come out exactly as without a mask (and as the oracle
+    computes them), the rows of masked problems are left alone wherever the kernel can skip them -- the fused fp32 kernel
+    per row, the resident-weight MFMA kernels per wave (rows of a masked problem that share a wave with a live one are
+    still computed, which is allowed)."""
+    rng = np.random.default_rng(12)
+    d, act = dims[-1], dims[0] - dims[-1]
+    P, N, H = 37, 16, 3
+    Ws, bs = make_mlp(rng, dims)
+    norm = make_norm(rng, d, act)
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=act, precision=prec)
+    s0 = torch.as_tensor((rng.normal(size=(P, d)) * 0.2).astype(np.float32), device="cuda")
+    low, high = [-1.0] * act, [1.0] * act
+    M = P * N
+    full = model.do_forward_sim_sampled(s0, nav.mpc_sampling(N, low, high, 5, 3, 11), M, H,
+                                       A_out=torch.zeros((M, H, act), device="cuda")).clone()
+    active = torch.as_tensor((rng.random(P) < 0.4).astype(np.uint8), device="cuda")
+    active[0] = 1
+    out = torch.full((H + 1, M, d), 123.0, device="cuda")
+    A_out = torch.zeros((M, H, act), device="cuda")
+    got = model.do_forward_sim_sampled(s0, nav.mpc_sampling(N, low, high, 5, 3, 11, active=active), M, H, out=out, A_out=A_out)
+    rows_live = active.bool().repeat_interleave(N)
+    assert torch.equal(got[:, rows_live], full[:, rows_live])
+    dead = got[:, ~rows_live]
+    untouched = (dead == 123.0).all(dim=0).all(dim=-1)
+    if prec == "f32":
+        assert bool(untouched.all())                      # per-row skip
+    else:
+        assert bool(untouched.any())                      # whole waves of masked problems were skipped
+        computed = ~untouched
+        assert torch.equal(dead[:, computed], full[:, ~rows_live][:, computed])
+    # and the live rows are what the oracle computes
+    nm64 = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in norm.items()}
+    p = int(torch.nonzero(active)[1]) if int(active.sum()) > 1 else 0
+    A = O.mpc_action_samples(5, 3 + p, N, H, act, 11, low, high)
+    ref = O.dyn_forward_sim(s0[p].cpu().numpy(), A, nm64, Ws, bs)                   # [H+1, N, d]
+    tol = 1e-4 if prec == "f32" else 3e-2
+    g = got[:, p * N:(p + 1) * N].cpu().numpy()
+    assert np.max(np.abs(g - ref)) <= tol * max(1.0, np.abs(ref).max())
