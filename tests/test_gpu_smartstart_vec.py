@@ -22,19 +22,21 @@ def ssc():
     return pkg
 
 
-def _setup(ssc, n, max_steps, eta, seed, N=96, H=3, give_up=2, log_modes=True, n_plans=3, chunk=16, env_id0=40):
+def _setup(ssc, n, max_steps, eta, seed, N=96, H=3, give_up=2, log_modes=True, n_plans=3, chunk=16, env_id0=40,
+           env_name="MountainCarContinuous-v0"):
     from smartstartcontinuous_amd import navigator as nav
     from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
     rng = np.random.default_rng(seed)
-    env = ssc.VecEnv("MountainCarContinuous-v0", n, seed=seed, max_episode_steps=max_steps, env_id0=env_id0)
+    d = 2 if env_name.startswith("Mountain") else 3
+    env = ssc.VecEnv(env_name, n, seed=seed, max_episode_steps=max_steps, env_id0=env_id0)
     env.reset()
-    agent = DDPG_Baselines_agent(ssc.make("MountainCarContinuous-v0"), None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32,
+    agent = DDPG_Baselines_agent(ssc.make(env_name), None, actor_h1=64, actor_h2=32, critic_h1=64, critic_h2=32,
                                  lastLayerTanh=True, seed=5, training=False, ou_mu=0.4, ou_sigma=0.6, precision="f32")
-    w = actor_weights(2, 64, 32, seed=77, w3_scale=0.5)
+    w = actor_weights(d, 64, 32, seed=77, w3_scale=0.5)
     agent.set_weights({k: torch.as_tensor(v) for k, v in w.items()})
-    Ws, bs = make_mlp(rng, (3, 32, 2))
-    norm = make_norm(rng, 2, 1)
-    model = nav.DynamicsModel(Ws, bs, norm, state_dim=2, act_dim=1, precision="f32")
+    Ws, bs = make_mlp(rng, (d + 1, 32, d))
+    norm = make_norm(rng, d, 1)
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=1, precision="f32")
     smart = ssc.VecSmartStart(env, agent, model, eta=eta, n_plans=n_plans, num_control_samples=N, horizon=H,
                               steps_before_giving_up_on_waypoint=give_up, final_steps=4, chunk_steps=chunk, seed=seed + 1,
                               log_modes=log_modes, w_max=max(max_steps + 1, 16))
@@ -138,23 +140,40 @@ def test_vec_smartstart_every_step_against_the_scalar_logic(ssc, n, K, max_steps
     assert env.stats.cpu().numpy()[2] == n * K and env.t == t0 + K
 
 
-def test_vec_smartstart_graph_replay_equals_step_by_step(ssc):
+def _pend_plans(rng, n):
+    """Plans in Pendulum observation space (cos, sin, theta-dot): short arcs near the upright position."""
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(6, 12))
+        th = np.cumsum(rng.normal(scale=0.15, size=L)) + rng.uniform(-1, 1)
+        thd = np.cumsum(rng.normal(scale=0.3, size=L))
+        path = np.stack([np.cos(th), np.sin(th), thd], 1)
+        stds, means = O.path_deltas_stds_and_means_per_dim(path)
+        r = O.radii_calc(means, stds, 1, 1, 1) + 1e-2
+        out.append((path, O.distances_left(path, O.distance_func(r)), r))
+    return out
+
+
+@pytest.mark.parametrize("env_name", ["MountainCarContinuous-v0", "Pendulum-v1"])
+def test_vec_smartstart_graph_replay_equals_step_by_step(ssc, env_name):
     """The captured five-launch step replayed K times == the same launches enqueued one by one, over two chunks with a
-    pool refresh in between (log, modes, env / navigator / OU state, statistics, episode records)."""
+    pool refresh in between (log, modes, env / navigator / OU state, statistics, episode records), for both envs."""
     res = []
+    pend = env_name.startswith("Pendulum")
+    plans = (lambda rng, k, near: _pend_plans(rng, k)) if pend else (lambda rng, k, near: _plans(rng, k, near_reset=near))
     for graph in (True, False):
         n, K = 300, 12
-        env, agent, w, _, smart = _setup(ssc, n, 9, 0.6, 4, N=32, H=2, chunk=K)
+        env, agent, w, _, smart = _setup(ssc, n, 9, 0.6, 4, N=32, H=2, chunk=K, env_name=env_name)
         rng = np.random.default_rng(1)
-        smart.pool.publish(_plans(rng, 3, near_reset=1))
+        smart.pool.publish(plans(rng, 3, 1))
         ring = ssc.EpisodeRing(8192, "cuda")
-        chunk = ssc.TransitionChunk(2, K, n, env.device)
+        chunk = ssc.TransitionChunk(env.obs_dim, K, n, env.device)
         logs = []
         for c in range(2):
             smart.rollout(K, chunk, ring=ring, graph=graph)
             torch.cuda.synchronize()
             logs.append([getattr(chunk, col).clone() for col in ("obs", "act", "rew", "done", "obs2")] + [smart.mode_log.clone()])
-            smart.pool.publish(_plans(rng, 3, near_reset=0))
+            smart.pool.publish(plans(rng, 3, 0))
         res.append((env, smart, logs, ring))
     (eg, sg, lg, rg), (ee, se, le, re_) = res
     for c in range(2):
