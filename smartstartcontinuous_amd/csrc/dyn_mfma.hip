@@ -55,6 +55,9 @@ constexpr int kMaxKS1 = 2;        // layer-1 k-steps of 32 slots: 2 bias slots +
 #ifndef SSC_DYN_LAG_X1
 #define SSC_DYN_LAG_X1 11
 #endif
+#ifndef SSC_DYN_LAG_G0_DMA
+#define SSC_DYN_LAG_G0_DMA 1   // 0: both wave groups issue (A/B: tools/gpu_c4_ab.sh)
+#endif
 #ifndef SSC_DYN_LAG_PRIO
 #define SSC_DYN_LAG_PRIO 3
 #endif
@@ -304,6 +307,8 @@ __host__ __device__ constexpr int dyn_a2_bufs() { return NFC == 2 ? (UT <= 4 ? U
 //   * group 0 takes the barrier of a step's tile 0 in the MIDDLE OF ITS PHASE instead (where group 1, inside tile 15 of
 //     the step before, arrives at about the same time) and runs tile 0 without one: its phase never makes group 1 wait
 //     for a barrier, and group 1's phase falls into group 0's tiles 0 and 1, which need none from it until X0 of tile 1;
+//   * group 0 alone feeds the ring (it is the group that WAITS at the tile barriers -- the oldest wave wins the issue
+//     arbitration and runs ahead -- so the LDS-DMA issue cost comes out of its slack instead of the critical group's time);
 //   * every wave takes 16 H + 1 barriers: group 0 one per phase + tiles 1..15 + one behind its last tile, group 1 one in
 //     its first phase + one in every tile.
 // MODE (compile-time when >= 0): 0 simulation with the actions read from memory, 1 simulation drawing its candidate
@@ -323,6 +328,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     constexpr int NBUF = LAG ? 4 : dyn_a2_bufs<UT, NFC>();
     constexpr bool STREAM = (NFC == 2) && (UT > 4);
     constexpr bool CMP = (KIN == 4);                            // compact lane-group layer 1 (l1_compact)
+    constexpr bool G0DMA = LAG && (SSC_DYN_LAG_G0_DMA != 0);    // LAG: wave group 0 issues every LDS-DMA piece
     constexpr int A1_BYTES = CMP ? MT * 512 : KS1 * MT * 1024;   // layer-1 fragments: 8 B per lane when compact
     constexpr int A2_CHUNKS = A2_TILE / 1024;           // LDS-DMA pieces per tile
     constexpr int PPW = (A2_CHUNKS + kNW - 1) / kNW;    // pieces per wave per tile
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                             SSC_STAMP(stamp_p1)
                             ph[4] += stamp_p1 - stamp_p0;
                         }
-                        if (group == 1) {
+                        if (group == 1 && !G0DMA) {
 #pragma unroll
                             for (int q = 0; q < PPW; ++q)
                                 if (!(SSC_DYN_ABLATE & 1))
@@ -727,6 +733,22 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                     acc[f & 1][1] = mfma16(a, h1f[1][f >> 1], acc[f & 1][1]);
                     if (STREAM) {
                         const int f0 = GROUP ? X1 + 2 : 1;  // first issue slot after this group's barrier
+                        if constexpr (G0DMA) {
+                            // group 0 feeds the ring alone (it is the group that waits at the barriers: the issue cost comes out of
+                            // its slack): all 32 pieces of tile jt + 1 in tile jt, eight per wave at fragments 1, 3, .. 15
+                            if (GROUP == 0 && !FIRST && f >= 1 && f <= 15 && (f & 1)) {
+                                const int piece = (wave + 4 * (f >> 1)) * 1024;
+                                if (!(SSC_DYN_ABLATE & 1))
+                                    lds_dma_1k(a2_rsrc, lane * 16, ((jt + 1) & (UT - 1)) * A2_TILE + piece, l_a2 + ((jt + 1) & 3) * A2_TILE + piece);
+                            }
+                            if (LAST && f > X0 && !(SSC_DYN_ABLATE & 1)) {   // the next step's tile 1: two pieces per fragment
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    const int piece = (wave + 4 * (2 * (f - X0 - 1) + h)) * 1024;
+                                    lds_dma_1k(a2_rsrc, lane * 16, 1 * A2_TILE + piece, l_a2 + 1 * A2_TILE + piece);
+                                }
+                            }
+                        } else {
                         if (!FIRST && f >= f0 && (f - f0) % 4 == 0 && (f - f0) / 4 < PPW) {
                             const int p = (f - f0) / 4;
                             if (!(SSC_DYN_ABLATE & 1))   // ablation 1: no W2 stream (wrong results; prices the LDS-DMA issue)
@@ -735,6 +757,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                         if (LAST && f > X0 && f - X0 - 1 < PPW && !(SSC_DYN_ABLATE & 1)) {
                             const int p = f - X0 - 1;
                             lds_dma_1k(a2_rsrc, lane * 16, 1 * A2_TILE + (wave + p * kNW) * 1024, l_a2 + 1 * A2_TILE + (wave + p * kNW) * 1024);
+                        }
                         }
                         if (!FIRST && !(SSC_DYN_ABLATE & 2) && f == (GROUP ? X1 : X0)) {  // barrier tl (ablation 2: none)
                             SSC_STAMP(stamp_t0)
