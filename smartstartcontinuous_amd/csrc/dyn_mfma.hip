@@ -58,6 +58,9 @@ constexpr int kMaxKS1 = 2;        // layer-1 k-steps of 32 slots: 2 bias slots +
 #ifndef SSC_DYN_LAG_G0_DMA
 #define SSC_DYN_LAG_G0_DMA 1   // 0: both wave groups issue (A/B: tools/gpu_c4_ab.sh)
 #endif
+#ifndef SSC_DYN_LAG_G1_TILE_PRIO
+#define SSC_DYN_LAG_G1_TILE_PRIO 0
+#endif
 #ifndef SSC_DYN_LAG_PRIO
 #define SSC_DYN_LAG_PRIO 3
 #endif
@@ -676,7 +679,10 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 }
             }
         }
-        if constexpr (LAG) __builtin_amdgcn_s_setprio(0);
+        if constexpr (LAG) {   // tiles: group 0 at priority 0; group 1 (the one the barriers wait for) may be given more
+            if (SSC_DYN_LAG_G1_TILE_PRIO != 0 && group == 1) __builtin_amdgcn_s_setprio(SSC_DYN_LAG_G1_TILE_PRIO);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // the actions of the next step: issued here, behind layer 1's scheduling fences, so that the loads fly
         // under the hidden tiles (hoisted to the top of the step they were waited for at once)
         if (!fwd_mode && t + 1 < g.H) fetch_actions(t + 1);
