@@ -52,3 +52,18 @@ for f in files:
 np.savez_compressed(os.path.join(OUT, "ddpg_hidden_layer_curves.npz"), steps=np.stack(steps), returns=np.stack(returns),
                     labels=np.asarray(labels, np.int32))
 print(len(files), "hidden-layer-size runs")
+
+# ---- the base agent alone on the EDITED env at power_scalar 0.4 (data/ddpg_baselines_summaries/good_params_cont_mc_editted/):
+# 12 runs x 1000 episodes of 1000 steps none of which ever reaches the goal -- what they record is how fast the learner
+# quiets the policy down (the -0.1 a^2 action cost is the only reward signal): median return -12 around episode 80, -1.7
+# around episode 180, -0.2 around episode 280.  A sharp, goal-free signature of the train step + OU exploration.
+files = sorted(glob.glob(os.path.join(REF, "data/ddpg_baselines_summaries/good_params_cont_mc_editted/*.json")))
+steps, returns = [], []
+for f in files:
+    d = json.load(open(f))
+    e = np.asarray(d["episodes"], np.float64)
+    assert e.shape == (1000, 2) and "ActionX0.4" in d["name"], (f, e.shape, d["name"])
+    steps.append(e[:, 0].astype(np.int16))
+    returns.append(e[:, 1].astype(np.float32))
+np.savez_compressed(os.path.join(OUT, "ddpg_edited_env_curves.npz"), steps=np.stack(steps), returns=np.stack(returns))
+print(len(files), "edited-env runs; goals:", int((np.stack(steps) < 1000).sum()))

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Fixture for the only evidence the reference holds for its SmartStart loop end to end (smart-start selection: critic
+values + KDE + UCB; navigation to the chosen state by the NND_MB navigator; DDPG from there): the 98 learning curves of
+examples/continuous/SmartStart_DDPG_Baselines_example.py shipped under
+data/smart_start_continuous_summaries/ddpg_baselines/{hyper_parameter_search, hyper_parameter_search_2} (stock
+MountainCarContinuous-v0, 25 runs each) and .../good_params_cont_mc_editted (the edited env at power_scalar 0.4, 48 runs).
+DATA only: per run the 1000 (steps, total reward) records and which episodes were smart-start episodes, + the
+hyper-parameters they were run with.
+
+    python tests/golden/make_smartstart_curves.py        # in the build container; writes smartstart_curves.npz
+"""
+import glob
+import json
+import os
+
+import numpy as np
+
+REF = os.environ.get("SSC_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+BASE = os.path.join(REF, "data/smart_start_continuous_summaries/ddpg_baselines")
+
+steps, returns, smart, group, params = [], [], [], [], {}
+for gi, d in enumerate(("hyper_parameter_search", "hyper_parameter_search_2", "good_params_cont_mc_editted")):
+    for f in sorted(glob.glob(os.path.join(BASE, d, "*.json"))):
+        j = json.load(open(f))
+        e = np.asarray(j["episodes"], np.float64)
+        assert e.shape == (1000, 2), (f, e.shape)
+        m = np.zeros(1000, bool)
+        m[np.asarray(j["smart_start_episodes"], np.int64)] = True
+        steps.append(e[:, 0].astype(np.int16))
+        returns.append(e[:, 1].astype(np.float32))
+        smart.append(m)
+        group.append(gi)
+        p = {k: v for k, v in j["param_dict"].items() if v != "Not serializable" and not k.startswith("zz_RANDOM")}
+        assert params.setdefault(gi, p) == p, f                   # every run of a directory used the same hyper-parameters
+        assert ("ActionX0.4" in j["name"]) == (gi == 2), j["name"]
+assert params[0] == params[1] == params[2]
+np.savez_compressed(os.path.join(OUT, "smartstart_curves.npz"), steps=np.stack(steps), returns=np.stack(returns),
+                    smart_start=np.packbits(np.stack(smart), axis=1), group=np.asarray(group, np.int8),
+                    param_dict=json.dumps(params[0], sort_keys=True))
+print(len(steps), "runs;", np.bincount(group), "per directory; smart-start episodes per run",
+      np.stack(smart).sum(1).min(), "-", np.stack(smart).sum(1).max())

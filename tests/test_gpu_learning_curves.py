@@ -143,3 +143,49 @@ def test_wide_ddpg_learning_curves_fall_inside_the_reference_band(golden_dir, h1
     assert lb[0] - 1.0 <= np.median(lates) <= lb[1] + 1.0, (lates, lb)
     assert max(firsts) <= max(int(b["first"].max()), 10) + 5, (firsts, b["first"])
     assert sum(1 for x in lates if x < lb[0] - 5.0) <= n_seeds // 3, (lates, lb)     # the reference itself has a rare diverged run
+
+
+# ---- the base agent on the EDITED env at power_scalar 0.4: no run ever reaches the goal, the curve is the action cost decaying --
+def edited_env_bands(golden_dir, windows=((0, 40), (40, 80))):
+    g = np.load(f"{golden_dir}/ddpg_edited_env_curves.npz")
+    steps, rets = g["steps"].astype(np.int64), g["returns"].astype(np.float64)
+    med = np.stack([np.median(rets[:, a:b], axis=1) for a, b in windows], axis=1)          # [runs, windows]
+    return dict(n=rets.shape[0], goals=int((steps < 1000).sum()), lo=med.min(axis=0), hi=med.max(axis=0), mid=np.median(med, axis=0))
+
+
+def test_edited_env_curve_fixture(golden_dir):
+    """(CPU) 12 runs x 1000 episodes without a single goal; the per-window medians of the runs lie within a few units of
+    each other -- the return is -0.1 * sum(a^2) of (quiet actor + epsilon-scaled OU noise), epsilon = 0.99^episode."""
+    b = edited_env_bands(golden_dir, windows=((0, 40), (40, 80), (160, 200), (280, 320)))
+    assert b["n"] == 12 and b["goals"] == 0
+    assert (b["hi"] - b["lo"] < [15.0, 10.0, 1.2, 0.12]).all()
+    assert np.allclose(b["mid"], [-34.4, -16.2, -1.74, -0.14], atol=0.3)
+    # 40 episodes later epsilon^2 is 0.99^80 = 0.45 times smaller: the decay of the curve IS the decay of the noise
+    assert 0.40 < b["mid"][1] / b["mid"][0] < 0.55
+
+
+@pytest.mark.gpu
+def test_ddpg_on_the_edited_env_quiets_down_like_the_reference_runs(golden_dir):
+    """2 seeds x 80 episodes x 1000 steps of rlTrain(DDPG_Baselines_agent) on Continuous_MountainCarEnv_Editted(0.4): like the
+    reference's 12 runs no episode reaches the goal, and the median return of episodes 0..39 and 40..79 follows the
+    reference's curve -- which pins the OU process (mu, sigma, theta, dt, per-episode reset, epsilon decay), the clip and
+    how fast the learner pulls the actor's output to zero.  (17 seeds of this engine: 16 inside / next to the bands, one
+    that saturates the actor instead, profiles/r03/curves/; the bands are widened by a quarter of their width.)"""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no fallback")
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from exp_smartstart_curves import run
+    b = edited_env_bands(golden_dir)
+    slack = 0.25 * (b["hi"] - b["lo"])
+    meds = []
+    for seed in (4003, 4004):
+        ep, _ = run("edited", 80, seed, None, "f32", None, smart=False)
+        assert ep.shape == (80, 2) and (ep[:, 0] == 1000).all(), "an episode ended before the time limit"
+        meds.append([np.median(ep[0:40, 1]), np.median(ep[40:80, 1])])
+        print("seed %d: median return of episodes 0-39 %.1f, 40-79 %.1f" % (seed, *meds[-1]), flush=True)
+    meds = np.asarray(meds)
+    print("reference: per-window [min, max] of the 12 runs' medians", b["lo"], b["hi"])
+    assert ((meds >= b["lo"] - slack - 2.5) & (meds <= b["hi"] + slack)).all(), (meds, b["lo"], b["hi"])
+    assert (b["lo"] - slack <= meds.mean(axis=0)).all() and (meds.mean(axis=0) <= b["hi"] + slack).all(), (meds, b["lo"], b["hi"])

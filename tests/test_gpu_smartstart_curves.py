@@ -1,0 +1,69 @@
+"""The SmartStart loop end to end -- smart-start selection (critic values + KDE + UCB), navigation to the chosen state by the
+NND_MB navigator, DDPG from there (smartexplorationcontinuous.py:223-376) -- against the ONLY evidence the reference holds
+for it: the 98 learning curves of examples/continuous/SmartStart_DDPG_Baselines_example.py it ships under
+data/smart_start_continuous_summaries/ddpg_baselines/ (tests/golden/smartstart_curves.npz, made by
+tests/golden/make_smartstart_curves.py).  Distributional, like test_gpu_learning_curves.py: scalar
+rlTrain(SmartStartContinuous(DDPG_Baselines_agent)) through the HIP path with the shipped hyper-parameters must look like
+draws from the reference's own run-to-run distribution."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_smartstart_curve_fixture(golden_dir):
+    """(CPU) the fixture is what make_smartstart_curves.py extracts: 50 stock-env + 48 edited-env runs of 1000 episodes."""
+    import json
+    g = np.load(f"{golden_dir}/smartstart_curves.npz")
+    assert g["steps"].shape == (98, 1000) and g["returns"].shape == (98, 1000)
+    assert np.bincount(g["group"]).tolist() == [25, 25, 48]
+    smart = np.unpackbits(g["smart_start"], axis=1)[:, :1000]
+    # eta = 0.5 decaying by 0.99 per episode: sum_k 0.5 * 0.99**k = 50 smart-start episodes expected per run
+    assert 32 <= smart.sum(axis=1).min() and smart.sum(axis=1).max() <= 64 and abs(smart.sum(axis=1).mean() - 48.5) < 2.5
+    p = json.loads(str(g["param_dict"]))
+    assert (p["eta"], p["eta_decay_factor"], p["n_ss"], p["exploration_param"], p["exploitation_param"]) == (0.5, 0.99, 2000, 2.0, 1.0)
+    assert (p["nnd_mb_num_control_samples"], p["nnd_mb_horizon"], p["nnd_mb_depth_fc_layers"], p["nnd_mb_num_fc_layers"]) == (5000, 4, 32, 1)
+    assert p["nnd_mb_num_episodes_for_aggregation"] == 4 and p["nnd_mb_path_shortcutting"] is True
+    stock = g["steps"][g["group"] < 2] < 999
+    first = np.array([int(np.argmax(r)) for r in stock])
+    assert first.max() <= 8                                                    # every stock-env run reaches the goal early
+
+
+@pytest.mark.gpu
+def test_scalar_smartstart_learning_curves_fall_inside_the_reference_band(golden_dir):
+    """5 seeds x 130 episodes on stock MountainCarContinuous-v0 with the shipped runs' hyper-parameters (N = 5000 candidates,
+    n_ss = 2000, eta 0.5 x 0.99^episode, retraining the navigator every 4th plan, the reference's own dataX/Y/Z as the
+    navigator's initial data set).  Per seed: the first goal episode, the median return and the goal rate of episodes 90..129
+    and the number of smart-start episodes; the reference's 50 runs define the inter-decile bands."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no fallback")
+    from exp_smartstart_curves import reference_bands, run
+    E, late, n_seeds = 130, (90, 130), 5
+    b = reference_bands("stock", E, late)
+    g = np.load(f"{golden_dir}/mc_reference_rollouts.npz")
+    data = dict(dataX=g["dataX"], dataY=g["dataY"], dataZ=g["dataZ"])
+    firsts, lates, rates, counts = [], [], [], []
+    for s in range(n_seeds):
+        ep, ss = run("stock", E, 3000 + s, data, "f32", b["params"])
+        assert ep.shape == (E, 2) and len(set(ss)) == len(ss) and all(0 < e < E for e in ss)   # episode 0 has no path to follow
+        goal = ep[:, 0] < 999
+        firsts.append(int(np.argmax(goal)) if goal.any() else E)
+        lates.append(float(np.median(ep[late[0]:late[1], 1])))
+        rates.append(float(goal[late[0]:late[1]].mean()))
+        counts.append(len(ss))
+        print("seed %d: first goal episode %d, late median return %.2f, goal rate %.2f, %d smart-start episodes"
+              % (3000 + s, firsts[-1], lates[-1], rates[-1], counts[-1]), flush=True)
+    print("reference bands: first goal", b["first_band"], "late median return", b["late_band"], "goal rate", b["goal_rate_band"],
+          "smart-start episodes", b["smart_band"])
+    fb, lb, sb = b["first_band"], b["late_band"], b["smart_band"]
+    assert fb[0] <= np.median(firsts) <= fb[1] and max(firsts) <= b["first"].max() + 2, (firsts, fb)
+    assert lb[0] <= np.median(lates) <= lb[1], (lates, lb)
+    assert np.sum((np.asarray(lates) < lb[0]) | (np.asarray(lates) > lb[1] + 0.5)) <= 1, (lates, lb)
+    assert np.median(rates) >= b["goal_rate_band"][0], (rates, b["goal_rate_band"])
+    # smart-start episodes: Binomial-like around sum(eta_k) = 36 in 130 episodes; the reference's decile band is 30..42
+    assert sb[0] <= np.median(counts) <= sb[1] and min(counts) >= sb[0] - 8 and max(counts) <= sb[1] + 8, (counts, sb)
