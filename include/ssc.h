@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSC_VERSION 102 /* 0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step */
+#define SSC_VERSION 103 /* 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
 
 typedef void *ssc_stream_t; /* hipStream_t */
 
@@ -605,9 +605,17 @@ int ssc_column_stats(const float *d_x, int64_t rows, int32_t cols, double *d_mea
 int ssc_zscore(const float *d_x, int64_t rows, int32_t cols, const double *d_mean, const double *d_std, float *d_out,
                int32_t out_stride, int32_t out_col0, ssc_stream_t stream);
 
+/* The same for the whole network-input matrix of :318 in one pass: d_out[r] = [zscore(x[r]) | zscore(y[r])], rows of
+ * cols_x + cols_y floats -- np.concatenate((dataX, dataY), axis=1) of the two z-scored matrices (NND_MB_agent.py:303-318).
+ * Bit-identical to two ssc_zscore calls into the same matrix; every output line is written whole. */
+int ssc_zscore_concat(const float *d_x, int32_t cols_x, const double *d_mean_x, const double *d_std_x, const float *d_y,
+                      int32_t cols_y, const double *d_mean_y, const double *d_std_y, int64_t rows, float *d_out,
+                      ssc_stream_t stream);
+
 /* helper_funcs.add_noise: x[r][c] += N(0, |mean_c * noise_to_signal|) in the columns where
- * mean_c * noise_to_signal > 0 (only those, :14).  Gaussian = Box-Muller of
- * Philox(seed; r, stream_id << 8 | c, TAG_DATA_NOISE = 6) words (x, y); oracle: add_noise_keyed. */
+ * mean_c * noise_to_signal > 0 (only those, :14).  One Philox(seed; r, stream_id << 8 | (c >> 2), TAG_DATA_NOISE = 6)
+ * evaluation serves four columns: word pair (x, y) for c & 3 in {0, 1}, (z, w) for {2, 3}; the cos output of the pair's
+ * Box-Muller transform for the even column, the sin output for the odd one; oracle: add_noise_keyed. */
 int ssc_add_noise(float *d_x, int64_t rows, int32_t cols, const double *d_mean, double noise_to_signal, uint64_t seed,
                   uint64_t stream_id, ssc_stream_t stream);
 

@@ -59,9 +59,7 @@ class TrainingSet:
         dev = self.dataX.device
         st = lambda k: torch.as_tensor(np.asarray(norm[k], np.float64).reshape(-1), device=dev)
         d, a = self.dataX.shape[1], self.dataY.shape[1]
-        inputs = torch.empty((len(self), d + a), dtype=torch.float32, device=dev)
-        zscore_into(self.dataX, st("mean_x"), st("std_x"), inputs, 0)
-        zscore_into(self.dataY, st("mean_y"), st("std_y"), inputs, d)
+        inputs = zscore_concat(self.dataX, st("mean_x"), st("std_x"), self.dataY, st("mean_y"), st("std_y"))
         return inputs, zscore_into(self.dataZ, st("mean_z"), st("std_z"), torch.empty_like(self.dataZ), 0)
 
 
@@ -120,6 +118,25 @@ def zscore_into(x, mean, std, out, col0=0):
     with torch.cuda.device(x.device):
         _ffi.check(lib.ssc_zscore(_ffi.ptr(x), rows, cols, _ffi.ptr(mean), _ffi.ptr(std), _ffi.ptr(out), out.shape[1],
                                   col0, _stream()))
+    return out
+
+
+def zscore_concat(x, mean_x, std_x, y, mean_y, std_y, out=None):
+    """[nan_to_num((x - mean_x) / std_x) | nan_to_num((y - mean_y) / std_y)] as one [rows, cols_x + cols_y] matrix
+    (NND_MB_agent.py:303-318: the two z-scored matrices, np.concatenate(..., axis=1)) in a single pass."""
+    lib = _ffi.lib()
+    x, y = x.contiguous(), y.contiguous()
+    rows, cx = x.shape
+    cy = y.shape[1]
+    if y.shape[0] != rows:
+        raise ValueError("x and y must have one row per data row")
+    if out is None:
+        out = torch.empty((rows, cx + cy), dtype=torch.float32, device=x.device)
+    if tuple(out.shape) != (rows, cx + cy) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("out must be a contiguous fp32 [rows, cols_x + cols_y] matrix")
+    with torch.cuda.device(x.device):
+        _ffi.check(lib.ssc_zscore_concat(_ffi.ptr(x), cx, _ffi.ptr(mean_x), _ffi.ptr(std_x), _ffi.ptr(y), cy, _ffi.ptr(mean_y),
+                                         _ffi.ptr(std_y), rows, _ffi.ptr(out), _stream()))
     return out
 
 

@@ -310,30 +310,82 @@ __global__ __launch_bounds__(kBlock) void zscore_kernel(const float *__restrict_
     }
 }
 
-template <int COLS>
-__global__ __launch_bounds__(kBlock) void add_noise_kernel(float *__restrict__ x, int64_t total, int32_t cols_rt,
-                                                            const double *__restrict__ mean, double nts, uint64_t seed,
-                                                            uint64_t stream_id) {
-    const int32_t cols = COLS > 0 ? COLS : cols_rt;
+// The network-input matrix of NND_MB_agent.py:318 in ONE pass: out[r] = [zscore(x[r]) | zscore(y[r])], rows of
+// CX + CY floats written back to back.  Two ssc_zscore launches into the same matrix each write 8 (or 4) of every 12
+// bytes -- partial lines on the write side, 2.8-3.0 TB/s; here every output line is written whole (3.5 TB/s for 2 + 1
+// columns, 4.8 TB/s for 3 + 1; a thread-per-row variant with the constants in registers measured 3.6 / 3.9).
+template <int CX, int CY>
+__global__ __launch_bounds__(kBlock) void zscore_concat_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                int64_t total, int32_t cx_rt, int32_t cy_rt,
+                                                                const double *__restrict__ mean_x, const double *__restrict__ sd_x,
+                                                                const double *__restrict__ mean_y, const double *__restrict__ sd_y,
+                                                                float *__restrict__ out) {
+    const int32_t cx = CX > 0 ? CX : cx_rt, cy = CX > 0 ? CY : cy_rt, cols = cx + cy;
+    __shared__ double mean_s[kBlock], inv_s[kBlock];
+    if ((int)threadIdx.x < cols) {
+        const int c = threadIdx.x;
+        mean_s[c] = c < cx ? mean_x[c] : mean_y[c - cx];
+        inv_s[c] = 1.0 / (c < cx ? sd_x[c] : sd_y[c - cx]);
+    }
     const int64_t first = (int64_t)blockIdx.x * (kBlock * kPerThread);
     const SpanIndex span(first, cols);
     float v[kPerThread];
-#pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
-        const int64_t e = first + threadIdx.x + j * kBlock;
-        v[j] = e < total ? x[e] : 0.0f;
-    }
+    int col[kPerThread];
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
         const uint32_t local = threadIdx.x + j * kBlock;
-        if (first + local >= total) break;
         int64_t r;
-        int c;
-        span.at(local, (uint32_t)cols, r, c);
-        const double sd = mean[c] * nts;
-        if (!(sd > 0.0)) continue;                    // helper_funcs.py:14: only where mean * noiseToSignal > 0
-        const u32x4 wds = rng_words(seed, (uint64_t)r, (stream_id << 8) | (uint64_t)c, TAG_DATA_NOISE);
-        x[first + local] = fmaf((float)sd, gaussian_f32(wds.x, wds.y), v[j]);
+        span.at(local, (uint32_t)cols, r, col[j]);
+        const int c = col[j];
+        v[j] = first + local < total ? (c < cx ? x[r * cx + c] : y[r * cy + (c - cx)]) : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+        const int64_t e = first + threadIdx.x + j * kBlock;
+        if (e >= total) break;
+        double z = ((double)v[j] - mean_s[col[j]]) * inv_s[col[j]];
+        if (z != z) z = 0.0;                      // np.nan_to_num, as in zscore_kernel
+        float f = (float)z;
+        if (f > 3.402823466e38f) f = 3.402823466e38f;
+        if (f < -3.402823466e38f) f = -3.402823466e38f;
+        out[e] = f;
+    }
+}
+
+// One thread per row and group of four columns: ONE Philox evaluation (counter stream_id << 8 | group) yields the four
+// gaussians of the group -- word pair (x, y) for columns 4g and 4g + 1, (z, w) for 4g + 2 and 4g + 3, the cos output of a
+// pair's Box-Muller transform for the even and the sin output for the odd column (oracle: add_noise_keyed).  The first
+// version drew one Philox + one Box-Muller per ELEMENT and was bound by that arithmetic at 2.4-3.0 TB/s.
+template <int COLS>
+__global__ __launch_bounds__(kBlock) void add_noise_kernel(float *__restrict__ x, int64_t rows, int32_t cols_rt,
+                                                            const double *__restrict__ mean, double nts, uint64_t seed,
+                                                            uint64_t stream_id) {
+    const int32_t cols = COLS > 0 ? COLS : cols_rt;
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= rows) return;
+    float *row = x + r * cols;
+    if (COLS > 0) {
+        float v[COLS > 0 ? COLS : 1];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) v[c] = row[c];
+        const u32x4 wds = rng_words(seed, (uint64_t)r, stream_id << 8, TAG_DATA_NOISE);
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            const double sd = mean[c] * nts;
+            if (!(sd > 0.0)) continue;                // helper_funcs.py:14: only where mean * noiseToSignal > 0
+            row[c] = fmaf((float)sd, gaussian_f32(c < 2 ? wds.x : wds.z, c < 2 ? wds.y : wds.w, (c & 1) != 0), v[c]);
+        }
+        return;
+    }
+    for (int g = 0; g * 4 < cols; ++g) {
+        const u32x4 wds = rng_words(seed, (uint64_t)r, (stream_id << 8) | (uint64_t)g, TAG_DATA_NOISE);
+        for (int j = 0; j < 4 && g * 4 + j < cols; ++j) {
+            const int c = g * 4 + j;
+            const double sd = mean[c] * nts;
+            if (!(sd > 0.0)) continue;
+            row[c] = fmaf((float)sd, gaussian_f32(j < 2 ? wds.x : wds.z, j < 2 ? wds.y : wds.w, (j & 1) != 0), row[c]);
+        }
     }
 }
 
@@ -429,16 +481,31 @@ int ssc_zscore(const float *d_x, int64_t rows, int32_t cols, const double *d_mea
     return check_launch("ssc_zscore");
 }
 
+int ssc_zscore_concat(const float *d_x, int32_t cols_x, const double *d_mean_x, const double *d_std_x, const float *d_y,
+                      int32_t cols_y, const double *d_mean_y, const double *d_std_y, int64_t rows, float *d_out,
+                      ssc_stream_t stream) {
+    SSC_REQUIRE(cols_x >= 1 && cols_y >= 1 && cols_x + cols_y <= kBlock && rows >= 0, "ssc_zscore_concat: cols %d + %d, rows %lld",
+                cols_x, cols_y, (long long)rows);
+    if (rows == 0) return SSC_OK;
+    SSC_REQUIRE(d_x && d_y && d_mean_x && d_std_x && d_mean_y && d_std_y && d_out, "ssc_zscore_concat: NULL pointer");
+    const int64_t total = rows * (cols_x + cols_y);
+    const dim3 grid(blocks_for(total, kBlock * kPerThread)), block(kBlock);
+    hipStream_t s = as_stream(stream);
+#define SSC_ZC(A, B) hipLaunchKernelGGL((zscore_concat_kernel<A, B>), grid, block, 0, s, d_x, d_y, total, cols_x, cols_y, d_mean_x, d_std_x, d_mean_y, d_std_y, d_out)
+    if (cols_x == 2 && cols_y == 1) SSC_ZC(2, 1); else if (cols_x == 3 && cols_y == 1) SSC_ZC(3, 1); else SSC_ZC(0, 0);
+#undef SSC_ZC
+    return check_launch("ssc_zscore_concat");
+}
+
 int ssc_add_noise(float *d_x, int64_t rows, int32_t cols, const double *d_mean, double noise_to_signal, uint64_t seed,
                   uint64_t stream_id, ssc_stream_t stream) {
     SSC_REQUIRE(cols >= 1 && cols <= 256 && rows >= 0, "ssc_add_noise: cols %d not in 1..256", cols);
     SSC_REQUIRE(stream_id < (1ull << 48), "ssc_add_noise: stream_id too large");
     if (rows == 0) return SSC_OK;
     SSC_REQUIRE(d_x && d_mean, "ssc_add_noise: NULL pointer");
-    const int64_t total = rows * cols;
-    const dim3 grid(blocks_for(total, kBlock * kPerThread)), block(kBlock);
+    const dim3 grid(blocks_for(rows, kBlock)), block(kBlock);
     hipStream_t s = as_stream(stream);
-#define SSC_AN(C) hipLaunchKernelGGL(add_noise_kernel<C>, grid, block, 0, s, d_x, total, cols, d_mean, noise_to_signal, seed, stream_id)
+#define SSC_AN(C) hipLaunchKernelGGL(add_noise_kernel<C>, grid, block, 0, s, d_x, rows, cols, d_mean, noise_to_signal, seed, stream_id)
     if (cols == 1) SSC_AN(1); else if (cols == 2) SSC_AN(2); else if (cols == 3) SSC_AN(3); else if (cols == 4) SSC_AN(4); else SSC_AN(0);
 #undef SSC_AN
     return check_launch("ssc_add_noise");

@@ -34,7 +34,7 @@ def test_header_symbols_exported_and_bound(built):
 def test_version_and_defaults(built):
     from smartstartcontinuous_amd import _ffi
     lib = _ffi.lib()
-    assert lib.ssc_version() == 102
+    assert lib.ssc_version() == 103
     p = _ffi.default_params(_ffi.SSC_ENV_MOUNTAINCAR, 0.4, 1000)
     assert abs(p.power - 0.0006) < 1e-9 and p.max_episode_steps == 1000
     assert abs(p.goal_position - 0.45) < 1e-7 and abs(p.min_position + 1.2) < 1e-7
@@ -79,6 +79,8 @@ def test_argument_validation_of_the_dataset_and_training_entry_points(built):
     assert lib.ssc_column_stats(None, 0, 3, None, None, None, 0, None) == E and b"at least one row" in lib.ssc_last_error()
     assert lib.ssc_zscore(None, 5, 3, None, None, None, 2, 0, None) == E                                       # out_stride < cols
     assert lib.ssc_zscore(None, 0, 3, None, None, None, 4, 1, None) == 0
+    assert lib.ssc_zscore_concat(None, 0, None, None, None, 1, None, None, 5, None, None) == E                     # cols_x < 1
+    assert lib.ssc_zscore_concat(None, 2, None, None, None, 1, None, None, 0, None, None) == 0
     assert lib.ssc_add_noise(None, 5, 300, None, 0.01, 1, 0, None) == E
     assert lib.ssc_add_noise(None, 5, 3, None, 0.01, 1, 1 << 50, None) == E and b"stream_id" in lib.ssc_last_error()
     assert lib.ssc_add_noise(None, 0, 3, None, 0.01, 1, 0, None) == 0

@@ -44,10 +44,12 @@ for env_id, K in (("Pendulum-v0", 200), ("MountainCarContinuous-v0", 333)):
     inputs = torch.empty((rows, d + 1), device="cuda")
     mean, std = cs.column_stats(X)
     t_z = timed(lambda: cs.zscore_into(X, mean, std, inputs, 0))
+    mean_y, std_y = cs.column_stats(Y)
+    t_zc = timed(lambda: cs.zscore_concat(X, mean, std, Y, mean_y, std_y, out=inputs))
     t_noise = timed(lambda: cs.add_noise_device(X, 0.01, 1, 0, mean=mean.abs()))
     t_roll = timed(lambda: env.rollout(K, policy=ssc.RandomPolicy(), out=chunk), reps=5)
     build_bytes = rows * ((3 * d + 1) * 4 + (2 * d + 1) * 4)       # read obs, obs2, act; write X, Y, Z
     print(f"{env_id}: {n} rollouts x {K} steps -> {rows} rows | rollout {t_roll:.3f} ms | scan {t_scan:.3f} ms "
           f"({n * K / t_scan / 1e6:.1f} GB/s of done bytes) | build {t_build:.3f} ms ({build_bytes / t_build / 1e6:.0f} GB/s) | "
           f"column_stats {t_stats:.3f} ms ({2 * rows * d * 4 / t_stats / 1e6:.0f} GB/s) | zscore {t_z:.3f} ms "
-          f"({2 * rows * d * 4 / t_z / 1e6:.0f} GB/s) | add_noise {t_noise:.3f} ms ({2 * rows * d * 4 / t_noise / 1e6:.0f} GB/s)")
+          f"({2 * rows * d * 4 / t_z / 1e6:.0f} GB/s) | zscore_concat {t_zc:.3f} ms ({2 * rows * (d + 1) * 4 / t_zc / 1e6:.0f} GB/s) | add_noise {t_noise:.3f} ms ({2 * rows * d * 4 / t_noise / 1e6:.0f} GB/s)")
