@@ -91,6 +91,29 @@ def profiled_valu_issue():
     return best
 
 
+C4_SOURCES = ("dyn_mfma.hip",)
+
+
+def profiled_pipe_busy():
+    """Matrix-pipe busy fraction of the forward-simulation kernel (BASELINE configs[3]): SQ_VALU_MFMA_BUSY_CYCLES per SIMD over
+    the launch's own length (SQ_BUSY_CYCLES per shader engine), both from the committed PMC pass of this same command
+    (profiles/*/c4/mfma_busy.json, written by tools/summarize_c4_busy.py) -- clock-independent, and reported only for the
+    kernel source it was measured on."""
+    import glob
+    sha, best = source_sha_of(C4_SOURCES), None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "c4", "mfma_busy.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        rel = os.path.relpath(f, ROOT)
+        if d.get("source_sha") == sha:
+            best = dict(d, source=rel)
+        elif best is None or "stale" in best:
+            best = {"stale": "%s was measured on kernel source %s, this build is %s" % (rel, d.get("source_sha"), sha)}
+    return best
+
+
 def bench_config3(args, torch, emit=True):
     """BASELINE configs[2]: 65 536 MountainCar envs + DDPG actor 64-32 (bf16 MFMA) + OU noise, fused."""
     import numpy as np
@@ -269,6 +292,9 @@ def bench_config4(args, torch, emit=True):
                         "kernel": "ssc::dyn_mfma_sim_kernel<16,2,true,4> (weight image prepared once; one event pair around the simulation launch of every MPC step)",
                         "kernel_ms_back_to_back": kms_b2b, "kernel_ms_back_to_back_note": "HIP-graph replay of 10 simulation launches with nothing in between",
                         "algorithmic_flop_per_launch": flop_row * M * H}}
+    pb = profiled_pipe_busy()
+    if pb is not None:
+        res["roofline"]["pipe_busy"] = pb
     if not args.no_cpu_baseline:
         from oracle import ssc_oracle as O               # the checker, timed as the CPU baseline only
         Wn, bn = [w.numpy() for w in Ws], [b.numpy() for b in bs]

@@ -48,6 +48,17 @@ def test_traffic_is_reported_only_for_the_sources_it_was_measured_on(tmp_path, m
     assert value is None and "stale" in note
 
 
+def test_issue_and_pipe_stamps_are_current_for_the_committed_kernels():
+    """roofline.valu_issue (config 3) and roofline.pipe_busy (config 4) come from committed PMC passes too; a stamp that
+    no longer matches the kernel source it was measured on is a hygiene failure of the repo."""
+    sys.path.insert(0, ROOT)
+    import bench
+    vi, pb = bench.profiled_valu_issue(), bench.profiled_pipe_busy()
+    assert vi is not None and "stale" not in vi and 0.5 < vi["frac"] < 1.0, vi
+    assert pb is not None and "stale" not in pb and 0.5 < pb["frac"] < 1.0, pb
+    assert abs(pb["SQ_VALU_MFMA_BUSY_CYCLES"] - 16 * pb["SQ_INSTS_MFMA"]) < 1.0        # 16 cycles per 16x16x32 bf16 MFMA
+
+
 def _run_bench(cmd, extra_env=None):
     import subprocess
     env = dict(os.environ)
