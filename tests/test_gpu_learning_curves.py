@@ -166,7 +166,7 @@ def test_edited_env_curve_fixture(golden_dir):
 
 @pytest.mark.gpu
 def test_ddpg_on_the_edited_env_quiets_down_like_the_reference_runs(golden_dir):
-    """2 seeds x 80 episodes x 1000 steps of rlTrain(DDPG_Baselines_agent) on Continuous_MountainCarEnv_Editted(0.4): like the
+    """One seed x 80 episodes x 1000 steps of rlTrain(DDPG_Baselines_agent) on Continuous_MountainCarEnv_Editted(0.4): like the
     reference's 12 runs no episode reaches the goal, and the median return of episodes 0..39 and 40..79 follows the
     reference's curve -- which pins the OU process (mu, sigma, theta, dt, per-episode reset, epsilon decay), the clip and
     how fast the learner pulls the actor's output to zero.  (17 seeds of this engine: 16 inside / next to the bands, one
@@ -180,7 +180,7 @@ def test_ddpg_on_the_edited_env_quiets_down_like_the_reference_runs(golden_dir):
     b = edited_env_bands(golden_dir)
     slack = 0.25 * (b["hi"] - b["lo"])
     meds = []
-    for seed in (4003, 4004):
+    for seed in (4004,):                      # 22 s; 17 seeds: profiles/r03/curves/edited_ddpg*.txt
         ep, _ = run("edited", 80, seed, None, "f32", None, smart=False)
         assert ep.shape == (80, 2) and (ep[:, 0] == 1000).all(), "an episode ended before the time limit"
         meds.append([np.median(ep[0:40, 1]), np.median(ep[40:80, 1])])

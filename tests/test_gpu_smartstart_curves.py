@@ -36,14 +36,14 @@ def test_smartstart_curve_fixture(golden_dir):
 
 @pytest.mark.gpu
 def test_scalar_smartstart_learning_curves_fall_inside_the_reference_band(golden_dir):
-    """5 seeds x 130 episodes on stock MountainCarContinuous-v0 with the shipped runs' hyper-parameters (N = 5000 candidates,
+    """3 seeds x 130 episodes on stock MountainCarContinuous-v0 with the shipped runs' hyper-parameters (N = 5000 candidates,
     n_ss = 2000, eta 0.5 x 0.99^episode, retraining the navigator every 4th plan, the reference's own dataX/Y/Z as the
     navigator's initial data set).  Per seed: the first goal episode, the median return and the goal rate of episodes 90..129
     and the number of smart-start episodes; the reference's 50 runs define the inter-decile bands."""
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU: the HIP path has no fallback")
     from exp_smartstart_curves import reference_bands, run
-    E, late, n_seeds = 130, (90, 130), 5
+    E, late, n_seeds = 130, (90, 130), 3          # 14 s per seed (8 seeds: profiles/r03/curves/stock8.txt)
     b = reference_bands("stock", E, late)
     g = np.load(f"{golden_dir}/mc_reference_rollouts.npz")
     data = dict(dataX=g["dataX"], dataY=g["dataY"], dataZ=g["dataZ"])
