@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSC_VERSION 103 /* 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
+#define SSC_VERSION 104 /* 0.1.4: ssc_path_shortcut; 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
 
 typedef void *ssc_stream_t; /* hipStream_t */
 
@@ -591,6 +591,14 @@ int ssc_dataset_scan(const ssc_transition_log *log, int32_t K, int64_t n, int32_
 int ssc_dataset_build(const ssc_transition_log *log, int32_t obs_dim, int32_t K, int64_t n, const int32_t *d_len,
                       const int64_t *d_off, int64_t capacity_rows, float *d_X, float *d_Y, float *d_Z,
                       ssc_stream_t stream);
+
+/* HOST function (no GPU work): path_shortcutter (smartstart/utilities/numerical.py:226-246) with the elliptical distance of
+ * :116-124 -- every pair of states (i, j >= i + 2) of path[n][d] within theta of each other is a candidate shortcut, the
+ * weighted interval scheduling of :189-222 (weight j - i - 1 per interval after the first, later intervals win ties) picks
+ * the non-overlapping set that deletes the most interior states.  keep[i] = 1 for the states that stay, *n_kept their count
+ * (may be NULL).  fp64, the reference's expression order: decisions identical to the numpy implementation. */
+int ssc_path_shortcut(const double *path, int32_t n, int32_t d, const double *radii, double theta, uint8_t *keep,
+                      int32_t *n_kept);
 
 /* mean_c = mean(x[:, c]); std_c = sqrt(mean((x[:, c] - mean_c)^2)) (NND_MB_agent.py:302-304: np.mean, then
  * np.std of the centred column), accumulated in f64 in a fixed order (bit-reproducible).  rows >= 1,

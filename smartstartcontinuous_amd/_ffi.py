@@ -184,6 +184,7 @@ _SIGNATURES = {
     "ssc_column_stats_workspace_bytes": (c_size_t, [c_int32]),
     "ssc_column_stats": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ssc_zscore": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "ssc_path_shortcut": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_double, c_void_p, c_void_p]),
     "ssc_zscore_concat": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p,
                                   c_void_p]),
     "ssc_add_noise": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_double, c_uint64, c_uint64, c_void_p]),

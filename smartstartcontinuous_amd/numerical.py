@@ -38,6 +38,7 @@ def elliptical_euclidean_distance_function_generator(radii):
         other_state = np.asarray(other_state, dtype=np.float64)
         return np.sqrt(np.sum(((state - other_state) / radii) ** 2, axis=max(state.ndim, other_state.ndim) - 1))
 
+    distance_func.radii = radii          # lets path_shortcutter hand the whole job to libssc's host routine
     return distance_func
 
 
@@ -132,10 +133,27 @@ def length_weighted_activities_solver(activities, sub_extra=0):
     return int(best[-1]), chosen
 
 
-def path_shortcutter(path, distance_func, theta):
+def _native_path_shortcut(a, radii, theta):
+    """``ssc_path_shortcut`` (csrc/path_geometry.cpp): the same decisions in native host code -- a 300-state path takes
+    0.1 ms instead of 1.5-6.5 ms, and eight plans per smart-start selection are the serial part of the vectorised loop."""
+    import ctypes
+    from . import _ffi
+    keep = np.ones(a.shape[0], np.uint8)
+    r = np.ascontiguousarray(radii, np.float64)
+    _ffi.check(_ffi.lib().ssc_path_shortcut(a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1],
+                                            r.ctypes.data_as(ctypes.c_void_p), float(theta),
+                                            keep.ctypes.data_as(ctypes.c_void_p), None))
+    return a[keep.astype(bool)]
+
+
+def path_shortcutter(path, distance_func, theta, native=True):
     """numerical.py:226-246: drop interior states between any two states (>= 2 apart) that are within
-    ``theta`` of each other, choosing the non-overlapping shortcuts that delete the most states."""
-    a = np.asarray(path, dtype=np.float64)
+    ``theta`` of each other, choosing the non-overlapping shortcuts that delete the most states.
+    With the elliptical distance of this module the work is done by libssc's host routine (``native=False``: numpy)."""
+    a = np.ascontiguousarray(path, dtype=np.float64)
+    radii = getattr(distance_func, "radii", None)
+    if native and radii is not None and a.ndim == 2 and 1 <= a.shape[1] <= 8 and a.shape[1] == len(radii):
+        return _native_path_shortcut(a, radii, theta)
     dist = distance_func(a[:, None, :], a[None, :, :])
     pairs = np.transpose(np.where(np.triu(dist <= theta, k=2)))
     _, chosen = length_weighted_activities_solver(pairs, sub_extra=1)

@@ -148,6 +148,21 @@ int main(void) {
     EXPECT(ssc_add_noise(NULL, 5, 300, NULL, 0.01, 1, 0, NULL) == SSC_EINVAL);
     EXPECT(ssc_add_noise(NULL, 0, 3, NULL, 0.01, 1, 0, NULL) == SSC_OK);
 
+    EXPECT(ssc_zscore_concat(NULL, 0, NULL, NULL, NULL, 1, NULL, NULL, 5, NULL, NULL) == SSC_EINVAL);
+    EXPECT(ssc_zscore_concat(NULL, 2, NULL, NULL, NULL, 1, NULL, NULL, 0, NULL, NULL) == SSC_OK);
+    /* host-only geometry: runs to completion under the sanitizers.  Five states on a line, theta 1: (1, 3) and (2, 4) are
+     * the candidate shortcuts (states 1 and 3 coincide, so do 2 and 4 within theta); one of them is taken */
+    {
+        const double path5[10] = {0, 0, 1, 1, 2, 2, 1, 1, 2, 2}, radii2[2] = {1, 1}, bad[2] = {1, 0};
+        uint8_t keep5[5];
+        int32_t kept = -1;
+        EXPECT(ssc_path_shortcut(path5, 5, 2, radii2, 1.0, keep5, &kept) == SSC_OK && kept == 4 && keep5[0] && keep5[4]);
+        EXPECT(ssc_path_shortcut(path5, 0, 2, radii2, 1.0, keep5, &kept) == SSC_OK && kept == 0);
+        EXPECT(ssc_path_shortcut(path5, 5, 2, bad, 1.0, keep5, NULL) == SSC_EINVAL);
+        EXPECT(ssc_path_shortcut(NULL, 5, 2, radii2, 1.0, NULL, NULL) == SSC_EINVAL);
+        EXPECT(ssc_path_shortcut(path5, 5, 9, radii2, 1.0, keep5, NULL) == SSC_EINVAL);
+    }
+
     /* the error text survives until the next failing call of this thread */
     EXPECT(ssc_add_noise(NULL, 5, 300, NULL, 0.01, 1, 0, NULL) == SSC_EINVAL && strstr(ssc_last_error(), "ssc_add_noise") != NULL);
     if (failures) { printf("%d expectation(s) failed\n", failures); return 1; }

@@ -22,7 +22,8 @@ def test_path_statistics_radii_shortcutter(kats):
         radii = N.radii_calc(means, stds, 1, 1, 1)
         assert np.allclose(radii, kats[f"p{c}_radii"], rtol=1e-12)
         dist = N.elliptical_euclidean_distance_function_generator(kats[f"p{c}_radii"])
-        assert np.array_equal(N.path_shortcutter(path, dist, 1), kats[f"p{c}_short"])
+        assert np.array_equal(N.path_shortcutter(path, dist, 1), kats[f"p{c}_short"])                   # libssc's host routine
+        assert np.array_equal(N.path_shortcutter(path, dist, 1, native=False), kats[f"p{c}_short"])     # the numpy statement
     # the reference's own unit-test vectors (tests/utilities/test_numerical.py:10-31, 88-103)
     assert N.path_deltas_stds_and_means_per_dim([[1], [2], [4]])[0][0] == .50
     assert N.length_weighted_activities_solver([[1, 4], [2, 8], [3, 11], [5, 7], [8, 15], [13, 18]])[0] == 13
@@ -128,6 +129,60 @@ def test_rltrain_loop_with_fake_env_and_agent():
     summ = rlTrain(Agent(), Env(), print_results=False, print_steps=False, num_episodes=2, max_steps=100)
     assert summ.episodes == [(7, -7.0)] * 2 and len(summ.best_path) == 8
     assert calls[:4] == ["start", "act", "obs", "act"] and calls.count("end") == 5
+
+
+def test_native_path_shortcut_makes_the_numpy_decisions():
+    """ssc_path_shortcut (csrc/path_geometry.cpp, host code) against the numpy statement of numerical.py:189-246 and against the
+    oracle: random walks in 1-4 dimensions, paths on an integer grid (exact ties in distance AND in shortcut weight, where
+    the reference's `inc >= best` rule decides), paths that revisit states, degenerate lengths, several thetas."""
+    rng = np.random.default_rng(42)
+    cases = []
+    for n in (0, 1, 2, 3, 4, 7, 40, 120, 300):
+        for d in (1, 2, 3, 4):
+            cases.append((np.cumsum(rng.normal(0, 0.01, (n, d)), axis=0), None))
+    for n in (6, 25, 90):
+        for d in (1, 2):
+            grid = np.cumsum(rng.integers(-1, 2, (n, d)), axis=0).astype(np.float64)      # integer lattice walk
+            cases.append((grid, np.ones(d)))
+    loop = np.concatenate([np.linspace([0, 0], [1, 1], 30), np.linspace([1, 1], [0, 0], 30)[1:]])
+    cases.append((loop, np.array([0.05, 0.05])))
+    checked = 0
+    for path, radii in cases:
+        if radii is None:
+            if len(path) < 2:
+                radii = np.ones(path.shape[1])
+            else:
+                stds, means = N.path_deltas_stds_and_means_per_dim(path)
+                radii = N.radii_calc(means, stds, 1, 1, 1)
+        dist = N.elliptical_euclidean_distance_function_generator(radii)
+        for theta in (0.5, 1.0, 2.0):
+            a = N.path_shortcutter(path, dist, theta)
+            if len(path) >= 1:
+                b = N.path_shortcutter(path, dist, theta, native=False)
+                assert a.shape == b.shape and np.array_equal(a, b), (path.shape, theta)
+                if len(path) >= 2:
+                    assert np.array_equal(a, O.path_shortcutter(path, O.distance_func(radii), theta))
+                assert len(a) <= len(path) and (len(path) == 0 or (np.array_equal(a[0], path[0]) and np.array_equal(a[-1], path[-1])))
+                checked += 1
+            else:
+                assert a.shape == (0, path.shape[1])
+    assert checked >= 100
+    # a generic distance function (no radii attribute) still runs the numpy statement
+    plain = lambda x, y: np.sqrt(np.sum((np.asarray(x) - np.asarray(y)) ** 2, axis=-1))
+    p = np.cumsum(rng.normal(0, 0.3, (30, 2)), axis=0)
+    d1 = N.elliptical_euclidean_distance_function_generator([1.0, 1.0])
+    assert np.array_equal(N.path_shortcutter(p, plain, 1.0), N.path_shortcutter(p, d1, 1.0))
+    # argument checks of the C entry point
+    from smartstartcontinuous_amd import _ffi
+    lib = _ffi.lib()
+    assert lib.ssc_path_shortcut(None, 5, 2, None, 1.0, None, None) == _ffi.SSC_EINVAL
+    assert lib.ssc_path_shortcut(None, 5, 9, None, 1.0, None, None) == _ffi.SSC_EINVAL and b"ssc_path_shortcut" in lib.ssc_last_error()
+    r = np.array([1.0, 0.0])
+    k = np.ones(3, np.uint8)
+    pth = np.zeros((3, 2))
+    import ctypes
+    assert lib.ssc_path_shortcut(pth.ctypes.data_as(ctypes.c_void_p), 3, 2, r.ctypes.data_as(ctypes.c_void_p), 1.0,
+                                 k.ctypes.data_as(ctypes.c_void_p), None) == _ffi.SSC_EINVAL          # radii must be positive
 
 
 def test_oracle_and_product_helpers_agree():
