@@ -578,7 +578,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=N_ENVS_PER_GPU)
     ap.add_argument("--chunk", type=int, default=CHUNK)
     ap.add_argument("--gather", choices=["bounded", "full", "none"], default="bounded")
-    ap.add_argument("--gather-every", type=int, default=4,
+    ap.add_argument("--gather-every", type=int, default=8,
                     help="N > 1: exchange the newest transitions every M-th chunk (M x as many steps per message: the "
                          "same records per second in fewer, larger RCCL messages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
