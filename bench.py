@@ -295,6 +295,21 @@ def bench_config4(args, torch, emit=True):
     pb = profiled_pipe_busy()
     if pb is not None:
         res["roofline"]["pipe_busy"] = pb
+    # SURVEY.md section 8(d) names H = 20 (the class default horizon, NND_MB_agent.py:62) beside H = 4: the same launch, 20 steps
+    H20 = 20
+    S20 = torch.empty((H20 + 1, M, d), device="cuda")
+    sp20 = nav.mpc_sampling(N, [-2.0], [2.0], 1234, 0, 0)
+    for _ in range(3):
+        model.do_forward_sim_sampled(s0_p, sp20, M, H20, out=S20)
+    e20 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+    for e0, e1 in e20:
+        e0.record(); model.do_forward_sim_sampled(s0_p, sp20, M, H20, out=S20); e1.record()
+    torch.cuda.synchronize()
+    k20 = sorted(x.elapsed_time(y) for x, y in e20)[len(e20) // 2]
+    res["h20"] = {"kernel_ms": k20, "row_steps_per_s": M * H20 / (k20 * 1e-3), "achieved": flop_row * M * H20 / (k20 * 1e-3) / 1e12,
+                  "unit": "TFLOP/s", "frac": flop_row * M * H20 / (k20 * 1e-3) / 1e12 / 2500.0,
+                  "note": "the forward simulation alone at horizon 20 (median of 10 launches back to back)"}
+    del S20
     if not args.no_cpu_baseline:
         from oracle import ssc_oracle as O               # the checker, timed as the CPU baseline only
         Wn, bn = [w.numpy() for w in Ws], [b.numpy() for b in bs]
@@ -882,7 +897,7 @@ def main():
                              ("smartstart_vec", bench_smartstart_vec)):
                 try:
                     r = fn(a2, torch, emit=False)
-                    other[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline",
+                    other[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline", "h20",
                                                      "navigated_fraction_last_chunk") if k in r}
                     other[name]["workload"] = r["config"]["workload"]
                 except Exception as e:           # noqa: BLE001
