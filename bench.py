@@ -871,6 +871,24 @@ def main():
             steady["frac_at_min"] = per_launch_bytes / (steady["min"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             steady["frac_at_p90"] = per_launch_bytes / (steady["p90"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             result["roofline"]["steady"] = steady
+        if world == 1:
+            # the write ceiling of THIS box, measured beside the kernel ("use the measured ceiling alongside
+            # nominal"): a plain fill of a buffer of the chunk's size, median of 10 launches
+            try:
+                fill = torch.empty(int(per_launch_bytes) // 4, dtype=torch.float32, device=dev)
+                for _ in range(3):
+                    fill.zero_()
+                fe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for e0, e1 in fe:
+                    e0.record(); fill.zero_(); e1.record()
+                torch.cuda.synchronize()
+                fms = sorted(x.elapsed_time(y) for x, y in fe)[len(fe) // 2]
+                result["roofline"]["fill_ceiling"] = {"achieved": fill.numel() * 4 / (fms * 1e-3) / 1e9, "unit": "GB/s", "ms": fms,
+                                                      "bytes": fill.numel() * 4, "kernel": "torch fill (zero_) of a buffer of the chunk's size",
+                                                      "rollout_over_fill": (per_launch_bytes / (kernel_ms * 1e-3)) / (fill.numel() * 4 / (fms * 1e-3))}
+                del fill
+            except Exception as e:           # noqa: BLE001
+                result["roofline"]["fill_ceiling"] = {"error": repr(e)}
         tr = profiled_traffic()
         if tr is not None and n == N_ENVS_PER_GPU and K == CHUNK:
             result["roofline"]["traffic"] = tr[0]
