@@ -295,6 +295,26 @@ def bench_config4(args, torch, emit=True):
     pb = profiled_pipe_busy()
     if pb is not None:
         res["roofline"]["pipe_busy"] = pb
+    # the box's own matrix ceiling at this shape ("confirm with a hipBLASLt [65536,512] x [512,512] probe"):
+    # a plain bf16 library GEMM through torch.matmul, median of 10 launches -- a measurement aid, not part of the product path
+    try:
+        ga = torch.randn((M, 512), device="cuda", dtype=torch.bfloat16)
+        gb = torch.randn((512, 512), device="cuda", dtype=torch.bfloat16)
+        gc = torch.empty((M, 512), device="cuda", dtype=torch.bfloat16)
+        for _ in range(5):
+            torch.matmul(ga, gb, out=gc)
+        ge = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for e0, e1 in ge:
+            e0.record(); torch.matmul(ga, gb, out=gc); e1.record()
+        torch.cuda.synchronize()
+        gms = sorted(x.elapsed_time(y) for x, y in ge)[len(ge) // 2]
+        gtf = 2.0 * M * 512 * 512 / (gms * 1e-3) / 1e12
+        res["roofline"]["gemm_probe"] = {"achieved": gtf, "unit": "TFLOP/s", "ms": gms,
+                                         "kernel": "torch.matmul bf16 [%d,512] x [512,512] (library GEMM)" % M,
+                                         "sim_over_probe": res["roofline"]["achieved"] / gtf}
+        del ga, gb, gc
+    except Exception as e:           # noqa: BLE001
+        res["roofline"]["gemm_probe"] = {"error": repr(e)}
     # SURVEY.md section 8(d) names H = 20 (the class default horizon, NND_MB_agent.py:62) beside H = 4: the same launch, 20 steps
     H20 = 20
     S20 = torch.empty((H20 + 1, M, d), device="cuda")
