@@ -4,7 +4,7 @@ values + KDE + UCB; navigation to the chosen state by the NND_MB navigator; DDPG
 examples/continuous/SmartStart_DDPG_Baselines_example.py shipped under
 data/smart_start_continuous_summaries/ddpg_baselines/{hyper_parameter_search, hyper_parameter_search_2} (stock
 MountainCarContinuous-v0, 25 runs each) and .../good_params_cont_mc_editted (the edited env at power_scalar 0.4, 48 runs).
-DATA only: per run the 1000 (steps, total reward) records and which episodes were smart-start episodes, + the
+(+ the 40 runs of .../ddpg_lr_experiment, groups 3 and 4.)  DATA only: per run the 1000 (steps, total reward) records and which episodes were smart-start episodes, + the
 hyper-parameters they were run with.
 
     python tests/golden/make_smartstart_curves.py        # in the build container; writes smartstart_curves.npz
@@ -35,6 +35,21 @@ for gi, d in enumerate(("hyper_parameter_search", "hyper_parameter_search_2", "g
         assert params.setdefault(gi, p) == p, f                   # every run of a directory used the same hyper-parameters
         assert ("ActionX0.4" in j["name"]) == (gi == 2), j["name"]
 assert params[0] == params[1] == params[2]
+# ---- .../ddpg_lr_experiment: the same example with the base agent's learning rates at 1e-4 (group 3) and 5e-4 (group 4), 20 runs
+# each -- kept for what they show about FAILED runs: 3 of the 40 hold a median return of -83 ... -89 over episodes 90-129 (a fourth -43), i.e. the
+# actor saturated at |a| = 1 (-0.1 * 1000 * a^2), the failure mode this engine's runs show at the same rate
+import re  # noqa: E402
+for f in sorted(glob.glob(os.path.join(BASE, "ddpg_lr_experiment", "*.json"))):
+    lr = float(re.search(r"-lr([0-9.e-]+)_", os.path.basename(f)).group(1))
+    j = json.load(open(f))
+    e = np.asarray(j["episodes"], np.float64)
+    assert e.shape == (1000, 2) and lr in (1e-4, 5e-4), (f, e.shape, lr)
+    m = np.zeros(1000, bool)
+    m[np.asarray(j["smart_start_episodes"], np.int64)] = True
+    steps.append(e[:, 0].astype(np.int16))
+    returns.append(e[:, 1].astype(np.float32))
+    smart.append(m)
+    group.append(3 if lr == 1e-4 else 4)
 np.savez_compressed(os.path.join(OUT, "smartstart_curves.npz"), steps=np.stack(steps), returns=np.stack(returns),
                     smart_start=np.packbits(np.stack(smart), axis=1), group=np.asarray(group, np.int8),
                     param_dict=json.dumps(params[0], sort_keys=True))

@@ -20,9 +20,14 @@ def test_smartstart_curve_fixture(golden_dir):
     """(CPU) the fixture is what make_smartstart_curves.py extracts: 50 stock-env + 48 edited-env runs of 1000 episodes."""
     import json
     g = np.load(f"{golden_dir}/smartstart_curves.npz")
-    assert g["steps"].shape == (98, 1000) and g["returns"].shape == (98, 1000)
-    assert np.bincount(g["group"]).tolist() == [25, 25, 48]
-    smart = np.unpackbits(g["smart_start"], axis=1)[:, :1000]
+    assert g["steps"].shape == (138, 1000) and g["returns"].shape == (138, 1000)
+    assert np.bincount(g["group"]).tolist() == [25, 25, 48, 20, 20]      # stock x 2, edited env, base-agent lr 1e-4 / 5e-4
+    # the failure mode of a DDPG run on this task, in the reference's own archive: the actor saturates at |a| = 1 and the
+    # episode return sits near -0.1 * 999 * 1 -- 3 of the 40 learning-rate runs end their first 130 episodes below -80, a
+    # fourth at -43, a fifth quiet at -3; 35 hold 87 ... 94
+    late_lr = np.median(g["returns"][g["group"] >= 3][:, 90:130].astype(np.float64), axis=1)
+    assert np.sum(late_lr < -80.0) == 3 and np.sum(late_lr < 0.0) == 5 and np.sum(late_lr > 85.0) == 35
+    smart = np.unpackbits(g["smart_start"], axis=1)[:, :1000][g["group"] < 3]
     # eta = 0.5 decaying by 0.99 per episode: sum_k 0.5 * 0.99**k = 50 smart-start episodes expected per run
     assert 32 <= smart.sum(axis=1).min() and smart.sum(axis=1).max() <= 64 and abs(smart.sum(axis=1).mean() - 48.5) < 2.5
     p = json.loads(str(g["param_dict"]))
