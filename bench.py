@@ -625,7 +625,8 @@ def main():
                          "packed payload staged through pinned host memory -- a rehearsal of the N > 1 control flow "
                          "(rank -> env_id0, barriers, MAX-reduced timings, rank-0 JSON) that also runs with several ranks "
                          "on ONE GPU; its numbers are not RCCL numbers")
-    ap.add_argument("--cpu-budget", type=float, default=24.0)
+    ap.add_argument("--cpu-budget", type=float, default=10.0,
+                    help="seconds of CPU work in the cpu_baseline leg (a bounded sample of the same workload)")
     ap.add_argument("--steady-launches", type=int, default=400,
                     help="extra untimed-for-`value` launches after the timed region whose per-launch distribution is "
                          "reported as roofline.steady (N = 1 only; 0 disables)")
@@ -733,8 +734,6 @@ def main():
 
     def one_step(i, events=None):
         chunk = chunks[i & 1]
-        if gather is not None:
-            gather.wait_buffer_free(i & 1)       # the side stream finished reading this buffer
         if events is not None:
             events[0].record()
         env.rollout(K, out=chunk, policy_desc=pd)
@@ -910,7 +909,8 @@ def main():
             except Exception as e:           # noqa: BLE001
                 result["roofline"]["fill_ceiling"] = {"error": repr(e)}
         tr = profiled_traffic()
-        if tr is not None and n == N_ENVS_PER_GPU and K == CHUNK:
+        if tr is not None and n == N_ENVS_PER_GPU and K == CHUNK and gather is None:   # the PMC pass is the N = 1 kernel alone:
+            # a run that also packs and ships transitions moves more bytes than it measured
             result["roofline"]["traffic"] = tr[0]
             result["roofline"]["traffic_source"] = tr[1]
         if world == 1 and not args.no_single_step and n == N_ENVS_PER_GPU:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSC_VERSION 104 /* 0.1.4: ssc_path_shortcut; 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
+#define SSC_VERSION 105 /* 0.1.5: ssc_ou_desc.d_epsilon, ssc_decay_schedule, ssc_replay_append_shard; 0.1.4: ssc_path_shortcut; 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
 
 typedef void *ssc_stream_t; /* hipStream_t */
 
@@ -84,6 +84,9 @@ typedef struct ssc_actor_desc {
 typedef struct ssc_ou_desc {
     float mu, sigma, theta, dt;
     float epsilon; /* current epsilon (decayed per episode by the host, :77-78); 0 disables noise */
+    const float *d_epsilon; /* not NULL: the current epsilon is this DEVICE float, read when the kernel starts (`epsilon` is
+                               ignored and the noise path always runs) -- so that a loop whose decay is computed on the
+                               device (ssc_decay_schedule) never needs the host between two rollouts */
 } ssc_ou_desc;
 
 typedef struct ssc_policy_desc {
@@ -174,6 +177,19 @@ int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *policy, int64_t 
                 const ssc_rollout_state *state, const ssc_transition_log *log,
                 const ssc_episode_ring *ring, double *d_stats, uint64_t seed, uint64_t env_id0,
                 uint64_t step0, ssc_stream_t stream);
+
+/* The per-episode decay of the exploration schedules, computed where the episode counter lives: the reference decays
+ * epsilon (DecayingOrnsteinUhlenbeckActionNoise.reduce_epsilon, DDPG_Baselines_agent.py:77-78, called from end_episode
+ * :255-258) and eta (SmartStartContinuous.reduce_eta, smartexplorationcontinuous.py:372-376) once per finished episode; a
+ * loop over n parallel envs decays once per GENERATION = `per_generation` finished episodes.  One thread:
+ *   g = floor((*d_finished - finished0) / per_generation);  for every schedule i < n_sched, (g - applied) times:
+ *   value_i = max(value_i * factor[i], floor[i])   in fp64, exactly the host's Python arithmetic;
+ * d_state = double[1 + n_sched]: {generations applied, value_0, ...} (caller-initialised: 0, start values);
+ * d_out[i] (device float, may be NULL) receives (float)value_i -- e.g. the ssc_ou_desc.d_epsilon of the next rollout.
+ * d_finished: a device double, e.g. d_stats + 3 of ssc_rollout (finished episodes), finished0 its value when the loop
+ * started.  n_sched <= 4; factor / floor are HOST arrays. */
+int ssc_decay_schedule(const double *d_finished, double finished0, double per_generation, int32_t n_sched, const double *factor,
+                       const double *floor, double *d_state, float *const *d_out, ssc_stream_t stream);
 
 /* Packs the LAST g steps of a transition log into one contiguous buffer for the per-chunk exchange
  * (the rollout gather of NN_Dynamics_Model/collect_samples_threaded.py:31-50 as ONE RCCL message):
@@ -483,6 +499,13 @@ typedef struct ssc_replay_ring {
  * deterministic, so no device counter and no host sync is needed. */
 int ssc_replay_append(const ssc_replay_ring *ring, const ssc_transition_log *log, int32_t K, int64_t n,
                       int64_t start, float reward_scale, ssc_stream_t stream);
+
+/* The same append for ONE SHARD of a step: the chunk holds envs [env_off, env_off + n) of n_total envs per step, its
+ * record (k, e) gets record number start + k * n_total + env_off + e -- the learner of a sharded run appends every
+ * rank's gathered records this way and ends up with the ring of the single-GPU run, whatever the world size.  `start`
+ * counts whole steps of n_total records; K * n_total <= capacity.  ep_run (if kept) is indexed by env_off + e. */
+int ssc_replay_append_shard(const ssc_replay_ring *ring, const ssc_transition_log *log, int32_t K, int64_t n,
+                            int64_t start, int64_t n_total, int64_t env_off, float reward_scale, ssc_stream_t stream);
 
 /* ReplayBuffer.sample_batch (replay_buffer.py:79-91: random.sample, i.e. uniform WITHOUT replacement
  * inside a batch) for n_batches batches at once: d_idx [n_batches][batch_size] row indices in

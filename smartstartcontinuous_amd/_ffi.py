@@ -46,7 +46,8 @@ class ActorDesc(Structure):
 
 
 class OuDesc(Structure):
-    _fields_ = [("mu", c_float), ("sigma", c_float), ("theta", c_float), ("dt", c_float), ("epsilon", c_float)]
+    _fields_ = [("mu", c_float), ("sigma", c_float), ("theta", c_float), ("dt", c_float), ("epsilon", c_float),
+                ("d_epsilon", c_void_p)]
 
 
 class PolicyDesc(Structure):
@@ -166,6 +167,10 @@ _SIGNATURES = {
                                c_void_p]),
     "ssc_replay_append": (c_int, [POINTER(ReplayRing), POINTER(TransitionLog), c_int32, c_int64, c_int64, c_float,
                                   c_void_p]),
+    "ssc_replay_append_shard": (c_int, [POINTER(ReplayRing), POINTER(TransitionLog), c_int32, c_int64, c_int64, c_int64, c_int64,
+                                        c_float, c_void_p]),
+    "ssc_decay_schedule": (c_int, [c_void_p, c_double, c_double, c_int32, POINTER(c_double), POINTER(c_double), c_void_p, POINTER(c_void_p),
+                                   c_void_p]),
     "ssc_replay_sample": (c_int, [c_uint64, c_uint64, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ssc_replay_smart_start_workspace_bytes": (c_size_t, [c_int32]),
     "ssc_replay_smart_start_indices": (c_int, [POINTER(ReplayRing), c_int64, c_int64, c_int32, c_uint64, c_uint64,

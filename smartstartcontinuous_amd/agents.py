@@ -131,10 +131,13 @@ def init_actor_weights(obs_dim, h1, h2, nb_actions, generator=None):
 PARAM_KEYS = ("W1", "b1", "W2", "b2", "W3", "b3")
 
 
-def flatten_params(weights, device):
+def flatten_params(weights, device, extra=0):
     """One flat fp32 tensor in TensorFlow trainable_vars order [W1|b1|W2|b2|W3|b3] plus a dict of VIEWS
-    into it, so that kernels reading the dict see what the learner kernel wrote into the flat array."""
+    into it, so that kernels reading the dict see what the learner kernel wrote into the flat array.
+    ``extra`` zero-initialised floats follow the parameters in the same allocation (flat[-extra:])."""
     parts = [torch.as_tensor(weights[k], dtype=torch.float32).reshape(-1) for k in PARAM_KEYS]
+    if extra:
+        parts.append(torch.zeros(int(extra), dtype=torch.float32))
     flat = torch.cat(parts).to(device).contiguous()
     views, o = {}, 0
     for k in PARAM_KEYS:
@@ -189,11 +192,17 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
             ou_epsilon, ou_min_epsilon, ou_epsilon_decay_factor, mu=ou_mu * np.ones(nb_actions),
             sigma=float(ou_sigma) * np.ones(nb_actions), theta=ou_theta)   # :152-157
         self.ou = dict(mu=ou_mu, sigma=ou_sigma, theta=ou_theta)
+        self.d_epsilon.fill_(float(max(ou_epsilon, 0.0)))
 
     # ---- weights ---------------------------------------------------------------------------
     def set_weights(self, weights):
         """weights: dict W1[obs,h1] b1 W2[h1,h2] b2 W3[h2,act] b3 (TensorFlow layout)."""
-        self.actor_flat, self.weights = flatten_params(weights, self.device)
+        # [parameters | epsilon]: what an actor needs from the learner is ONE contiguous array (one broadcast in the
+        # sharded loop); the trailing float is the device copy of the OU epsilon (as_policy(device_epsilon=True))
+        self.actor_sync, self.weights = flatten_params(weights, self.device, extra=1)
+        self.actor_flat, self.d_epsilon = self.actor_sync[:-1], self.actor_sync[-1:]
+        if hasattr(self, "decaying_ou_action_noise"):
+            self.d_epsilon.fill_(float(max(self.decaying_ou_action_noise.epsilon, 0.0)))
         self.target_actor_flat = self.actor_flat.clone()        # target_init_updates (ddpg_editted.py:331-336)
         self._adam_actor = (torch.zeros_like(self.actor_flat), torch.zeros_like(self.actor_flat))
         if hasattr(self, "_adam_t"):
@@ -259,12 +268,14 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         action = np.clip(action, -1.0, 1.0)                    # :271
         return self.scale(self.scale(action))
 
-    def as_policy(self, precision=None):
-        """The same action path as a fused-rollout policy (current epsilon)."""
+    def as_policy(self, precision=None, device_epsilon=False):
+        """The same action path as a fused-rollout policy (current epsilon).  ``device_epsilon``: the kernel reads
+        epsilon from ``self.d_epsilon`` (kept current by a :class:`rl_train.DecaySchedule`) instead of the host value."""
         n = self.decaying_ou_action_noise
         return ActorPolicy(self.weights, last_layer_tanh=self.lastLayerTanh, precision=precision or "bf16_mfma",
                            ou_mu=float(self.ou["mu"]), ou_sigma=float(self.ou["sigma"]), ou_theta=float(self.ou["theta"]),
-                           ou_dt=n.dt, ou_epsilon=float(max(n.epsilon, 0)), obs_clip=float(self.observation_range[1]))
+                           ou_dt=n.dt, ou_epsilon=float(max(n.epsilon, 0)), obs_clip=float(self.observation_range[1]),
+                           d_ou_epsilon=self.d_epsilon if device_epsilon else None)
 
     def get_state_value(self, state):
         """:197-204 -> DDPG_editted.get_q_value (ddpg_editted.py:274-279): Q(s, pi(s)) without noise.

@@ -137,6 +137,37 @@ int validate_mc_params(const ssc_env_params *p, const char *who) {
     return SSC_OK;
 }
 
+
+// reduce_epsilon / reduce_eta (DDPG_Baselines_agent.py:77-78, smartexplorationcontinuous.py:372-376) once per finished
+// GENERATION of episodes, where the episode counter lives.  One thread; the arithmetic is the host's Python float (fp64).
+struct DecayArgs {
+    const double *finished;
+    double finished0, per_generation;
+    int32_t n_sched;
+    double factor[4], floor_[4];
+    double *state;
+    float *out[4];
+};
+
+__global__ void decay_schedule_kernel(DecayArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double target = floor((*a.finished - a.finished0) / a.per_generation);
+    const double applied = a.state[0];
+    int64_t todo = (int64_t)(target - applied);
+    if (todo < 0) todo = 0;
+    for (int i = 0; i < a.n_sched; ++i) {
+        double v = a.state[1 + i];
+        for (int64_t g = 0; g < todo; ++g) {
+            const double nv = fmax(v * a.factor[i], a.floor_[i]);
+            if (nv == v) break;  // reached its floor (or factor 1): further generations change nothing
+            v = nv;
+        }
+        a.state[1 + i] = v;
+        if (a.out[i] != nullptr) *a.out[i] = (float)v;
+    }
+    if (todo > 0) a.state[0] = applied + (double)todo;
+}
+
 }  // namespace ssc
 
 using namespace ssc;
@@ -223,6 +254,25 @@ int ssc_env_observe(const ssc_env_params *p, int64_t n, const float *d_s0, const
     hipLaunchKernelGGL(env_observe_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream), p->kind, n,
                        d_s0, d_s1, d_obs);
     return check_launch("ssc_env_observe");
+}
+
+
+int ssc_decay_schedule(const double *d_finished, double finished0, double per_generation, int32_t n_sched, const double *factor,
+                       const double *floor, double *d_state, float *const *d_out, ssc_stream_t stream) {
+    SSC_REQUIRE(d_finished != nullptr && d_state != nullptr, "ssc_decay_schedule: NULL device pointer");
+    SSC_REQUIRE(n_sched >= 0 && n_sched <= 4, "ssc_decay_schedule: n_sched = %d not in 0..4", n_sched);
+    SSC_REQUIRE(per_generation > 0.0, "ssc_decay_schedule: per_generation must be positive");
+    if (n_sched == 0) return SSC_OK;
+    SSC_REQUIRE(factor != nullptr && floor != nullptr, "ssc_decay_schedule: NULL factor / floor array");
+    DecayArgs a{};
+    a.finished = d_finished; a.finished0 = finished0; a.per_generation = per_generation; a.n_sched = n_sched; a.state = d_state;
+    for (int i = 0; i < n_sched; ++i) {
+        SSC_REQUIRE(factor[i] >= 0.0, "ssc_decay_schedule: negative factor");
+        a.factor[i] = factor[i]; a.floor_[i] = floor[i];
+        a.out[i] = d_out != nullptr ? d_out[i] : nullptr;
+    }
+    hipLaunchKernelGGL(decay_schedule_kernel, dim3(1), dim3(64), 0, as_stream(stream), a);
+    return check_launch("ssc_decay_schedule");
 }
 
 }  // extern "C"

@@ -20,6 +20,7 @@ struct ReplayAppendArgs {
     ssc_transition_log log;
     int64_t n, row_stride, done_row_stride;
     int64_t first, count, start;  // records [first, first + count) of the chunk go to ring slots (start + j) % capacity
+    int64_t n_total, env_off;     // ssc_replay_append_shard: the chunk is envs [env_off, env_off + n) of n_total per step
     float reward_scale;
 };
 
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(kBlock) void replay_append_kernel(ReplayAppendArgs 
     if (i >= g.count) return;
     const int64_t j = g.first + i;           // record number inside the chunk: step-major, then env
     const int64_t k = j / g.n, e = j - k * g.n;
-    const int64_t pos = (g.start + j) % g.ring.capacity;
+    const int64_t pos = (g.start + k * g.n_total + g.env_off + e) % g.ring.capacity;
     const int64_t src = k * g.row_stride + e;
     const int od = g.ring.obs_dim;
 #pragma unroll
@@ -48,14 +49,14 @@ __global__ __launch_bounds__(kBlock) void replay_append_indexed_kernel(ReplayApp
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= g.n) return;
     const int od = g.ring.obs_dim;
-    int32_t run = g.ring.ep_run[e];
+    int32_t run = g.ring.ep_run[g.env_off + e];
     for (int32_t k = 0; k < K; ++k) {
         const int64_t src = (int64_t)k * g.row_stride + e;
         const uint8_t t = g.log.done[(int64_t)k * g.done_row_stride + e];
         run += 1;
         const int64_t j = (int64_t)k * g.n + e;
         if (j >= g.first) {
-            const int64_t pos = (g.start + j) % g.ring.capacity;
+            const int64_t pos = (g.start + (int64_t)k * g.n_total + g.env_off + e) % g.ring.capacity;
 #pragma unroll
             for (int c = 0; c < SSC_MAX_OBS; ++c)
                 if (c < od) {
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void replay_append_indexed_kernel(ReplayApp
         }
         if (t) run = 0;  // rlTrain breaks on done and the next step opens a new episode (rlTrain.py:97, replay_buffer.py:109-115)
     }
-    g.ring.ep_run[e] = run;
+    g.ring.ep_run[g.env_off + e] = run;
 }
 
 // ---- smart-start index queries --------------------------------------------------------------------------------
@@ -314,35 +315,54 @@ using namespace ssc;
 
 extern "C" {
 
-int ssc_replay_append(const ssc_replay_ring *ring, const ssc_transition_log *log, int32_t K, int64_t n,
-                      int64_t start, float reward_scale, ssc_stream_t stream) {
-    SSC_REQUIRE(ring != nullptr && log != nullptr, "ssc_replay_append: NULL descriptor");
+static int replay_append_impl(const char *fn, const ssc_replay_ring *ring, const ssc_transition_log *log, int32_t K, int64_t n,
+                              int64_t start, int64_t n_total, int64_t env_off, float reward_scale, ssc_stream_t stream) {
+    SSC_REQUIRE(ring != nullptr && log != nullptr, "%s: NULL descriptor", fn);
     SSC_REQUIRE(ring->capacity > 0 && ring->obs_dim >= 1 && ring->obs_dim <= SSC_MAX_OBS && ring->act_dim == 1,
-                "ssc_replay_append: capacity %lld / obs_dim %d / act_dim %d not supported", (long long)ring->capacity,
+                "%s: capacity %lld / obs_dim %d / act_dim %d not supported", fn, (long long)ring->capacity,
                 ring->obs_dim, ring->act_dim);
-    SSC_REQUIRE(K >= 0 && n >= 0 && start >= 0, "ssc_replay_append: negative size");
+    SSC_REQUIRE(K >= 0 && n >= 0 && start >= 0, "%s: negative size", fn);
+    SSC_REQUIRE(env_off >= 0 && env_off + n <= n_total, "%s: shard [%lld, %lld) outside the %lld envs of a step", fn,
+                (long long)env_off, (long long)(env_off + n), (long long)n_total);
     if ((int64_t)K * n == 0) return SSC_OK;
-    SSC_REQUIRE(ring->s && ring->a && ring->r && ring->t && ring->s2, "ssc_replay_append: NULL ring array");
-    SSC_REQUIRE(log->act && log->rew && log->done, "ssc_replay_append: NULL log column");
+    SSC_REQUIRE(ring->s && ring->a && ring->r && ring->t && ring->s2, "%s: NULL ring array", fn);
+    SSC_REQUIRE(log->act && log->rew && log->done, "%s: NULL log column", fn);
     for (int c = 0; c < ring->obs_dim; ++c)
-        SSC_REQUIRE(log->obs[c] && log->obs2[c], "ssc_replay_append: NULL obs column %d", c);
+        SSC_REQUIRE(log->obs[c] && log->obs2[c], "%s: NULL obs column %d", fn, c);
     ReplayAppendArgs g;
-    g.ring = *ring; g.log = *log; g.n = n;
+    g.ring = *ring; g.log = *log; g.n = n; g.n_total = n_total; g.env_off = env_off;
     g.row_stride = log->row_stride ? log->row_stride : n;
     g.done_row_stride = log->done_row_stride ? log->done_row_stride : n;
     const int64_t total = (int64_t)K * n;
-    g.count = total < ring->capacity ? total : ring->capacity;  // older records of the chunk would be overwritten anyway
+    if (n_total == n) {
+        g.count = total < ring->capacity ? total : ring->capacity;  // older records of the chunk would be overwritten anyway
+    } else {
+        SSC_REQUIRE((int64_t)K * n_total <= ring->capacity, "%s: %d steps of %lld envs do not fit a ring of %lld records", fn, K,
+                    (long long)n_total, (long long)ring->capacity);
+        g.count = total;
+    }
     g.first = total - g.count;
     g.start = start; g.reward_scale = reward_scale;
-    SSC_REQUIRE((ring->ep_steps == nullptr) == (ring->ep_run == nullptr), "ssc_replay_append: ep_steps and ep_run come together");
+    SSC_REQUIRE((ring->ep_steps == nullptr) == (ring->ep_run == nullptr), "%s: ep_steps and ep_run come together", fn);
     if (ring->ep_steps != nullptr) {
-        SSC_REQUIRE(start % n == 0, "ssc_replay_append: an indexed ring takes whole steps of n = %lld envs (start = %lld)",
-                    (long long)n, (long long)start);
+        SSC_REQUIRE(start % n_total == 0, "%s: an indexed ring takes whole steps of n = %lld envs (start = %lld)", fn,
+                    (long long)n_total, (long long)start);
         hipLaunchKernelGGL(replay_append_indexed_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream), g, K);
-        return check_launch("ssc_replay_append");
+        return check_launch(fn);
     }
     hipLaunchKernelGGL(replay_append_kernel, dim3(blocks_for(g.count)), dim3(kBlock), 0, as_stream(stream), g);
-    return check_launch("ssc_replay_append");
+    return check_launch(fn);
+}
+
+int ssc_replay_append(const ssc_replay_ring *ring, const ssc_transition_log *log, int32_t K, int64_t n,
+                      int64_t start, float reward_scale, ssc_stream_t stream) {
+    return replay_append_impl("ssc_replay_append", ring, log, K, n, start, n, 0, reward_scale, stream);
+}
+
+int ssc_replay_append_shard(const ssc_replay_ring *ring, const ssc_transition_log *log, int32_t K, int64_t n,
+                            int64_t start, int64_t n_total, int64_t env_off, float reward_scale, ssc_stream_t stream) {
+    SSC_REQUIRE(n_total >= 1, "ssc_replay_append_shard: n_total = %lld", (long long)n_total);
+    return replay_append_impl("ssc_replay_append_shard", ring, log, K, n, start, n_total, env_off, reward_scale, stream);
 }
 
 static int smart_table_size(int32_t n_ss) {

@@ -51,6 +51,7 @@ struct PolicyArgs {
     float act_low, act_span, act_high;
     ActorWeights actor;
     float ou_mu, ou_sigma, ou_theta, ou_dt, ou_eps;
+    const float *d_eps;  // ssc_ou_desc::d_epsilon: the device value wins over ou_eps and the noise path always runs
 };
 
 // ------------------------------------------------------------------------------- envs --
@@ -145,14 +146,15 @@ struct ActorPolicy {
     u32x4 cache;
     float ou_x, mu, sig_sqrt_dt, theta_dt, eps;
     float low, high, obs_clip;
-    bool identity_scale;
+    bool identity_scale, noisy;
 
     __device__ void init(const PolicyArgs &pa, const RolloutArgs &ra, int64_t i) {
         net.init(pa.actor);
         mu = pa.ou_mu;
         sig_sqrt_dt = pa.ou_sigma * sqrtf(pa.ou_dt);
         theta_dt = pa.ou_theta * pa.ou_dt;
-        eps = fmaxf(pa.ou_eps, 0.0f);  // DDPG_Baselines_agent.py:74
+        eps = fmaxf(pa.d_eps != nullptr ? *pa.d_eps : pa.ou_eps, 0.0f);  // DDPG_Baselines_agent.py:74
+        noisy = pa.d_eps != nullptr || eps > 0.0f;
         ou_x = (ra.st.ou_x != nullptr) ? ra.st.ou_x[i] : 0.0f;
         low = pa.act_low;
         high = pa.act_high;
@@ -168,7 +170,7 @@ struct ActorPolicy {
 #pragma unroll
         for (int c = 0; c < OBS; ++c) oc[c] = clip_obs(obs[c], obs_clip);
         float a = net.forward(oc);
-        if (eps > 0.0f) {  // wave-uniform
+        if (noisy) {  // wave-uniform
             if (first || (t & 3) == 0) cache = rng_words(seed, env_id, t >> 2, TAG_OU);
             const float g = ou_gaussian_from_words(cache, t);
             ou_x = fmaf(sig_sqrt_dt, g, fmaf(theta_dt, mu - ou_x, ou_x));
@@ -204,7 +206,7 @@ struct ActorPolicyFused {
         mu = pa.ou_mu;
         sig_sqrt_dt = pa.ou_sigma * sqrtf(pa.ou_dt);
         theta_dt = pa.ou_theta * pa.ou_dt;
-        eps = pa.ou_eps;  // > 0 (dispatch)
+        eps = pa.d_eps != nullptr ? fmaxf(*pa.d_eps, 0.0f) : pa.ou_eps;  // host value: > 0 (dispatch)
         ou_x = ra.st.ou_x[i];
     }
     // Box-Muller like gaussian_f32 in three pieces, so that the radius and the sin output of a word pair computed in
@@ -560,7 +562,7 @@ static int dispatch_policy(const typename EnvT::Const &ec, const ssc_policy_desc
             // -- DDPG's (-5, 5) against |pos| <= 1.2, |vel| <= 0.07 -- never acts, so the fused policy skips it)
             const float obs_bound = fmaxf(fmaxf(fabsf(ec.min_position), fabsf(ec.max_position)), fabsf(ec.max_speed));
             const bool clip_inert = !(a.obs_clip > 0.0f) || a.obs_clip >= obs_bound;
-            if (a.h1 <= 64 && a.h2 <= 32 && pa.act_low == -1.0f && pa.act_high == 1.0f && pa.ou_eps > 0.0f && clip_inert) {
+            if (a.h1 <= 64 && a.h2 <= 32 && pa.act_low == -1.0f && pa.act_high == 1.0f && (pa.ou_eps > 0.0f || pa.d_eps != nullptr) && clip_inert) {
                 if (a.last_layer_tanh) return launch_rollout<EnvT, ActorPolicyFused<true>>(ec, pa, ra, stream);
                 return launch_rollout<EnvT, ActorPolicyFused<false>>(ec, pa, ra, stream);
             }
@@ -843,7 +845,8 @@ extern "C" int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *polic
         pa.ou_theta = policy->ou.theta;
         pa.ou_dt = policy->ou.dt;
         pa.ou_eps = policy->ou.epsilon;
-        SSC_REQUIRE(!(pa.ou_eps > 0.0f) || state->ou_x != nullptr, "ssc_rollout: OU noise needs state->ou_x");
+        pa.d_eps = policy->ou.d_epsilon;
+        SSC_REQUIRE(!(pa.ou_eps > 0.0f || pa.d_eps != nullptr) || state->ou_x != nullptr, "ssc_rollout: OU noise needs state->ou_x");
     }
     if (p->kind == SSC_ENV_MOUNTAINCAR) {
         if (int rc = validate_mc_params(p, "ssc_rollout")) return rc;

@@ -319,6 +319,25 @@ class DeviceReplayBuffer:
                                                        self.count, float(reward_scale), self._stream()))
         self.count += K * chunk.N
 
+    def append_shards(self, shards, n_total, reward_scale=1.0):
+        """One step-major append of ``n_total`` envs per step delivered as shards: ``shards`` = [(chunk, env_off), ...],
+        every chunk holding the same K steps of envs [env_off, env_off + chunk.N) (``ssc_replay_append_shard``).  The ring
+        ends up exactly as after ``append_chunk`` of the one chunk over all ``n_total`` envs -- the learner of a sharded
+        run appends every rank's gathered records this way (record number = step * n_total + global env)."""
+        if self.track_episodes and n_total != self.n_envs:
+            raise ValueError(f"this ring indexes episodes of {self.n_envs} envs, the shards cover {n_total}")
+        K = shards[0][0].K
+        if sum(c.N for c, _ in shards) != n_total or any(c.K != K for c, _ in shards):
+            raise ValueError("the shards must cover the n_total envs of the same K steps exactly once")
+        ring = self.ring_struct()
+        with self._torch.cuda.device(self.device):
+            for chunk, env_off in shards:
+                log = chunk.as_struct()
+                self._ffi.check(self.lib.ssc_replay_append_shard(self._ctypes.byref(ring), self._ctypes.byref(log), K, chunk.N,
+                                                                 self.count, int(n_total), int(env_off), float(reward_scale),
+                                                                 self._stream()))
+        self.count += K * int(n_total)
+
     def sample_indices(self, n_batches, batch_size):
         """int32 [n_batches, batch_size] row indices, distinct inside a batch."""
         if len(self) < batch_size:

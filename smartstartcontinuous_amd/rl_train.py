@@ -235,8 +235,69 @@ def rl_train_vec(env, policy, num_chunks, chunk_steps=1024, ring_capacity=1 << 2
     return summary
 
 
+class DecaySchedule:
+    """The per-episode decays of the reference -- ``reduce_epsilon`` (DDPG_Baselines_agent.py:77-78, from end_episode
+    :255-258) and ``reduce_eta`` (smartexplorationcontinuous.py:372-376) -- for a loop over n parallel envs, kept on the
+    DEVICE: one decay per GENERATION = ``per_generation`` finished episodes (once per episode per env), computed by
+    ``ssc_decay_schedule`` from the finished-episode counter the rollout kernel accumulates (``env.stats[3]``).  The
+    arithmetic is the host's (fp64 ``value = max(value * factor, floor)``, one application per generation), so the
+    values equal ``reduce_epsilon()`` called ``generations`` times -- but no chunk boundary needs the host any more.
+
+    ``entries``: list of (start value, factor, floor, out) with ``out`` a 1-element fp32 device tensor (or None) that
+    receives the current value -- e.g. ``agent.d_epsilon``, which ``agent.as_policy(device_epsilon=True)`` hands to the
+    rollout kernel."""
+
+    def __init__(self, device, per_generation, entries):
+        import ctypes
+        import torch
+        from . import _ffi
+        self._ffi, self._ct, self._torch = _ffi, ctypes, torch
+        self.device = torch.device(device)
+        self.per_generation = float(per_generation)
+        self.n = len(entries)
+        if not 1 <= self.n <= 4:
+            raise ValueError("1..4 schedules")
+        self._factor = (ctypes.c_double * self.n)(*[float(e[1]) for e in entries])
+        self._floor = (ctypes.c_double * self.n)(*[float(e[2]) for e in entries])
+        self.state = torch.tensor([0.0] + [float(e[0]) for e in entries], dtype=torch.float64, device=self.device)
+        self.outs = [e[3] for e in entries]
+        self._out_ptrs = (ctypes.c_void_p * self.n)(*[None if o is None else o.data_ptr() for o in self.outs])
+        for e in entries:
+            if e[3] is not None:
+                e[3].fill_(float(e[0]))
+
+    def update(self, finished, finished0=0.0):
+        """Enqueue the decay on the current stream; ``finished``: device fp64 view of the finished-episode counter,
+        ``finished0``: what it read when the loop started."""
+        ffi, ct, torch = self._ffi, self._ct, self._torch
+        with torch.cuda.device(self.device):
+            ffi.check(ffi.lib().ssc_decay_schedule(ffi.ptr(finished), float(finished0), self.per_generation, self.n, self._factor, self._floor,
+                                                   ffi.ptr(self.state), self._out_ptrs,
+                                                   ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def read(self):
+        """(generations applied, [current values]) -- a device -> host read (synchronises the current stream)."""
+        st = self.state.cpu().tolist()
+        return int(st[0]), st[1:]
+
+
+def epsilon_schedule(agent, per_generation, device=None):
+    """DecaySchedule of one agent's OU epsilon, starting from its current host value and writing ``agent.d_epsilon``."""
+    n = agent.decaying_ou_action_noise
+    return DecaySchedule(device if device is not None else agent.device, per_generation,
+                         [(float(n.epsilon), n.epsilon_decay_factor, n.min_epsilon, agent.d_epsilon)])
+
+
+def default_drain_every(ring_capacity, n_envs, chunk_steps, shortest_episode=64):
+    """How many chunks an episode ring of ``ring_capacity`` records holds when no episode is shorter than
+    ``shortest_episode`` steps (clamped to 1..16)."""
+    per_chunk = n_envs * -(-int(chunk_steps) // shortest_episode)
+    return int(max(1, min(16, ring_capacity // max(per_chunk, 1))))
+
+
 def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1 << 20, train_iters=None,
-                      replay_last_steps=None, seed=0, ring_capacity=1 << 20, track_episodes=False, overlap=False):
+                      replay_last_steps=None, seed=0, ring_capacity=1 << 20, track_episodes=False, overlap=False,
+                      drain_every=None):
     """Actor-learner loop entirely in HBM: every chunk is a fused rollout of ``chunk_steps`` steps of all
     ``env.n`` envs under the agent's current actor (+ OU noise), appended to a device replay ring, followed
     by ``train_iters`` DDPG iterations (default ``agent.num_train_iterations``) on batches drawn from it.
@@ -244,6 +305,14 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
     (rlTrain.py:75-100, DDPG_Baselines_agent.py:238-273).  ``track_episodes`` keeps the episode index in the device
     ring as well, so that ``smartstart.device_smart_start_path(replay, agent, radii, n_ss)`` can pick a smart-start
     state and recover the path to it without the replay contents leaving HBM.
+
+    Nothing at a chunk boundary needs the host: epsilon decays once per generation of finished episodes ON THE DEVICE
+    (:class:`DecaySchedule` behind each rollout, the kernel reads ``agent.d_epsilon``), and the finished-episode records
+    are read back every ``drain_every`` chunks only (default: as many chunks as the episode ring holds,
+    :func:`default_drain_every`; a ring that overflows drops records and counts them in
+    ``summary.dropped_episode_records``).  The host therefore runs ahead of the GPU and the chunk costs what its
+    kernels cost.  The host-side ``agent.decaying_ou_action_noise.epsilon`` is brought up to date when the loop ends.
+
     ``overlap=True`` rolls chunk i+1 on a second stream WHILE the learner runs its iterations on chunk i: the rollout
     then acts with a snapshot of the actor taken before those iterations (one chunk stale -- the single-GPU form of
     ``rl_train_sharded_ddpg(pipelined=True)``); everything else (replay contents, epsilon decay per finished
@@ -259,22 +328,32 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
     replay = DeviceReplayBuffer(replay_capacity, env.obs_dim, 1, env.device, seed=seed, track_episodes=track_episodes,
                                 n_envs=env.n, max_path_len=(env.spec.max_episode_steps or 1000) + 1)
     losses = []
-    generations = 0.0   # finished episodes / env.n: epsilon decays once per episode PER ENV (DDPG_Baselines_agent.py:255-258)
-    with torch.cuda.device(env.device):                  # env.device need not be the process's current device
-        side = torch.cuda.Stream(env.device)             # episode-record readback, off the learner's stream
-        rolled = torch.cuda.Event()
+    if drain_every is None:
+        drain_every = default_drain_every(ring_capacity, env.n, chunk_steps)
+    schedule = epsilon_schedule(agent, env.n, env.device)   # once per episode PER ENV (DDPG_Baselines_agent.py:255-258)
+    finished, finished0 = env.stats[3:4], float(env.stats[3].item())   # the env may have run before: count from here
+    dropped = 0
 
-    def decay(n_finished):
-        nonlocal generations
-        generations += n_finished / float(env.n)
-        while generations >= 1.0:
-            agent.decaying_ou_action_noise.reduce_epsilon()
-            generations -= 1.0
+    def after_rollout():
+        schedule.update(finished, finished0)
+
+    def drain():
+        nonlocal dropped
+        (ids, lens, rets), d = ring.drain()
+        dropped += d
+        summary.extend_records(lens, rets)
+
+    def finish():
+        drain()
+        summary.dropped_episode_records = dropped
+        _g, (eps,) = schedule.read()
+        agent.decaying_ou_action_noise.epsilon = eps
 
     if overlap:
         from .vec_env import ActorPolicy
         cur = torch.cuda.current_stream(env.device)
-        act = torch.cuda.Stream(env.device)              # the rollouts' stream
+        with torch.cuda.device(env.device):              # env.device need not be the process's current device
+            act = torch.cuda.Stream(env.device)          # the rollouts' stream
         chunks = [chunk, TransitionChunk(env.obs_dim, chunk_steps, env.n, env.device)]
         snap = agent.actor_flat.clone()                  # the weights the NEXT rollout acts with
         views, o = {}, 0
@@ -284,16 +363,20 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
         rolled2 = [torch.cuda.Event(), torch.cuda.Event()]
         appended = [torch.cuda.Event(), torch.cuda.Event()]
         snap_ready = torch.cuda.Event()
+        live = agent.as_policy(device_epsilon=True)
+        pd = env.policy_desc(ActorPolicy(views, last_layer_tanh=live.last_layer_tanh, precision=live.precision, ou_mu=live.ou_mu,
+                                         ou_sigma=live.ou_sigma, ou_theta=live.ou_theta, ou_dt=live.ou_dt,
+                                         obs_clip=live.obs_clip, d_ou_epsilon=agent.d_epsilon))
+        act.wait_stream(cur)
+
+        drained = torch.cuda.Event()
 
         def launch_rollout(b, wait_for):
-            live = agent.as_policy()                     # OU parameters and the current epsilon
-            pol = ActorPolicy(views, last_layer_tanh=live.last_layer_tanh, precision=live.precision, ou_mu=live.ou_mu,
-                              ou_sigma=live.ou_sigma, ou_theta=live.ou_theta, ou_dt=live.ou_dt, ou_epsilon=live.ou_epsilon,
-                              obs_clip=live.obs_clip)
             for e in wait_for:
                 act.wait_event(e)
             with torch.cuda.stream(act):
-                env.rollout(chunk_steps, out=chunks[b], ring=ring, policy_desc=env.policy_desc(pol))
+                env.rollout(chunk_steps, out=chunks[b], ring=ring, policy_desc=pd)
+                after_rollout()
                 rolled2[b].record(act)
 
         snap_ready.record(cur)
@@ -305,31 +388,31 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
             appended[b].record(cur)
             snap.copy_(agent.actor_flat)                 # behind train i-1 on this stream, in front of train i
             snap_ready.record(cur)
-            l = agent.train_from(replay, train_iters)    # queued BEFORE the host blocks on the episode records below
+            l = agent.train_from(replay, train_iters)
             if l is not None:
                 losses.append(l)
-            (ids, lens, rets), _d, drained = ring.drain_overlapped(side, rolled2[b])
-            summary.extend_records(lens, rets)
-            decay(len(lens))
+            extra = []
+            if (i + 1) % drain_every == 0:               # the ring holds the records of chunks <= i; rollout i+1 is not queued yet
+                drain()
+                drained.record(cur)                      # ... and must not start before the cursor reset
+                extra = [drained]
             if i + 1 < num_chunks:                       # chunk buffer b^1 was last read by append i-1
-                launch_rollout(b ^ 1, [snap_ready, drained] + ([appended[b ^ 1]] if i >= 1 else []))
+                launch_rollout(b ^ 1, [snap_ready] + extra + ([appended[b ^ 1]] if i >= 1 else []))
         cur.wait_stream(act)
+        finish()
         return summary, losses, replay
 
-    for _ in range(num_chunks):
-        pd = env.policy_desc(agent.as_policy())          # weights are views into the flat parameter arrays
+    pd = env.policy_desc(agent.as_policy(device_epsilon=True))   # weights are views into the flat parameter arrays
+    for i in range(num_chunks):
         out = env.rollout(chunk_steps, out=chunk, ring=ring, policy_desc=pd)
-        rolled.record(torch.cuda.current_stream(env.device))
+        after_rollout()
         replay.append_chunk(out, reward_scale=agent.reward_scale, last_steps=replay_last_steps)
         l = agent.train_from(replay, train_iters)
         if l is not None:
             losses.append(l)
-        # the host needs the finished episodes of THIS chunk before it can launch the next one (epsilon decay); it waits
-        # for the rollout only -- append + learner iterations are already queued and run while the records are read
-        (ids, lens, rets), _d, drained = ring.drain_overlapped(side, rolled)
-        torch.cuda.current_stream(env.device).wait_event(drained)
-        summary.extend_records(lens, rets)
-        decay(len(lens))
+        if (i + 1) % drain_every == 0:
+            drain()
+    finish()
     return summary, losses, replay
 
 

@@ -158,11 +158,6 @@ class TransitionGather:
         slot = self.last_slot if slot is None else slot
         return self._stats_view(self.recv[slot][src_rank], self.n_all[src_rank])
 
-    def wait_buffer_free(self, slot):
-        """Kept for callers that overwrite a chunk from another stream; with ``submit`` the pack runs
-        in order on the producing stream, so the chunk buffer is free as soon as ``submit`` returns."""
-        return None
-
     def wait_received(self, slot):
         """Make the current stream wait until receive slot ``slot`` holds its chunk (dst only; no host sync)."""
         if self.cuda and self.received[slot] is not None:
@@ -259,34 +254,45 @@ def _views_like(flat, like):
 
 def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, learner=0, gather_steps=None,
                           replay_capacity=1 << 20, train_iters=None, seed=0, group=None, ring_capacity=1 << 20,
-                          pipelined=False):
+                          pipelined=False, drain_every=None, on_chunk=None):
     """The actor-learner loop of ``rl_train_vec_ddpg`` over ``world`` GPUs (one process each, ``env`` = this rank's
     shard of one global env-id space).  Per chunk:
 
       every rank     rolls its envs out under the actor (fused kernel, OU noise), packs the last
                      ``gather_steps`` steps (default: 2^20 / N_total) and joins ONE gather to the learner;
-      learner rank   appends every rank's records to its device replay ring, runs ``train_iters`` DDPG iterations
-                     (``ssc_ddpg_train``), then
-      every rank     joins ONE broadcast of the learner's flat actor parameters (``MpiAdam.sync``,
-                     ddpg_editted.py:331-336).
+      learner rank   appends every rank's records to its device replay ring -- record number = step * N_total + global
+                     env id (``append_shards``), i.e. the ring of the single-GPU run whatever the world size --, runs
+                     ``train_iters`` DDPG iterations (``ssc_ddpg_train``), decays epsilon once per generation of
+                     N_total finished episodes out of the gathered statistics (:class:`rl_train.DecaySchedule`), then
+      every rank     joins ONE broadcast of the learner's ``agent.actor_sync`` = [flat actor parameters | epsilon]
+                     (``MpiAdam.sync``, ddpg_editted.py:331-336); the rollout kernel reads both where they landed.
+
+    Envs are keyed by their GLOBAL id and the schedule by GLOBAL counts, so the transitions every env produces, the
+    learner's replay ring and every parameter generation are the same for any world size (tests: 2 ranks == 1 rank, bit
+    for bit).  Nothing at a chunk boundary reads the device: the finished-episode records go to the host every
+    ``drain_every`` chunks.
 
     ``pipelined=False`` (the reference's own ordering: act, store, train, act ...): the gather is waited for, the
-    learner trains, and the broadcast lands in ``agent.actor_flat`` -- which the rollout policy reads through views --
+    learner trains, and the broadcast lands in ``agent.actor_sync`` -- which the rollout policy reads through views --
     before the next chunk starts.  Every actor idles while the learner trains.
 
     ``pipelined=True``: nothing on a rollout stream waits for the learner -- on the learner rank either: the append
     and the DDPG iterations run on a LEARNER STREAM of their own (ordered against the receive slots and the parameter
-    buffers by events), gather AND broadcast run on the side stream; the parameters are double-buffered (generation g,
-    = trained on the chunks <= g, lands in buffer g & 1) and chunk j is rolled with generation j - 2, so the learner
-    trains on chunk j-1 while every rank (its own included) already rolls chunk j: ONE CHUNK STALE compared with the
-    synchronous loop (which rolls chunk j with generation j - 1).  The per-chunk critical path is
-    max(T_rollout, T_gather + T_train + T_broadcast) instead of their sum.  The receive side is double-buffered too
-    (``TransitionGather``), and the gather that refills a receive slot waits for the learner stream to have consumed it.
+    buffers by events), gather AND broadcast run on the side stream; the synchronised array is double-buffered
+    (generation g = parameters trained on the chunks <= g + the epsilon after chunk g, lands in buffer g & 1) and chunk j
+    is rolled with generation j - 2, so the learner trains on chunk j-1 while every rank (its own included) already rolls
+    chunk j: ONE CHUNK STALE compared with the synchronous loop (which rolls chunk j with generation j - 1).  The
+    per-chunk critical path is max(T_rollout, T_gather + T_train + T_broadcast) instead of their sum.  The receive side
+    is double-buffered too (``TransitionGather``), and the gather that refills a receive slot waits for the learner
+    stream to have consumed it.
+
+    ``on_chunk(i, chunk, env)`` -- if given -- is called right after rollout i was enqueued (same stream), e.g. to copy
+    the chunk's transition log.
 
     Returns (Summary of THIS rank's finished episodes, losses per chunk [learner only], replay [learner only])."""
     from .replay_buffer import DeviceReplayBuffer
-    from .rl_train import Summary
-    from .vec_env import ActorPolicy, EpisodeRing, TransitionChunk
+    from .rl_train import Summary, default_drain_every, epsilon_schedule
+    from .vec_env import EpisodeRing, TransitionChunk
     gather = TransitionGather(env.obs_dim, 1, env.n, world, rank, env.device, dst=learner, group=group) \
         if gather_steps is None else None
     if gather is not None:      # the default G needs the TRUE global N (shards may differ by one env)
@@ -295,50 +301,73 @@ def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, lear
     else:
         g, n_all = int(gather_steps), None
     gather = TransitionGather(env.obs_dim, g, env.n, world, rank, env.device, dst=learner, group=group, n_all=n_all)
+    n_total = gather.n_total
+    env_off = [sum(gather.n_all[:r]) for r in range(world)]
     summary = Summary("sharded_ddpg_" + env.spec.id)
     ring = EpisodeRing(ring_capacity, env.device)
+    if drain_every is None:
+        drain_every = default_drain_every(ring_capacity, env.n, chunk_steps)
     chunks = [TransitionChunk(env.obs_dim, chunk_steps, env.n, env.device) for _ in range(2 if pipelined else 1)]
     replay = DeviceReplayBuffer(replay_capacity, env.obs_dim, 1, env.device, seed=seed) if rank == learner else None
-    broadcast_flat(agent.actor_flat, src=learner, group=group)          # MpiAdam.sync: start from the root's parameters
+    schedule = epsilon_schedule(agent, n_total, env.device) if rank == learner else None
+    broadcast_flat(agent.actor_sync, src=learner, group=group)          # MpiAdam.sync: start from the root's parameters (+ epsilon)
+    stats0 = env.stats.clone()                                          # the statistics that travel count from here
+    delta = torch.zeros_like(env.stats)
+    finished = torch.zeros(1, dtype=torch.float64, device=env.device)   # learner: episodes finished on all ranks
     losses = []
-    generations = 0.0
+    dropped = 0
     cuda = env.device.type == "cuda" and gather.side is not None
     if pipelined:
-        wbuf = [agent.actor_flat.clone(), agent.actor_flat.clone()]     # generation g lives in wbuf[g & 1]
-        wviews = [_views_like(b, agent.weights) for b in wbuf]
+        wbuf = [agent.actor_sync.clone(), agent.actor_sync.clone()]     # generation g lives in wbuf[g & 1]
+        base = agent.as_policy()
+        pds = [env.policy_desc(dataclasses.replace(base, weights=_views_like(b[:-1], agent.weights), d_ou_epsilon=b[-1:]))
+               for b in wbuf]                                           # the SAME policy the synchronous loop builds
         bcast_done = [None, None]
         learned = [None, None]                                          # learner stream is done with recv[slot] / wrote wbuf[slot]
         lstream = torch.cuda.Stream(env.device) if (cuda and rank == learner) else None
         if lstream is not None:
             lstream.wait_stream(torch.cuda.current_stream(env.device))  # replay / parameter setup happened on the main stream
+    else:
+        pd = env.policy_desc(agent.as_policy(device_epsilon=True))
 
     def learn(slot):
         gather.wait_received(slot)
-        for src in range(world):
-            replay.append_chunk(TransitionChunk.from_columns(*gather.unpack(src, slot)), reward_scale=agent.reward_scale)
+        replay.append_shards([(TransitionChunk.from_columns(*gather.unpack(src, slot)), env_off[src]) for src in range(world)],
+                             n_total, reward_scale=agent.reward_scale)
         l = agent.train_from(replay, train_iters)
         if l is not None:
             losses.append(l)
+        torch.sum(torch.stack([gather.received_stats(src, slot)[3] for src in range(world)]), dim=0, keepdim=True, out=finished)
+        schedule.update(finished)                                       # -> agent.d_epsilon, the tail of agent.actor_sync
+
+    def drain():
+        nonlocal dropped
+        (ids, lens, rets), d = ring.drain()
+        dropped += d
+        summary.extend_records(lens, rets)
 
     for i in range(num_chunks):
         slot = i & 1
         if not pipelined:
-            pd = env.policy_desc(agent.as_policy())
             env.rollout(chunk_steps, out=chunks[0], ring=ring, policy_desc=pd)
-            gather.submit(chunks[0], slot, env.stats)
+            if on_chunk is not None:
+                on_chunk(i, chunks[0], env)
+            torch.sub(env.stats, stats0, out=delta)
+            gather.submit(chunks[0], slot, delta)
             gather.finish()
             if rank == learner:
                 learn(slot)
-            broadcast_flat(agent.actor_flat, src=learner, group=group)
+            broadcast_flat(agent.actor_sync, src=learner, group=group)
         else:
             main = torch.cuda.current_stream(env.device) if cuda else None
             if cuda and bcast_done[slot] is not None:
                 main.wait_event(bcast_done[slot])                       # generation i-2 has landed in wbuf[slot]
-            # the SAME policy the synchronous loop builds (observation clip included), reading generation i-2
-            pol = dataclasses.replace(agent.as_policy(), weights=wviews[slot])
-            env.rollout(chunk_steps, out=chunks[slot], ring=ring, policy_desc=env.policy_desc(pol))
+            env.rollout(chunk_steps, out=chunks[slot], ring=ring, policy_desc=pds[slot])   # reads generation i-2
+            if on_chunk is not None:
+                on_chunk(i, chunks[slot], env)
+            torch.sub(env.stats, stats0, out=delta)
             # side stream: gather(i) after this rollout -- and after the learner stream has read chunk i-2 out of recv[slot]
-            gather.submit(chunks[slot], slot, env.stats, after=learned[slot])
+            gather.submit(chunks[slot], slot, delta, after=learned[slot])
             if cuda:
                 trained = torch.cuda.Event()
                 if rank == learner:
@@ -346,7 +375,7 @@ def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, lear
                     # wbuf[slot]), trains generation i and parks it in wbuf[slot]; the main stream goes on to rollout(i+1)
                     with torch.cuda.stream(lstream):
                         learn(slot)
-                        wbuf[slot].copy_(agent.actor_flat)
+                        wbuf[slot].copy_(agent.actor_sync)
                         trained.record(lstream)
                     learned[slot] = trained
                 else:
@@ -360,20 +389,19 @@ def rl_train_sharded_ddpg(env, agent, num_chunks, chunk_steps, rank, world, lear
             else:
                 if rank == learner:
                     learn(slot)
-                    wbuf[slot].copy_(agent.actor_flat)
+                    wbuf[slot].copy_(agent.actor_sync)
                 broadcast_flat(wbuf[slot], src=learner, group=group)
-        (ids, lens, rets), _d = ring.drain()
-        summary.extend_records(lens, rets)
-        generations += len(lens) / float(env.n)      # epsilon decays once per episode per env (DDPG_Baselines_agent.py:255-258)
-        while generations >= 1.0:
-            agent.decaying_ou_action_noise.reduce_epsilon()
-            generations -= 1.0
+        if (i + 1) % drain_every == 0:
+            drain()
     if pipelined:
         gather.finish()
         if lstream is not None:
             torch.cuda.current_stream(env.device).wait_stream(lstream)
         if rank != learner:
             # the actors end with the newest generation they received
-            newest = (num_chunks - 1) & 1
-            agent.actor_flat.copy_(wbuf[newest])
+            agent.actor_sync.copy_(wbuf[(num_chunks - 1) & 1])
+    drain()
+    summary.dropped_episode_records = dropped
+    # the host-side noise object follows the device schedule (exact on the learner, the broadcast fp32 value elsewhere)
+    agent.decaying_ou_action_noise.epsilon = schedule.read()[1][0] if rank == learner else float(agent.d_epsilon.item())
     return summary, losses, replay

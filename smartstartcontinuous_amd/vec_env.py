@@ -72,6 +72,8 @@ class ActorPolicy:
     ou_dt: float = 1e-2
     ou_epsilon: float = 1.0
     obs_clip: float = 0.0              # > 0: the actor sees clip(obs, -obs_clip, obs_clip) (ddpg_editted.py:106-109: 5.0)
+    d_ou_epsilon: object = None        # a 1-element fp32 device tensor: the kernel reads epsilon from it (ou_epsilon is
+                                       # ignored) -- rl_train.DecaySchedule keeps it current without the host
 
 
 @dataclass
@@ -325,6 +327,12 @@ class VecEnv:
         a.precision = {"f32": _ffi.SSC_PREC_F32, "bf16_mfma": _ffi.SSC_PREC_BF16_MFMA}[policy.precision]
         pd.ou.mu, pd.ou.sigma, pd.ou.theta = policy.ou_mu, policy.ou_sigma, policy.ou_theta
         pd.ou.dt, pd.ou.epsilon = policy.ou_dt, policy.ou_epsilon
+        if policy.d_ou_epsilon is not None:
+            d = policy.d_ou_epsilon
+            if d.dtype != torch.float32 or d.numel() != 1 or not d.is_cuda or d.device.index != self.s0.device.index:
+                raise ValueError("d_ou_epsilon must be ONE fp32 value on the env's device")
+            pd.ou.d_epsilon = d.data_ptr()
+            w["_d_eps"] = d
         return pd, w  # keep the tensors alive for the duration of the launch
 
     def rollout(self, K, policy=None, out=None, ring=None, log=True, policy_desc=None):

@@ -164,12 +164,14 @@ def test_sharded_actor_learner_loop_world1_equals_vec_loop(ssc):
     env_d, agent_d = setup()
     replay_d = DeviceReplayBuffer(4096, 2, 1, env_d.device, seed=3)
     gens = {-2: agent_d.actor_flat.clone(), -1: agent_d.actor_flat.clone()}
+    eps_gen = {-2: agent_d.decaying_ou_action_noise.epsilon, -1: agent_d.decaying_ou_action_noise.epsilon}
     losses_d = []
     from smartstartcontinuous_amd.vec_env import EpisodeRing
     ring_d, finished = EpisodeRing(1 << 16, env_d.device), 0.0
     for j in range(5):
         pol = agent_d.as_policy()
         pol.weights = _views_like(gens[j - 2], agent_d.weights)
+        pol.ou_epsilon = float(eps_gen[j - 2])          # epsilon is part of the generation (rides in the broadcast)
         chunk = env_d.rollout(48, pol, ring=ring_d)
         tail = ssc.TransitionChunk.from_columns(chunk.obs[:, -8:], chunk.act[-8:], chunk.rew[-8:], chunk.obs2[:, -8:], chunk.done[-8:])
         replay_d.append_chunk(tail, reward_scale=agent_d.reward_scale)
@@ -180,6 +182,8 @@ def test_sharded_actor_learner_loop_world1_equals_vec_loop(ssc):
         while finished >= 1.0:
             agent_d.decaying_ou_action_noise.reduce_epsilon()
             finished -= 1.0
+        eps_gen[j] = agent_d.decaying_ou_action_noise.epsilon
+    assert agent_c.decaying_ou_action_noise.epsilon == agent_d.decaying_ou_action_noise.epsilon < 1.0
     assert torch.equal(agent_c.actor_flat, agent_d.actor_flat) and torch.equal(agent_c.critic_flat, agent_d.critic_flat)
     assert len(losses_c) == 5 and all(torch.equal(x, y) for x, y in zip(losses_c, losses_d))
     assert torch.equal(replay_c.s, replay_d.s) and torch.equal(env_c.s0, env_d.s0)
@@ -227,9 +231,11 @@ def test_sharded_pipelined_loop_clips_observations_like_the_learner(ssc):
         env_d, agent_d = setup()
         replay_d = DeviceReplayBuffer(4096, 3, 1, env_d.device, seed=3)
         gens = {-2: agent_d.actor_flat.clone(), -1: agent_d.actor_flat.clone()}
+        eps_gen = {-2: agent_d.decaying_ou_action_noise.epsilon, -1: agent_d.decaying_ou_action_noise.epsilon}
         ring_d, finished = EpisodeRing(1 << 16, env_d.device), 0.0
         for j in range(5):
-            pol = dataclasses.replace(agent_d.as_policy(), weights=_views_like(gens[j - 2], agent_d.weights))
+            pol = dataclasses.replace(agent_d.as_policy(), weights=_views_like(gens[j - 2], agent_d.weights),
+                                      ou_epsilon=float(eps_gen[j - 2]))
             if not clip:
                 pol.obs_clip = 0.0
             chunk = env_d.rollout(24, pol, ring=ring_d)
@@ -242,6 +248,7 @@ def test_sharded_pipelined_loop_clips_observations_like_the_learner(ssc):
             while finished >= 1.0:
                 agent_d.decaying_ou_action_noise.reduce_epsilon()
                 finished -= 1.0
+            eps_gen[j] = agent_d.decaying_ou_action_noise.epsilon
         return env_d, agent_d, replay_d
     env_d, agent_d, replay_d = hand(True)
     assert torch.equal(replay_c.s, replay_d.s) and torch.equal(replay_c.a, replay_d.a)

@@ -51,7 +51,6 @@ def _worker(rank, world, port, obs_dim, g, tmp, allreduce=True, unequal=False):
         chunk = FakeChunk(obs_dim, K, N, rank)
         chunk.act += it
         stats = torch.tensor([1.5 * (rank + 1), rank, K * N, it], dtype=torch.float64)
-        tg.wait_buffer_free(it & 1)
         tg.submit(chunk, it & 1, stats)
     tg.finish()
     ok = True
