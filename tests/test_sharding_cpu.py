@@ -35,16 +35,16 @@ class FakeChunk:
         self.done = ((torch.arange(K * N).reshape(K, N) + rank) % 7 == 0).to(torch.uint8)
 
 
-def _worker(rank, world, port, obs_dim, g, tmp, allreduce=True, unequal=False):
+def _worker(rank, world, port, obs_dim, g, tmp, allreduce=True, unequal=False, n_total=75):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     K, N = 12, 37
     if unequal:                         # shard_range(75, 2): 38 + 37 envs -- the shards differ by one env
-        lo, hi = shard_range(75, world, rank)
+        lo, hi = shard_range(n_total, world, rank)
         N = hi - lo
     tg = TransitionGather(obs_dim, g, N, world, rank, "cpu", allreduce_stats=allreduce)
-    assert tg.n_all == [shard_range(75, world, r)[1] - shard_range(75, world, r)[0] for r in range(world)] if unequal \
+    assert tg.n_all == [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world)] if unequal \
         else tg.n_all == [N] * world
     assert tg.n_total == sum(tg.n_all)
     for it in range(3):
@@ -91,3 +91,18 @@ def test_gather_and_allreduce_world2_gloo(tmp_path, obs_dim, g, allreduce, unequ
     s.close()
     mp.spawn(_worker, args=(2, port, obs_dim, g, str(tmp_path), allreduce, unequal), nprocs=2, join=True)
     assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
+
+
+def test_gather_world8_gloo_unequal_shards(tmp_path):
+    """BASELINE configs[4] in miniature: 8 ranks, the shard sizes of shard_range(524288 + 3, 8, r) scaled down by 4096
+    (three ranks own one env more), one gather per chunk to the learner, statistics summed out of the payloads."""
+    n_total = (524288 + 3 * 4096) // 4096                      # 131 = 3 x 17 + 5 x 16
+    sizes = [shard_range(n_total, 8, r)[1] - shard_range(n_total, 8, r)[0] for r in range(8)]
+    big = [shard_range(524288 + 3, 8, r)[1] - shard_range(524288 + 3, 8, r)[0] for r in range(8)]
+    assert sizes == [17, 17, 17, 16, 16, 16, 16, 16] and [b - 65536 for b in big] == [1, 1, 1, 0, 0, 0, 0, 0]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(8, port, 2, 4, str(tmp_path), False, True, n_total), nprocs=8, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(8)] == ["1"] * 8
