@@ -105,6 +105,7 @@ struct DynPack {
     size_t b2;   // f32  [UT jt][2 mh][4 g][4 r]              b2 in accumulator layout (when not in the k slots)
     size_t b3;   // f32  [4 g][4 r]
     size_t nm;   // f32  [6][8]  mean_x 1/std_x mean_y 1/std_y mean_z std_z
+    size_t ctr;  // i32  [2]     row-tile counter of walking blocks (DynSimArgs::tile_ctr), zero at rest
     size_t total;
 };
 
@@ -119,6 +120,7 @@ static DynPack make_pack(int UT, int nfc) {
     p.b2 = o; o += al256((size_t)UT * 32 * 4);
     p.b3 = o; o += al256(16 * 4);
     p.nm = o; o += al256(48 * 4);
+    p.ctr = o; o += 256;
     p.total = o;
     return p;
 }
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(256) void dyn_pack_kernel(DynNet n, int UT, DynPack
         else if (q == 2) v = nm.mean_y[k & 3]; else if (q == 3) v = 1.0f / nm.std_y[k & 3];
         else if (q == 4) v = nm.mean_z[k]; else v = nm.std_z[k];
         reinterpret_cast<float *>(ws + pk.nm)[gid] = v;
+        if (gid < 2) reinterpret_cast<int32_t *>(ws + pk.ctr)[gid] = 0;
     }
     const int64_t n_a2 = (n.nfc == 2) ? (int64_t)UT * UT * 2 * 64 * 8 : 0;
     const int64_t n_a3 = (int64_t)UT * 4 * 8 * 8;
@@ -240,6 +243,11 @@ struct DynSimArgs {
     int32_t fwd_mode;       // 1: plain y = net(x) (ssc_mlp_forward); 0: forward simulation
     const float *s0;
     int64_t s0_rows;        // consecutive rows sharing one start state (m / number of start states)
+    int32_t walk;           // streamed W2: a block walks over row tiles -- blockIdx.x, blockIdx.x + gridDim.x, then whatever the
+                            // shared counter hands out -- and fetches the next tile's start states by LDS-DMA under the last
+                            // step of the current one (launch_sim decides)
+    int32_t *tile_ctr;      // walk: device int32[2], zero between launches: {row tiles handed out beyond the first two rounds,
+                            // blocks that have finished}; the last block to finish zeroes both again
     const float *A;         // sim: [m][H][a]; fwd: x [m][in]
     float *S;               // sim: [H+1][m][d]; fwd: y [m][out]
     const unsigned char *a1, *a2, *a3;  // packed weight image (workspace)
@@ -317,9 +325,12 @@ __host__ __device__ constexpr int dyn_a2_bufs() { return NFC == 2 ? (UT <= 4 ? U
 // MODE (compile-time when >= 0): 0 simulation with the actions read from memory, 1 simulation drawing its candidate
 // actions itself, 2 plain forward; -1: decided by the run-time flags.  With the mode known the per-step input code holds
 // no load (mode 1), so no s_waitcnt vmcnt(0) in front of it has to sit out the LDS-DMA pieces still in flight.
-template <int UT, int NFC, bool BIASK, int KIN, bool LAG = false, int MODE = -1>
+// WALK (streamed W2 only): the block walks over row tiles (next_tile below); compiled as its own instantiation so that the launch
+// with one block per row tile -- the 65 536-row BASELINE shape -- carries none of the boundary code or its registers.
+template <int UT, int NFC, bool BIASK, int KIN, bool LAG = false, int MODE = -1, bool WALK = false>
 __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs g) {
     static_assert(!LAG || (UT == 16 && NFC == 2 && KIN == 4), "LAG: streamed W2 with the compact layer-1 layout");
+    static_assert(!WALK || ((NFC == 2) && (UT > 4) && MODE != 2), "WALK: streamed W2, simulation modes");
     constexpr int DS = KIN < SSC_MAX_STATE ? KIN : SSC_MAX_STATE;  // state / output registers per row
     constexpr int KS1 = (2 + 3 * KIN + 31) / 32;                   // layer-1 k-steps compiled in
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -340,6 +351,9 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     unsigned char *l_a3 = l_a1 + A1_BYTES;
     float *l_b2 = reinterpret_cast<float *>(l_a3 + UT * 512);
     float *l_b3 = l_b2 + UT * 32;
+    // STREAM: start states of the NEXT row tile of a walking block, [wave][column tile][k group = state component][16 rows]
+    float *l_s0 = l_b3 + 16;
+    int32_t *l_nn = reinterpret_cast<int32_t *>(l_s0 + kNW * 2 * 64);   // ... and the row tile after that one (see next_tile below)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -389,7 +403,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     // ---- this lane's rows: one per 16-row column tile; the 4 k-group lanes of a row carry it redundantly ----
     // A block of a kernel whose weights are RESIDENT in LDS (no W2 stream) can walk over row tiles tile, tile + gridDim.x, ...
     // (setup_rows below); the launcher gives every tile its own block, see launch_sim.
-    int64_t row[2], rowc[2];
+    int32_t rowc[2];   // this lane's row of each column tile, clamped to m - 1 (run_mfma: m < 2^31); == the row when valid[]
     bool valid[2];
     float st[2][DS];
 
@@ -400,12 +414,14 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     // matrix never has to exist in memory
     constexpr int AMAX = KIN < 4 ? KIN : 4;
     float act[2][AMAX];
-    uint64_t sid[2] = {0, 0};
     u32x4 wcache[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
     int wc = -1;  // Philox call the cached words belong to (block-uniform)
     uint64_t tt = 0;
     if (sample) tt = (g.t + (g.t_base != nullptr ? *g.t_base : 0)) * (uint64_t)((g.H * g.a + 3) / 4);
-    auto fetch_actions = [&](int ts) __attribute__((always_inline)) {
+    // (ar / av: the rows the actions belong to -- this tile's, or, from the last step of a walking block's tile, the next tile's)
+    auto fetch_actions = [&](int ts, int32_t ar0, int32_t ar1, bool av0, bool av1) __attribute__((always_inline)) {
+        const int32_t ar[2] = {ar0, ar1};
+        const bool av[2] = {av0, av1};
         if (sample) {
 #pragma unroll
             for (int ai = 0; ai < AMAX; ++ai)
@@ -414,18 +430,24 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                     if (c4 != wc) {  // block-uniform
                         wc = c4;
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) wcache[nt] = rng_words(g.seed, sid[nt], tt + (uint64_t)c4, TAG_MPC);
+                        for (int nt = 0; nt < 2; ++nt) {
+                            // sample id of the row: (problem, sample within the problem) -- derived here, once per Philox call,
+                            // rather than kept in four registers across the step loop
+                            const uint32_t r32 = (uint32_t)ar[nt], q = r32 / (uint32_t)g.N;
+                            const uint64_t sidv = ((g.pid0 + (uint64_t)q) << 32) + (uint64_t)(r32 - q * (uint32_t)g.N);
+                            wcache[nt] = rng_words(g.seed, sidv, tt + (uint64_t)c4, TAG_MPC);
+                        }
                     }
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         act[nt][ai] = uniform_f32(pick(wcache[nt], (uint32_t)(f & 3)), g.low[ai], g.span[ai]);
-                        if (g.A_out != nullptr && valid[nt] && kg == 0) g.A_out[(rowc[nt] * g.H + ts) * g.a + ai] = act[nt][ai];
+                        if (g.A_out != nullptr && av[nt] && kg == 0) g.A_out[((int64_t)ar[nt] * g.H + ts) * g.a + ai] = act[nt][ai];
                     }
                 }
         } else {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const float *ap = g.A + (rowc[nt] * g.H + ts) * g.a;
+                const float *ap = g.A + ((int64_t)ar[nt] * g.H + ts) * g.a;
 #pragma unroll
                 for (int ai = 0; ai < AMAX; ++ai)
                     if (ai < g.a) act[nt][ai] = ap[ai];
@@ -433,33 +455,88 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         }
     };
     bool skip_tile = false;
-    auto setup_rows = [&](int64_t tile) __attribute__((always_inline)) {   // (a call would put the row state in scratch memory)
+    // (rows fit 32 bits, run_mfma: the per-tile index arithmetic of a walking block runs inside the phase the other wave
+    // group has to bridge, and a 64-bit division is ~10 x a 32-bit one)
+    // `ga`: the kernel arguments the row set-up reads.  At the row-tile boundary of a walking block they are RE-READ from the
+    // kernarg segment (scalar loads, once per row tile) instead of being kept in ~16 SGPRs across the step loop, where
+    // the allocator has none to spare (SGPR spills cost VGPR lanes, and the VGPR file is exactly full)
+    auto setup_rows = [&](const DynSimArgs &ga, int64_t tile, auto staged_tag) __attribute__((always_inline)) {   // (a call would put the row state in scratch memory)
+        constexpr bool staged = decltype(staged_tag)::value;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            row[nt] = tile * kDynRows + wave * 32 + nt * 16 + c;
-            valid[nt] = row[nt] < g.m;
-            rowc[nt] = valid[nt] ? row[nt] : g.m - 1;
-            if (!fwd_mode) {
+            const int64_t r64 = tile * kDynRows + wave * 32 + nt * 16 + c;
+            valid[nt] = r64 < ga.m;
+            rowc[nt] = (int32_t)(valid[nt] ? r64 : ga.m - 1);
+            // staged: a walking block at a row-tile boundary -- the start states were fetched by stage_next_tile under the
+            // previous tile's last step, where the sample ids were switched and the first actions drawn as well (step loop).
+            // (The state is assigned ONCE, behind the branch: with a store to st[] in one arm and one to act[] in the other
+            // the optimiser merges the two into a store through a pointer phi, and both arrays end up in scratch memory.)
+            float s_new[DS];
+            if (STREAM && staged) {
+                int cc = c;
+                asm volatile("" : "+v"(cc));   // (keeps the lane's LDS address from being hoisted out of the step loop -- and spilled)
+#pragma unroll
+                for (int k = 0; k < DS; ++k) s_new[k] = l_s0[((wave * 2 + nt) * 4 + (k & 3)) * 16 + cc];
+            } else {
 #pragma unroll
                 for (int k = 0; k < DS; ++k)
-                    st[nt][k] = (k < g.d) ? g.s0[(rowc[nt] / g.s0_rows) * g.d + k] : 0.0f;   // s0_rows: rows per start state
+                    s_new[k] = (!fwd_mode && k < ga.d) ? ga.s0[((int64_t)rowc[nt] / ga.s0_rows) * ga.d + k] : 0.0f;   // s0_rows: rows per start state
             }
-            if (sample) sid[nt] = ((g.pid0 + (uint64_t)(rowc[nt] / g.N)) << 32) + (uint64_t)(rowc[nt] % g.N);
 #pragma unroll
-            for (int ai = 0; ai < AMAX; ++ai) act[nt][ai] = 0.0f;
+            for (int k = 0; k < DS; ++k) st[nt][k] = (k < ga.d && (k < 4 || !(STREAM && staged))) ? s_new[k] : 0.0f;
+            if (!(STREAM && staged)) {
+#pragma unroll
+                for (int ai = 0; ai < AMAX; ++ai) act[nt][ai] = 0.0f;
+            }
         }
+        if (STREAM && staged) return;
         wc = -1;
         // a wave none of whose rows belongs to a live problem (ssc_mpc_sampling.d_problem_active: e.g. the envs of the
         // vectorised SmartStart loop that are not navigating) skips the tile -- only where no ring barrier needs it
         skip_tile = false;
-        if (!STREAM && sample && g.active != nullptr) {
-            const bool mine = (valid[0] && g.active[rowc[0] / g.N] != 0) || (valid[1] && g.active[rowc[1] / g.N] != 0);
+        if (!STREAM && sample && ga.active != nullptr) {
+            const bool mine = (valid[0] && ga.active[rowc[0] / ga.N] != 0) || (valid[1] && ga.active[rowc[1] / ga.N] != 0);
             skip_tile = __builtin_amdgcn_ballot_w64(mine) == 0;
         }
-        if (!fwd_mode && g.H > 0 && !skip_tile) fetch_actions(0);
+        if (!fwd_mode && g.H > 0 && !skip_tile) fetch_actions(0, rowc[0], rowc[1], valid[0], valid[1]);
     };
     int64_t tile = blockIdx.x;
-    setup_rows(tile);
+    setup_rows(g, tile, std::false_type{});
+    // STREAM, walking block: lane (c, kg) fetches component kg of the start state of row c of each of its two column tiles
+    // of row tile `nxt` -- global -> LDS with no register in between (the register file is full while the hidden tiles
+    // run); the pieces are tracked by vmcnt like the W2 pieces and every tile barrier waits for vmcnt(0)
+    // (kernel arguments read by the boundary code only are RE-READ from the kernarg segment there -- scalar loads, once per row
+    // tile -- instead of living in SGPRs across the step loop, where the allocator has none to spare: SGPR spills cost VGPR
+    // lanes, and the VGPR file is exactly full)
+    typedef const __attribute__((address_space(4))) DynSimArgs *KernArgs;
+    auto reread_args = [&]() __attribute__((always_inline)) -> KernArgs {
+        KernArgs gp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();  // `g` is the only argument
+        asm volatile("" : "+s"(gp));   // opaque: the loads below are not merged with the kernel's own argument loads
+        return gp;
+    };
+    auto stage_next_tile = [&](int64_t nxt, int32_t &nr0, int32_t &nr1, bool &nv0, bool &nv1) __attribute__((always_inline)) {
+        KernArgs gp = reread_args();
+        struct { const float *s0; int64_t s0_rows, m; int32_t d; } ga = {gp->s0, gp->s0_rows, g.m, g.d};
+        // (the descriptor is built here, once per row tile, instead of living in four SGPRs across the step loop)
+        const __amdgpu_buffer_rsrc_t s0_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(ga.s0), 0, (int)(((ga.m + ga.s0_rows - 1) / ga.s0_rows) * ga.d * 4), 0x00020000);
+        auto one = [&](auto nt_tag, int32_t &nr, bool &nv) __attribute__((always_inline)) {
+            constexpr int nt = decltype(nt_tag)::value;
+            const int64_t r = nxt * kDynRows + wave * 32 + nt * 16 + c;
+            nv = r < ga.m;
+            const uint32_t rc = (uint32_t)(nv ? r : ga.m - 1);
+            nr = (int32_t)rc;
+            const uint32_t voff = ((rc / (uint32_t)ga.s0_rows) * (uint32_t)ga.d + (uint32_t)(kg < ga.d ? kg : 0)) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                s0_rsrc,
+                reinterpret_cast<__attribute__((address_space(3))) void *>(
+                    static_cast<uint32_t>(reinterpret_cast<uintptr_t>(l_s0 + (wave * 2 + nt) * 64))),
+                4, (int)voff, 0, 0, 0);
+        };
+        one(std::integral_constant<int, 0>{}, nr0, nv0);
+        one(std::integral_constant<int, 1>{}, nr1, nv1);
+        wc = -1;
+    };
 
     // Normalisation constants per network input (input k = state k for k < d, else action k-d) and per state
     // delta, read once through scalar loads: block-uniform, so they live in SGPRs and the per-step input code
@@ -505,22 +582,36 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     const uint64_t stamp_r0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
     uint64_t ph[6] = {0, 0, 0, 0, 0, 0};  // diagnostic: cycles in input code / layer 1 / hidden tiles / step tail / phase barrier / tile barriers
 #define SSC_STAMP(var) uint64_t var = 0; if (SSC_DYN_ABLATE & 16) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-    for (;;) {   // row tiles of this block (one pass when W2 is streamed)
+    int vt = 0;  // steps this block has run over all its row tiles: the W2 ring and its barriers go on across row tiles
+    // Row tiles of a walking block: its first two are blockIdx.x and blockIdx.x + gridDim.x, every later one comes from a
+    // counter all blocks share (the CUs do not run at one clock -- XCDs differ by several per cent under this load -- so
+    // a fixed stride would make every launch wait for the slowest CU).  The block always knows its NEXT tile: during the
+    // last step of tile i wave 0 draws the index of tile i + 2 (the atomic is issued at the top of the step and its
+    // result parked in LDS behind layer 1), and everybody picks it up at the boundary into tile i + 1, many barriers later.
+    const int64_t n_tiles = (g.m + kDynRows - 1) / kDynRows;
+    int64_t next_tile = WALK ? tile + gridDim.x : n_tiles;
+    int round = 0;   // row tiles this block has finished; the LDS slot alternates (H = 1: wave 0 parks the next draw while the
+                     // slowest wave -- 1.5 hidden tiles behind -- may not have read the previous one yet)
+    for (;;) {   // row tiles of this block
     if (!skip_tile) {
-    for (int t = 0; t < g.H; ++t) {
+    for (int t = 0; t < g.H; ++t, ++vt) {
         SSC_STAMP(stamp_a)
+        const bool draw = WALK && t + 1 == g.H && next_tile < n_tiles;   // block-uniform
+        int32_t drawn = 0;
+        if (draw && wave == 0 && lane == 0)
+            drawn = __hip_atomic_fetch_add(g.tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- inputs: record S[t]; layer-1 B fragments of x = normalised (state, action) ---------------
         bf16x8 xf[2][KS1];
         s16x4 xc[2];   // CMP: the compact layer-1 B fragments (four k slots per lane)
         if constexpr (CMP) {
             // The phase is what the other wave of this SIMD has to bridge with W2 tiles: it runs at raised issue priority
             // (set behind the last hidden tile, dropped again in front of the first one) ...
-            if (LAG && t == 0) __builtin_amdgcn_s_setprio(SSC_DYN_LAG_PRIO);
+            if (LAG && vt == 0) __builtin_amdgcn_s_setprio(SSC_DYN_LAG_PRIO);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 float xv;
                 if (fwd_mode) {
-                    xv = (kg < g.in) ? g.A[rowc[nt] * g.in + kg] : 0.0f;
+                    xv = (kg < g.in) ? g.A[(int64_t)rowc[nt] * g.in + kg] : 0.0f;
                 } else {
                     xv = st[nt][0];
 #pragma unroll
@@ -543,7 +634,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     if (valid[nt] && kg == 0) {
-                        float *sp = g.S + ((int64_t)t * g.m + row[nt]) * g.d;
+                        float *sp = g.S + ((int64_t)t * g.m + rowc[nt]) * g.d;
 #pragma unroll
                         for (int k = 0; k < DS; ++k)
                             if (k < g.d) sp[k] = st[nt][k];  // dynamics_model.py:225
@@ -555,10 +646,10 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             float xs[KIN];
             if (fwd_mode) {
 #pragma unroll
-                for (int k = 0; k < KIN; ++k) xs[k] = (k < g.in) ? g.A[rowc[nt] * g.in + k] : 0.0f;
+                for (int k = 0; k < KIN; ++k) xs[k] = (k < g.in) ? g.A[(int64_t)rowc[nt] * g.in + k] : 0.0f;
             } else {
                 if (valid[nt] && kg == 0) {
-                    float *sp = g.S + ((int64_t)t * g.m + row[nt]) * g.d;
+                    float *sp = g.S + ((int64_t)t * g.m + rowc[nt]) * g.d;
 #pragma unroll
                     for (int k = 0; k < DS; ++k)
                         if (k < g.d) sp[k] = st[nt][k];  // dynamics_model.py:225
@@ -659,7 +750,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                     // barrier #16 t: group 0 takes the barrier of this step's tile 0 HERE, about where group 1 (inside
                     // tile 15 of the step before) reaches it; in step 0 group 1 takes its first one here as well and
                     // then issues its pieces of tile 2 (later steps: in tile 15 of the step before)
-                    if (p == kLagBarrierPair && (group == 0 || t == 0)) {
+                    if (p == kLagBarrierPair && (group == 0 || vt == 0)) {
                         if (!(SSC_DYN_ABLATE & 2)) {
                             SSC_STAMP(stamp_p0)
                             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile 1 landed
@@ -685,7 +776,22 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         }
         // the actions of the next step: issued here, behind layer 1's scheduling fences, so that the loads fly
         // under the hidden tiles (hoisted to the top of the step they were waited for at once)
-        if (!fwd_mode && t + 1 < g.H) fetch_actions(t + 1);
+        if (!fwd_mode) {
+            int ts = t + 1;
+            int32_t ar0 = rowc[0], ar1 = rowc[1];
+            bool av0 = valid[0], av1 = valid[1];
+            bool more = ts < g.H;
+            if (draw) {   // the last step of a row tile that has a successor
+                if (wave == 0 && lane == 0) {
+                    l_nn[round & 1] = 2 * (int32_t)gridDim.x + drawn;
+                    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): in LDS before this wave's next barrier (the ring barriers are bare s_barriers)
+                }
+                stage_next_tile(next_tile, ar0, ar1, av0, av1);
+                ts = 0;
+                more = true;
+            }
+            if (more) fetch_actions(ts, ar0, ar1, av0, av1);
+        }
         // ---- hidden layer 2 (+ output layer fused per tile) -------------------------------------
         f32x4 acc3[2];
         acc3[0] = acc3[1] = *reinterpret_cast<const f32x4 *>(l_b3 + kg * 4);
@@ -833,7 +939,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 if (valid[nt] && kg == 0) {
 #pragma unroll
                     for (int o = 0; o < DS; ++o)
-                        if (o < g.out) g.S[row[nt] * g.out + o] = z[o];
+                        if (o < g.out) g.S[(int64_t)rowc[nt] * g.out + o] = z[o];
                 }
             } else {
 #pragma unroll
@@ -848,14 +954,23 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             if (valid[nt] && kg == 0) {
 #pragma unroll
                 for (int k = 0; k < DS; ++k)
-                    if (k < g.d) g.S[((int64_t)g.H * g.m + row[nt]) * g.d + k] = st[nt][k];  // :240
+                    if (k < g.d) g.S[((int64_t)g.H * g.m + rowc[nt]) * g.d + k] = st[nt][k];  // :240
             }
     }
     }
-    if (STREAM) break;
-    tile += gridDim.x;
-    if (tile * kDynRows >= g.m) break;
-    setup_rows(tile);
+    if constexpr (STREAM && !WALK) break;
+    if constexpr (STREAM) {
+        tile = next_tile;
+        if (tile >= n_tiles) break;
+        next_tile = __builtin_amdgcn_readfirstlane(l_nn[round & 1]);
+        ++round;
+    } else {
+        tile += gridDim.x;
+        if (tile >= n_tiles) break;
+    }
+    // (a streamed-W2 block gets here only when it walks -- launch_sim: simulation modes, H > 0 -- with the next tile staged)
+    if constexpr (STREAM) setup_rows(g, tile, std::true_type{});
+    else setup_rows(g, tile, std::false_type{});
     }
     // LAG: group 1's last tile holds barrier #16 H; group 0 meets it here (no phase follows its last tile)
     if (LAG && group == 0 && g.H > 0 && !(SSC_DYN_ABLATE & 2)) {
@@ -864,6 +979,12 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     }
     // group 1 issued LDS-DMA after its last barrier: it must land before this workgroup's LDS is released
     if (STREAM) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (WALK && tid == 0) {   // every draw of this block is behind it: the last block out leaves the counters at zero
+        if (__hip_atomic_fetch_add(g.tile_ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+            __hip_atomic_store(g.tile_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.tile_ctr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (SSC_DYN_ABLATE & 16) {
         const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c0, dr = __builtin_amdgcn_s_memrealtime() - stamp_r0;
         if (lane == 0 && (wave == 0 || wave == 4)) {  // per block 2 x 24 dwords (wave 0, wave 4): {dc, dr}, 4 phase sums, entry and loop-start realtime, 2 barrier sums
@@ -898,21 +1019,47 @@ size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp) {
 }
 
 template <int UT, int NFC, bool BIASK, int KIN, bool LAG = false, int MODE = -1>
-static int launch_sim(const DynSimArgs &g, hipStream_t s) {
+static int launch_sim(DynSimArgs g, hipStream_t s) {
+    constexpr bool STREAM = (NFC == 2) && (UT > 4);
     const size_t lds = (size_t)(LAG ? 4 : dyn_a2_bufs<UT, NFC>()) * UT * 2048 +
-                       (KIN == 4 ? (size_t)UT * 1024 : (size_t)l1_ksteps(KIN) * UT * 2048) + (size_t)UT * 512 + (size_t)UT * 128 + 64;
-    auto kern = dyn_mfma_sim_kernel<UT, NFC, BIASK, KIN, LAG, MODE>;
+                       (KIN == 4 ? (size_t)UT * 1024 : (size_t)l1_ksteps(KIN) * UT * 2048) + (size_t)UT * 512 + (size_t)UT * 128 + 64 +
+                       (STREAM ? (size_t)kNW * 2 * 64 * 4 + 64 : 0);   // + the start-state staging area and next-tile slots of a walking block
+    const int64_t tiles = (g.m + kDynRows - 1) / kDynRows;
+    unsigned grid = (unsigned)tiles;
+    g.walk = 0;
+    const void *kern = reinterpret_cast<const void *>(dyn_mfma_sim_kernel<UT, NFC, BIASK, KIN, LAG, MODE>);
+    // Only the 4-slot LAG kernel of the BASELINE shape walks (the other streamed shapes keep a block per tile).
+    if constexpr (STREAM && LAG && MODE != 2) {
+        // Streamed W2 (one block per CU: 8 waves x 256 VGPRs, ~158 KB of LDS): with more row tiles than CUs a block WALKS
+        // over row tiles -- the W2 ring, its barriers and the two wave groups' 1.5-tile lag run on across the row tiles
+        // as if the next tile's first step were the next step of the same rows, so the prologue (weight images + the
+        // first two W2 tiles: ~4.5 us of a ~92 us tile at H = 4) is paid once per block instead of once per 256 rows.
+        // The next tile's start states come in by LDS-DMA under the current tile's last step (stage_next_tile), the
+        // tiles beyond a block's first two are handed out by a shared counter (next_tile in the kernel).
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+                n_cu = v;
+            else
+                n_cu = 256;
+        }
+        const int64_t n_s0 = g.s0_rows > 0 ? (g.m + g.s0_rows - 1) / g.s0_rows : 0;
+        const bool can_walk = !g.fwd_mode && g.H > 0 && g.d <= 4 && g.m <= 0x7fffffffLL && n_s0 * g.d * 4 <= 0x7fffffffLL;
+        if (can_walk && tiles > n_cu && g.tile_ctr != nullptr) {
+            grid = (unsigned)n_cu;
+            g.walk = 1;
+            kern = reinterpret_cast<const void *>(dyn_mfma_sim_kernel<UT, NFC, BIASK, KIN, LAG, MODE, true>);
+        }
+    }
     if (lds > 64 * 1024) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+        int rc = check_hip(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "hipFuncSetAttribute(dyn_mfma_sim_kernel)");
         if (rc) return rc;
     }
-    // One block per 256-row tile.  (The kernel can walk a block over several tiles -- grid < tiles -- so that the prologue
-    // is paid once per block; measured for the 1 x 32 network at 1 M rows x 4 steps: 96 us against 81 us with one tile
-    // per block, the per-tile row loads no longer overlap across blocks.  Not used.)
-    const unsigned grid = (unsigned)((g.m + kDynRows - 1) / kDynRows);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDynThreads), lds, s, g);
+    void *params[] = {&g};
+    if (int rc = check_hip(hipLaunchKernel(kern, dim3(grid), dim3(kDynThreads), params, lds, s), "hipLaunchKernel(dyn_mfma_sim_kernel)"))
+        return rc;
     return check_launch("dyn_mfma_sim_kernel");
 }
 
@@ -949,10 +1096,12 @@ static int run_mfma(const ssc_mlp_desc *mlp, DynSimArgs &g, void *wsv, hipStream
     const DynPack pk = make_pack(UT, nfc);
     const DynNet n = make_net(mlp, UT);
     unsigned char *ws = static_cast<unsigned char *>(wsv);
+    SSC_REQUIRE(g.m <= 0x7fffffffLL, "dyn_mfma: m = %lld rows per launch (the kernel indexes rows with 32 bits)", (long long)g.m);
     g.in = n.in; g.out = n.out;
     g.a1 = ws + pk.a1; g.a2 = ws + pk.a2; g.a3 = ws + pk.a3;
     g.b2 = reinterpret_cast<const float *>(ws + pk.b2); g.b3 = reinterpret_cast<const float *>(ws + pk.b3);
     g.nm = reinterpret_cast<const float *>(ws + pk.nm);
+    g.tile_ctr = reinterpret_cast<int32_t *>(ws + pk.ctr);
     const int kin = (n.in <= 4 && n.out <= 4) ? 4 : (n.in <= 10 ? 10 : kMaxIn);
 #define SSC_DYN_CASE(U, F, B)                                                                 \
     if (UT == U && nfc == F && n.biask == B)                                                  \

@@ -862,3 +862,48 @@ def test_forward_sim_skips_masked_problems(nav, prec, dims):
     tol = 1e-4 if prec == "f32" else 3e-2
     g = got[:, p * N:(p + 1) * N].cpu().numpy()
     assert np.max(np.abs(g - ref)) <= tol * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("P,N,H,sampled", [(5000, 16, 4, True), (5000, 16, 1, True), (1, 70000 + 37, 3, True), (300, 257, 2, False)])
+def test_streamed_sim_kernel_walking_over_row_tiles_equals_one_tile_per_block(nav, P, N, H, sampled):
+    """More row tiles than CUs: a block of the streamed-W2 kernel (2 x 500) WALKS over row tiles (the W2 ring, its barriers and
+    the wave groups' lag run on across tiles; the next tile's start states arrive by LDS-DMA under the current tile's last
+    step).  Rows are independent, so the walk must reproduce -- bit for bit -- the same kernel run on sub-batches of at most
+    256 tiles, which get a block per tile: per-env start states, ragged last tile, H = 1 (every step is a tile boundary), one
+    problem spanning every tile, and the actions-from-memory mode.  (BASELINE configs[3] as written: 65 536 envs x 16
+    candidates = 4096 row tiles.)"""
+    rng = np.random.default_rng(11)
+    d, act = 3, 1
+    Ws, bs = make_mlp(rng, (d + act, 500, 500, d))
+    model = nav.DynamicsModel(Ws, bs, make_norm(rng, d, act), state_dim=d, act_dim=act, precision="bf16_mfma")
+    M = P * N
+    assert M > 256 * 256                                               # more tiles than the chip has CUs
+    s0 = torch.as_tensor((rng.normal(size=(P, d)) * 0.2).astype(np.float32), device="cuda")
+    if sampled:
+        sp = nav.mpc_sampling(N, [-2.0], [2.0], 77, 9, 5)
+        A_all = torch.empty((M, H, act), device="cuda")
+        S = model.do_forward_sim_sampled(s0, sp, M, H, A_out=A_all).clone()
+        assert torch.equal(A_all, nav.mpc_sample_actions(P, N, H, [-2.0], [2.0], seed=77, problem_id0=9, t=5))
+    else:
+        A_all = torch.as_tensor(rng.uniform(-2, 2, size=(M, H, act)).astype(np.float32), device="cuda")
+        S = model.do_forward_sim(s0, A_all).clone()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(S).all())
+    # the same rows in pieces of whole problems, each <= 65 536 rows (<= 256 tiles: one tile per block, no walk), from memory
+    per = max(1, 65536 // N) if P > 1 else 1
+    if P == 1:                                                         # one problem: pieces of rows, same start state
+        for r0 in range(0, M, 65536):
+            r1 = min(M, r0 + 65536)
+            ref = model.do_forward_sim(s0, A_all[r0:r1].contiguous())
+            assert torch.equal(S[:, r0:r1], ref), (r0, r1)
+    else:
+        for p0 in range(0, P, per):
+            p1 = min(P, p0 + per)
+            ref = model.do_forward_sim(s0[p0:p1].contiguous(), A_all[p0 * N:p1 * N].contiguous())
+            assert torch.equal(S[:, p0 * N:p1 * N], ref), (p0, p1)
+    # and against the fp32 kernels on a strided subset of rows (the same tolerance as test_forward_sim_mfma)
+    rows = torch.arange(0, M, 997, device="cuda")
+    s0_rows = s0[(rows // N).clamp(max=P - 1)]
+    ref32 = model.do_forward_sim(s0_rows, A_all[rows].contiguous(), precision="f32")
+    err = (S[:, rows] - ref32).abs().max().item() / max(1.0, ref32.abs().max().item())
+    assert err <= 3e-2, err

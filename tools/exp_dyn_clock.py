@@ -7,7 +7,11 @@ import smartstartcontinuous_amd._ffi as F
 F.LIB_PATH = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "tools/_build/libssc_clk.so")
 import torch, numpy as np, time
 from exp_nav import make
-dims, M, H = (4, 500, 500, 3), 65536, int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dims, M, H = (4, 500, 500, 3), (int(sys.argv[4]) if len(sys.argv) > 4 else 65536), int(sys.argv[2]) if len(sys.argv) > 2 else 20
+N_CU = torch.cuda.get_device_properties(0).multi_processor_count
+TILES = M // 256
+BLOCKS = TILES if TILES <= N_CU else N_CU          # more tiles than CUs: the blocks walk (dyn_mfma.hip launch_sim)
+HT = H * -(-TILES // BLOCKS)                         # steps a block runs over all its row tiles
 model, d, a = make(dims)
 A = torch.rand((M, H, a), device="cuda") * 2 - 1
 s0 = torch.randn((M, d), device="cuda") * 0.3
@@ -15,8 +19,8 @@ S = torch.empty((H + 1, M, d), device="cuda")
 SAMPLE = len(sys.argv) > 3 and sys.argv[3] == "sample"      # the MPC step's form: candidate actions drawn in the kernel
 if SAMPLE:
     from smartstartcontinuous_amd import navigator as nav
-    sp = nav.mpc_sampling(4096, [-1.0] * a, [1.0] * a, 1234, 0, 0)
-    s0p = s0[:16].contiguous()
+    sp = nav.mpc_sampling(4096 if M == 65536 else 16, [-1.0] * a, [1.0] * a, 1234, 0, 0)
+    s0p = s0[:(16 if M == 65536 else M // 16)].contiguous()
     run = lambda: model.do_forward_sim_sampled(s0p, sp, M, H, precision="bf16_mfma", out=S)
 else:
     run = lambda: model.do_forward_sim(s0, A, precision="bf16_mfma", out=S)
@@ -27,10 +31,11 @@ while time.time() - t0 < 2.0:
     torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); run(); e1.record(); torch.cuda.synchronize()
-raw = S.view(torch.int32).flatten()[: 48 * (M // 256)].cpu().numpy().astype(np.uint32).reshape(-1, 2, 12, 2).astype(np.uint64)
+raw = S.view(torch.int32).flatten()[: 48 * BLOCKS].cpu().numpy().astype(np.uint32).reshape(-1, 2, 12, 2).astype(np.uint64)
 v = raw[..., 0] | (raw[..., 1] << np.uint64(32))       # [block][group][dc, dr, input, layer 1, hidden tiles, tail, entry_rt, loop_rt]
 dc, dr = v[:, 0, 0], v[:, 0, 1]
 clk = dc / dr * 100.0
+H_ONE, H = H, HT
 mf = 560 * 2 * 32 * H   # MFMA pipe cycles per SIMD for the step loop (2 waves x 17920 cyc of MFMAs per step)
 print("launch %.4f ms; blocks %d; step-loop cycles median %.0f (%.0f per step); realtime median %.1f us; clock median %.0f MHz (min %.0f max %.0f); MFMA floor %.0f cyc -> pipe busy %.1f %%"
       % (e0.elapsed_time(e1), len(dc), np.median(dc), np.median(dc) / H, np.median(dr) / 100.0, np.median(clk), clk.min(), clk.max(), mf, 100.0 * mf / np.median(dc)))
