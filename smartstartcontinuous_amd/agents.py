@@ -429,8 +429,9 @@ class NND_MB_agent(NavigationRLAgent):
                  save_resulting_dynamics_model=False, load_existing_dynamics_model=False,
                  make_training_dataset_noisy=True, num_rollouts_train=25, num_rollouts_val=20,
                  steps_per_rollout_train=333, steps_per_rollout_val=333,
-                 device="cuda", precision="bf16_mfma", seed=1234, per_row_projection=False, **unused):
+                 device="cuda", precision="bf16_mfma", seed=1234, per_row_projection=False, noise_stream=0, **unused):
         self.env = env
+        self.noise_stream = int(noise_stream)   # which pair of Philox streams add_noise draws the data set's noise from
         self.device = torch.device(device)
         self.replay_buffer = replay_buffer if replay_buffer is not None else ReplayBuffer(self, BUFFER_SIZE)
         self.final_steps, self.steps_per_waypoint = final_steps, steps_per_waypoint
@@ -517,8 +518,8 @@ class NND_MB_agent(NavigationRLAgent):
             raise ValueError("the random rollouts produced no training rows")
         self.states_val, self.controls_val, _, _ = collector.collect_samples(num_rollouts_val, steps_per_rollout_val)
         if make_training_dataset_noisy:
-            cs.add_noise_device(train.dataX, self.noiseToSignal, self.seed, stream_id=0)
-            cs.add_noise_device(train.dataZ, self.noiseToSignal, self.seed, stream_id=1)
+            cs.add_noise_device(train.dataX, self.noiseToSignal, self.seed, stream_id=2 * self.noise_stream)
+            cs.add_noise_device(train.dataZ, self.noiseToSignal, self.seed, stream_id=2 * self.noise_stream + 1)
         self.dataX, self.dataY, self.dataZ = train.dataX, train.dataY, train.dataZ
         (mx, sx), (my, sy), (mz, sz) = (cs.column_stats(v) for v in (train.dataX, train.dataY, train.dataZ))
         host = lambda t: t.cpu().numpy()

@@ -1021,9 +1021,8 @@ size_t dyn_mfma_workspace_bytes(const ssc_mlp_desc *mlp) {
 template <int UT, int NFC, bool BIASK, int KIN, bool LAG = false, int MODE = -1>
 static int launch_sim(DynSimArgs g, hipStream_t s) {
     constexpr bool STREAM = (NFC == 2) && (UT > 4);
-    const size_t lds = (size_t)(LAG ? 4 : dyn_a2_bufs<UT, NFC>()) * UT * 2048 +
-                       (KIN == 4 ? (size_t)UT * 1024 : (size_t)l1_ksteps(KIN) * UT * 2048) + (size_t)UT * 512 + (size_t)UT * 128 + 64 +
-                       (STREAM ? (size_t)kNW * 2 * 64 * 4 + 64 : 0);   // + the start-state staging area and next-tile slots of a walking block
+    size_t lds = (size_t)(LAG ? 4 : dyn_a2_bufs<UT, NFC>()) * UT * 2048 +
+                 (KIN == 4 ? (size_t)UT * 1024 : (size_t)l1_ksteps(KIN) * UT * 2048) + (size_t)UT * 512 + (size_t)UT * 128 + 64;
     const int64_t tiles = (g.m + kDynRows - 1) / kDynRows;
     unsigned grid = (unsigned)tiles;
     g.walk = 0;
@@ -1049,6 +1048,7 @@ static int launch_sim(DynSimArgs g, hipStream_t s) {
         if (can_walk && tiles > n_cu && g.tile_ctr != nullptr) {
             grid = (unsigned)n_cu;
             g.walk = 1;
+            lds += (size_t)kNW * 2 * 64 * 4 + 64;   // the start-state staging area and the next-tile slots
             kern = reinterpret_cast<const void *>(dyn_mfma_sim_kernel<UT, NFC, BIASK, KIN, LAG, MODE, true>);
         }
     }

@@ -297,7 +297,7 @@ def default_drain_every(ring_capacity, n_envs, chunk_steps, shortest_episode=64)
 
 def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1 << 20, train_iters=None,
                       replay_last_steps=None, seed=0, ring_capacity=1 << 20, track_episodes=False, overlap=False,
-                      drain_every=None):
+                      drain_every=None, on_chunk=None):
     """Actor-learner loop entirely in HBM: every chunk is a fused rollout of ``chunk_steps`` steps of all
     ``env.n`` envs under the agent's current actor (+ OU noise), appended to a device replay ring, followed
     by ``train_iters`` DDPG iterations (default ``agent.num_train_iterations``) on batches drawn from it.
@@ -318,6 +318,7 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
     ``rl_train_sharded_ddpg(pipelined=True)``); everything else (replay contents, epsilon decay per finished
     generation, sampling) is ordered as in the synchronous loop, and the result is deterministic.  The default follows
     the reference's order: act with the weights of the last completed train().
+    ``on_chunk(i, chunk, env)`` -- if given -- is called once chunk i's rollout, append and learner iterations are enqueued.
     Returns (Summary, losses per chunk, replay)."""
     import torch
     from .replay_buffer import DeviceReplayBuffer
@@ -391,6 +392,8 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
             l = agent.train_from(replay, train_iters)
             if l is not None:
                 losses.append(l)
+            if on_chunk is not None:
+                on_chunk(i, chunks[b], env)
             extra = []
             if (i + 1) % drain_every == 0:               # the ring holds the records of chunks <= i; rollout i+1 is not queued yet
                 drain()
@@ -410,6 +413,8 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
         l = agent.train_from(replay, train_iters)
         if l is not None:
             losses.append(l)
+        if on_chunk is not None:
+            on_chunk(i, out, env)
         if (i + 1) % drain_every == 0:
             drain()
     finish()
