@@ -484,6 +484,111 @@ def bench_smartstart_vec(args, torch, emit=True, P=N_ENVS_PER_GPU, N=16, H=4, K=
     return res
 
 
+def bench_mpc_reference_shape(args, torch, emit=True, H=4):
+    """The MPC step in the shape every shipped SmartStart run uses (examples/continuous/SmartStart_DDPG_Baselines_example.py:94-95;
+    class default NND_MB_agent.py:62): N = 5000 candidate sequences per problem (and 500), horizon 4, the 1 x 32 dynamics model,
+    MountainCar dims -- P problems at once with P * N ~ 1 Mi simulated rows per step.  Three launches per step: the fused fp32
+    simulation of the small network (``dyn_small_sim_kernel``: a row per lane, weights broadcast from LDS, candidates drawn in the
+    kernel), and the two-pass scorer (generate_scores_add_delta's batch-global projection scalars, NND_MB_agent.py:566-628; pass B
+    selects).  VALU-bound: 2 * (3 * 32 + 32 * 2) = 320 flop per row-step against the 157.3 TFLOP/s fp32 vector peak says little --
+    the issue-slot share (``valu_issue``, from the committed PMC pass) is the roof that binds."""
+    import numpy as np
+
+    from smartstartcontinuous_amd import RandomPolicy, VecEnv
+    from smartstartcontinuous_amd import collect_samples as cs
+    from smartstartcontinuous_amd import navigator as nav
+    from smartstartcontinuous_amd import numerical as num
+    from smartstartcontinuous_amd import _ffi
+    from smartstartcontinuous_amd.agents import init_dynamics_weights
+    d, a = 2, 1
+    denv = VecEnv("MountainCarContinuous-v0", 64, seed=1234)
+    dchunk = denv.rollout(150, RandomPolicy())
+    ts = cs.dataset_from_chunk(dchunk)
+    (mx, sx), (my, sy), (mz, sz) = (cs.column_stats(v) for v in (ts.dataX, ts.dataY, ts.dataZ))
+    host = lambda t: t.cpu().numpy()
+    norm = dict(mean_x=host(mx), std_x=host(sx), mean_y=host(my), std_y=host(sy), mean_z=host(mz), std_z=host(sz))
+    Ws, bs = init_dynamics_weights(d + a, d, 1, 32, torch.Generator().manual_seed(1234))
+    model = nav.DynamicsModel(Ws, bs, norm, d, a, precision="f32")
+    path = dchunk.obs[:, :150, 0].t().double().cpu().numpy()
+    stds, means = num.path_deltas_stds_and_means_per_dim(path)
+    rad = num.radii_calc(means, stds, 1, 1, 1)
+    left = num.distances_left(path, num.elliptical_euclidean_distance_function_generator(rad))
+    out = {}
+    for N in (5000, 500):
+        P = max(1, (1 << 20) // N)
+        M = P * N
+        ps = nav.MpcProblemSet([path] * P, [left] * P, [rad] * P, [0] * P, theta=1.0, gamma=0.75, horizontal_penalty_factor=0.5)
+        s0_p = torch.as_tensor(np.repeat(path[:1], P, axis=0), dtype=torch.float32, device="cuda")
+        S = torch.empty((H + 1, M, d), device="cuda")
+        sel = dict(scores=torch.empty(M, device="cuda"), best=torch.empty(P, dtype=torch.int32, device="cuda"),
+                   best_score=torch.empty(P, device="cuda"), action=torch.empty((P, a), device="cuda"),
+                   ws=torch.empty(_ffi.lib().ssc_mpc_score_workspace_bytes(P, N, H), dtype=torch.uint8, device="cuda"))
+
+        def step(t, ev=None):
+            sp = nav.mpc_sampling(N, [-1.0], [1.0], 1234, 0, t)
+            if ev is not None:
+                ev[0].record()
+            model.do_forward_sim_sampled(s0_p, sp, M, H, out=S)
+            if ev is not None:
+                ev[1].record()
+            nav.mpc_score_select(ps, S, sampling=sp, act_dim=a, noise_amount=0.005, seed=1234, problem_id0=0, t=t, want_path=False, out=sel)
+        for t in range(args.warmup + min(args.settle_launches, 300)):
+            step(t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(args.steps):
+            step(t)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for t, ev in enumerate(evs):
+            step(t, ev)
+        torch.cuda.synchronize()
+        kms = sorted(x.elapsed_time(y) for x, y in evs)[len(evs) // 2]
+        flop_row = 2.0 * ((d + a) * 32 + 32 * d)
+        out["N%d" % N] = {"problems": P, "rows": M, "ms_per_mpc_step": el / args.steps * 1e3, "row_steps_per_s": M * H * args.steps / el,
+                          "mpc_problems_per_s": P * args.steps / el, "sim_kernel_ms": kms, "sim_row_steps_per_s": M * H / (kms * 1e-3),
+                          "sim_tflops": flop_row * M * H / (kms * 1e-3) / 1e12}
+    r5 = out["N5000"]
+    res = {"metric": "row-steps/sec, MPC step in the reference's shipped shape (N = 5000 candidates, H = 4, NND_MB 1x32)",
+           "value": r5["row_steps_per_s"], "unit": "row-steps/s", "n_gpus": 1, "steps": args.steps, "ms_per_step": r5["ms_per_mpc_step"],
+           "higher_is_better": True, "dtype": "f32 (VALU)", "data": "synthetic", "by_candidates": out,
+           "config": {"workload": "MountainCar dims (in 3, out 2), num_fc_layers 1, depth 32; N = 5000 x %d problems (and 500 x %d) ~ 1 Mi rows, "
+                                  "horizon %d; simulate (in-kernel sampling) + score A + score B/select = 3 launches per MPC step"
+                                  % (out["N5000"]["problems"], out["N500"]["problems"], H)},
+           "roofline": {"bound": "valu_issue", "achieved": r5["sim_tflops"], "peak": 157.3, "unit": "TFLOP/s", "frac": r5["sim_tflops"] / 157.3,
+                        "traffic": None, "kernel": "ssc::dyn_small_sim_kernel", "kernel_ms": r5["sim_kernel_ms"],
+                        "note": "fp32 vector flop of the network alone against the vector peak; the kernel spends most of its issue slots on the "
+                                "z-score, Philox sampling and LDS weight broadcasts around them (valu_issue)"}}
+    vi = profiled_small_sim_issue()
+    if vi is not None:
+        res["roofline"]["valu_issue"] = vi
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
+
+
+SMALL_SIM_SOURCES = ("dyn_model.hip",)
+
+
+def profiled_small_sim_issue():
+    """SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of dyn_small_sim_kernel from the committed PMC pass of `bench.py --config 5`
+    (profiles/*/mpc_ref/valu_issue.json), reported only for the kernel source it was measured on."""
+    import glob
+    sha, best = source_sha_of(SMALL_SIM_SOURCES), None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "mpc_ref", "valu_issue.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        rel = os.path.relpath(f, ROOT)
+        if d.get("source_sha") == sha:
+            best = dict(d, source=rel)
+        elif best is None or "stale" in best:
+            best = {"stale": "%s was measured on kernel source %s, this build is %s" % (rel, d.get("source_sha"), sha)}
+    return best
+
+
 def profiled_traffic():
     """HBM bytes per launch of the rollout kernel from the committed rocprofv3 PMC passes
     (profiles/<tag>/traffic.json: WRITE_SIZE*1024 + 2*FETCH_SIZE*1024, gfx950 correction) -- the counters cannot
@@ -652,9 +757,10 @@ def main():
                     help="config 2, one GPU: skip the BASELINE configs[2] / configs[3] lines attached as `other_configs`")
     ap.add_argument("--no-per-env", action="store_true", help="--config 4: skip the one-navigator-per-env leg")
     ap.add_argument("--per-env-only", action="store_true", help="--config 4: ONLY the one-navigator-per-env leg (profiling runs)")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based): 2 = headline random-policy rollout (default), "
-                         "3 = + DDPG actor MFMA, 4 = NND_MB 2x500 forward sim + MPC")
+                         "3 = + DDPG actor MFMA, 4 = NND_MB 2x500 forward sim + MPC; 5 = (not a BASELINE config) the MPC step in "
+                         "the reference's shipped shape, N = 5000 / 500 candidates on the 1x32 model")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch rehearsal: parse, (self-)spawn the ranks, rendezvous (process group + barrier), print one "
                          "JSON line on rank 0 and exit before anything touches a GPU -- what the CPU suite runs")
@@ -689,6 +795,8 @@ def main():
             sys.exit("--config 3/4 are single-GPU measurements")
         if not torch.cuda.is_available():
             sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        if args.config == 5:
+            return bench_mpc_reference_shape(args, torch) and 0
         if args.config == 4:
             if args.per_env_only:
                 return bench_config4_envs(args, torch) and 0
@@ -947,11 +1055,11 @@ def main():
             other = {}
             # (a failure in one of these legs must not cost the headline line: it is reported in place of the leg)
             for name, fn in (("config3", bench_config3), ("config4", bench_config4), ("config4_per_env", bench_config4_envs),
-                             ("smartstart_vec", bench_smartstart_vec)):
+                             ("smartstart_vec", bench_smartstart_vec), ("mpc_reference_shape", bench_mpc_reference_shape)):
                 try:
                     r = fn(a2, torch, emit=False)
                     other[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline", "h20",
-                                                     "navigated_fraction_last_chunk") if k in r}
+                                                     "navigated_fraction_last_chunk", "by_candidates") if k in r}
                     other[name]["workload"] = r["config"]["workload"]
                 except Exception as e:           # noqa: BLE001
                     other[name] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -13,7 +13,7 @@ import smartstartcontinuous_amd as ssc
 from smartstartcontinuous_amd.agents import DDPG_Baselines_agent
 
 
-def ddpg(envs, K, iters, batch, chunks, seed, window=10):
+def ddpg(envs, K, iters, batch, chunks, seed, last_steps=0, capacity_log2=20, window=50, quiet=0):
     g = np.load(os.path.join(ROOT, "tests", "golden", "ddpg_good_params_curves.npz"))
     p = json.loads(str(g["param_dict"]))
     env = ssc.VecEnv("MountainCarContinuous-v0", envs, seed=seed)
@@ -34,11 +34,14 @@ def ddpg(envs, K, iters, batch, chunks, seed, window=10):
         state["last"] = st
         if state["first"] is None and st[1] > 0:
             state["first"] = (i + 1) * K * envs
-        print("chunks %4d  env-steps %.3g  episodes %7d  goal share %.3f  mean return %7.2f  mean length %5.0f  epsilon(dev) %.3f  (%.1f s)"
-              % (i + 1, st[2], d[3], d[1] / max(d[3], 1), d[0] / max(d[3], 1), d[2] / max(d[3], 1), float(agent.d_epsilon.item()), time.time() - t0), flush=True)
-    s, losses, replay = ssc.rl_train_vec_ddpg(env, agent, chunks, chunk_steps=K, replay_capacity=1 << 20, seed=seed, on_chunk=progress)
+        if not quiet:
+            print("chunks %4d  env-steps %.3g  episodes %7d  goal share %.3f  mean return %7.2f  mean length %5.0f  epsilon(dev) %.3f  (%.1f s)"
+                  % (i + 1, st[2], d[3], d[1] / max(d[3], 1), d[0] / max(d[3], 1), d[2] / max(d[3], 1), float(agent.d_epsilon.item()), time.time() - t0), flush=True)
+    s, losses, replay = ssc.rl_train_vec_ddpg(env, agent, chunks, chunk_steps=K, replay_capacity=1 << capacity_log2, seed=seed, on_chunk=progress,
+                                              replay_last_steps=last_steps or None)
     ep = np.asarray(s.episodes, np.float64).reshape(-1, 2)
     late = ep[-max(1, len(ep) // 10):]
+    print("cfg envs %d K %d iters %d batch %d chunks %d seed %d last %d cap 2^%d:" % (envs, K, iters, batch, chunks, seed, last_steps, capacity_log2), end=" ")
     print("first goal within %s env-steps; %d episodes; late tenth: median return %.2f, median length %.0f, goal share %.3f; dropped records %d"
           % (state["first"], len(ep), np.median(late[:, 1]), np.median(late[:, 0]), (late[:, 0] < 999).mean(), s.dropped_episode_records))
 
@@ -77,6 +80,6 @@ def smartstart(envs, samples, chunks, seed, noise_stream, K=64, max_steps=300):
 if __name__ == "__main__":
     a = sys.argv[1:]
     if a[0] == "ddpg":
-        ddpg(*[int(x) for x in a[1:7]])
+        ddpg(*[int(x) for x in a[1:]])
     else:
         smartstart(*[int(x) for x in a[1:6]])
