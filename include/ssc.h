@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSC_VERSION 105 /* 0.1.5: ssc_ou_desc.d_epsilon, ssc_decay_schedule, ssc_replay_append_shard; 0.1.4: ssc_path_shortcut; 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
+#define SSC_VERSION 106 /* 0.1.6: ssc_nav_compact + live lists in ssc_mpc_sampling / ssc_mpc_problems; 0.1.5: ssc_ou_desc.d_epsilon, ssc_decay_schedule, ssc_replay_append_shard; 0.1.4: ssc_path_shortcut; 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
 
 typedef void *ssc_stream_t; /* hipStream_t */
 
@@ -277,6 +277,10 @@ typedef struct ssc_mpc_problems {
     /* Optional: device [P] bytes; a problem whose byte is 0 is not scored by the one-launch scorer (n_samples <= 64): its
      * scores / best_idx entries are left untouched.  NULL: every problem is scored. */
     const uint8_t *active;
+    /* Optional compact work list (ssc_nav_compact), as in ssc_mpc_sampling: the one-launch scorer serves the *n_live problems
+     * live_list[0 .. *n_live) and nothing else; outputs stay indexed by problem. */
+    const int32_t *live_list;
+    const int32_t *n_live;
 } ssc_mpc_problems;
 
 /* all_samples = npr.uniform(low, high, (N, H, act)) (NND_MB_agent.py:500-501) for P problems:
@@ -299,6 +303,12 @@ typedef struct ssc_mpc_sampling {
      * d_S / d_A_out is then left untouched).  The kernels with LDS-resident weights (depth <= 128, or one hidden layer) skip
      * a wave whose rows all belong to such problems; the streamed-W2 kernel ignores the mask.  NULL: every problem is live. */
     const uint8_t *d_problem_active;
+    /* Optional COMPACT work list (ssc_nav_compact): device int32 list of the live problems and device count.  With both given
+     * the fused small-network kernel assigns thread block i * 256 + j to row (list[slot] * N + sample) of the slot-th LIVE
+     * problem -- the launch still covers P * N threads (HIP-graph safe), blocks past *d_n_live exit at once -- and every
+     * array keeps its problem-major layout.  Other kernels ignore the list (they simulate every row). */
+    const int32_t *d_live_list;
+    const int32_t *d_n_live;
 } ssc_mpc_sampling;
 
 /* ssc_mpc_sample_actions + ssc_dyn_forward_sim in ONE launch (Dyn_Model.do_forward_sim fed by get_best_sim_actions,
@@ -397,7 +407,14 @@ typedef struct ssc_smartstart_step {
     float act_low, act_high;
     uint8_t *d_mode_log;         /* [K][P] or NULL */
     int64_t mode_log_stride;     /* row stride of d_mode_log (0: P) */
+    int32_t *d_n_live;           /* optional: the counter of ssc_nav_compact, zeroed by this launch (the last one of a step) so
+                                    that the next step's compaction starts from 0 without a launch of its own */
 } ssc_smartstart_step;
+
+/* The envs that are navigating (d_mode[i] != 0) as a compact list: d_list[0 .. *d_count) = their indices (any order),
+ * *d_count their number.  *d_count must be 0 on entry (ssc_smartstart_step.d_n_live leaves it so).  One pass: ballot +
+ * prefix inside a wave, one atomic per wave for its base. */
+int ssc_nav_compact(int64_t n, const uint8_t *d_mode, int32_t *d_list, int32_t *d_count, ssc_stream_t stream);
 
 int ssc_smartstart_rollout_step(const ssc_env_params *p, const ssc_mpc_problems *problems, const ssc_mpc_nav_state *nav,
                                 const ssc_smartstart_step *ss, const float *d_A, const int32_t *d_best_idx,

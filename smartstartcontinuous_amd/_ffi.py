@@ -90,19 +90,20 @@ class MpcProblems(Structure):
                 ("wp", c_void_p), ("left", c_void_p), ("wp_off", c_void_p), ("cur_idx", c_void_p),
                 ("radii", c_void_p), ("theta", c_float), ("gamma", c_float),
                 ("horizontal_penalty_factor", c_float), ("per_row_projection", c_int32),
-                ("plan_of", c_void_p), ("wp_len", c_void_p), ("active", c_void_p)]
+                ("plan_of", c_void_p), ("wp_len", c_void_p), ("active", c_void_p),
+                ("live_list", c_void_p), ("n_live", c_void_p)]
 
 
 class SmartStartStep(Structure):
     _fields_ = [("mode", c_void_p), ("plan_of", c_void_p), ("d_actor_out", c_void_p), ("d_eta", c_void_p),
                 ("d_ou_epsilon", c_void_p), ("d_pool", c_void_p), ("ou", OuDesc), ("act_low", c_float), ("act_high", c_float),
-                ("d_mode_log", c_void_p), ("mode_log_stride", c_int64)]
+                ("d_mode_log", c_void_p), ("mode_log_stride", c_int64), ("d_n_live", c_void_p)]
 
 
 class MpcSampling(Structure):
     _fields_ = [("n_samples", c_int32), ("low", c_float * SSC_MAX_ACT), ("high", c_float * SSC_MAX_ACT),
                 ("seed", c_uint64), ("problem_id0", c_uint64), ("t", c_uint64), ("d_t_base", c_void_p),
-                ("d_problem_active", c_void_p)]
+                ("d_problem_active", c_void_p), ("d_live_list", c_void_p), ("d_n_live", c_void_p)]
 
 
 class CriticDesc(Structure):
@@ -219,6 +220,7 @@ _SIGNATURES = {
                                             c_void_p, c_void_p, c_float, c_uint64, c_uint64, POINTER(RolloutState),
                                             POINTER(TransitionLog), POINTER(EpisodeRing), c_void_p, c_uint64, c_uint64, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ssc_nav_compact": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ssc_mpc_score_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "ssc_mpc_score": (c_int, [POINTER(MpcProblems), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                               c_void_p]),

@@ -144,6 +144,7 @@ struct SmallSimArgs {
     const uint64_t *t_base;
     float low[SSC_MAX_ACT], span[SSC_MAX_ACT];
     const uint8_t *active;
+    const int32_t *live_list, *n_live;   // ssc_mpc_sampling: compact work list (threads -> rows of live problems)
 };
 
 constexpr int kSmallMaxDepth = 128;
@@ -152,6 +153,13 @@ __global__ __launch_bounds__(256) void dyn_small_sim_kernel(SmallSimArgs g) {
     __shared__ __attribute__((aligned(16))) float rec[kSmallMaxDepth][8];
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int in = g.d + g.a;
+    // compact work list: thread (slot * N + n) serves sample n of problem live_list[slot]; a block whose first slot lies
+    // past the live count has nothing to do (block-uniform: in front of the barrier)
+    int32_t n_live = 0;
+    if (g.live_list != nullptr) {
+        n_live = *g.n_live;
+        if ((int64_t)blockIdx.x * 256 >= (int64_t)n_live * g.N) return;
+    }
     for (int e = threadIdx.x; e < g.depth * 8; e += 256) {
         const int j = e >> 3, q = e & 7;
         float v = 0.0f;
@@ -162,8 +170,13 @@ __global__ __launch_bounds__(256) void dyn_small_sim_kernel(SmallSimArgs g) {
     }
     __syncthreads();
     const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = gi < g.m;
-    const int64_t row = valid ? gi : g.m - 1;
+    bool valid = gi < g.m;
+    int64_t row = valid ? gi : g.m - 1;
+    if (g.live_list != nullptr) {
+        const int64_t slot = gi / g.N;
+        valid = slot < n_live;
+        row = valid ? (int64_t)g.live_list[slot] * g.N + (gi - slot * g.N) : 0;
+    }
     if (!valid || (g.active != nullptr && g.active[row / g.N] == 0)) return;   // (no barrier below)
     float st[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -247,6 +260,7 @@ static int launch_small_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, const
             g.span[a] = a < act_dim ? sp->high[a] - sp->low[a] : 0.0f;
         }
         g.active = sp->d_problem_active;
+        if (sp->d_live_list != nullptr && sp->d_n_live != nullptr) { g.live_list = sp->d_live_list; g.n_live = sp->d_n_live; }
     }
     hipLaunchKernelGGL(dyn_small_sim_kernel, dim3(blocks_for(m)), dim3(256), 0, s, g);
     return check_launch("dyn_small_sim_kernel");

@@ -157,7 +157,10 @@ __device__ __forceinline__ void load_window(const MpcArgs &a, int p, int lane, i
     const int q = plan_index(a, p);     // == p unless the problems share a plan pool
     const int off = a.wp_off[q];
     const int Wabs = plan_len(a, q);
-    const int iabs = a.cur_idx[p];
+    // (clamped: a plan slot re-published under an env that still follows it -- a pool too small for the refresh cadence --
+    // may be shorter than the env's waypoint index; the env then heads for the new plan's last waypoint instead of reading
+    // outside the window)
+    const int iabs = min(a.cur_idx[p], max(Wabs - 1, 0));
     const int wb = max(iabs - 1, 0);
     const int cnt = max(min(Wabs - wb, a.H + 4), 0);
     float *wps = win, *lefts = win + kWinMax * a.d, *inv_r = lefts + kWinMax;
@@ -390,8 +393,14 @@ __device__ __forceinline__ void mpc_small_body(MpcArgs a, const SelectArgs &sel,
     __shared__ float cproj[kGroups][kMaxH1 + 1];
     const int g = threadIdx.x / G, n = threadIdx.x & (G - 1);
     const int pq = blockIdx.x * kGroups + g;
-    const bool has = pq < a.P;
-    const int p = has ? pq : a.P - 1;            // a group past the last problem shadows it and writes nothing
+    int n_serve = a.P;
+    if (a.live_list != nullptr) {   // compact work list: group pq serves problem live_list[pq]
+        n_serve = *a.n_live;
+        if (blockIdx.x * kGroups >= n_serve) return;   // block-uniform, in front of every barrier
+    }
+    const bool has = pq < n_serve;
+    const int ps = has ? pq : n_serve - 1;       // a group past the last problem shadows it and writes nothing
+    const int p = a.live_list != nullptr ? a.live_list[ps] : ps;
     // a problem masked out by a.active (an env that is not navigating) costs its group three barriers and nothing else
     const bool scored = a.active == nullptr || a.active[p] != 0;    // group-uniform
     const bool live = has && n < a.N && scored;
@@ -436,6 +445,20 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_small_kernel(MpcArgs a, SelectA
                                                               float *__restrict__ scores, int32_t *__restrict__ best_idx,
                                                               float *__restrict__ best_score) {
     SSC_MPC_DISPATCH_D(a, mpc_small_body<G>(a, sel, S, scores, best_idx, best_score));
+}
+
+// The navigating envs as a compact list (ssc_nav_compact): wave ballot + prefix, one atomic per wave for its base.
+__global__ __launch_bounds__(256) void nav_compact_kernel(int64_t n, const uint8_t *__restrict__ mode, int32_t *__restrict__ list,
+                                                          int32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool nav = i < n && mode[i] != 0;
+    const uint64_t b = __builtin_amdgcn_ballot_w64(nav);
+    if (b == 0) return;   // wave-uniform
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __builtin_popcountll(b));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (nav) list[base + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
 }
 
 struct ActBounds {
@@ -558,6 +581,7 @@ static int mpc_score_common(const char *who, const ssc_mpc_problems *pr, const f
     MpcArgs a;
     a.P = pr->n_problems; a.N = pr->n_samples; a.H = pr->horizon; a.d = pr->state_dim;
     a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx; a.plan_of = pr->plan_of; a.wp_len = pr->wp_len; a.active = pr->active;
+    a.live_list = (pr->live_list != nullptr && pr->n_live != nullptr) ? pr->live_list : nullptr; a.n_live = pr->n_live;
     a.theta = pr->theta; a.gamma = pr->gamma; a.hpf = pr->horizontal_penalty_factor;
     a.per_row = pr->per_row_projection;
     a.nblk = (a.N + kMpcBlock - 1) / kMpcBlock;
@@ -637,6 +661,7 @@ int ssc_mpc_observe(const ssc_mpc_problems *pr, const float *d_new_state, int32_
     MpcArgs a{};
     a.P = pr->n_problems; a.d = pr->state_dim;
     a.wp = pr->wp; a.left = pr->left; a.radii = pr->radii; a.wp_off = pr->wp_off; a.cur_idx = pr->cur_idx; a.plan_of = pr->plan_of; a.wp_len = pr->wp_len; a.active = pr->active;
+    a.live_list = (pr->live_list != nullptr && pr->n_live != nullptr) ? pr->live_list : nullptr; a.n_live = pr->n_live;
     a.theta = pr->theta;
     hipLaunchKernelGGL(mpc_observe_kernel, dim3((a.P + 63) / 64), dim3(64), 0, as_stream(stream), a, d_new_state,
                        d_cur_idx, d_actions_done, give_up_after, final_steps, d_at_goal);
@@ -654,6 +679,14 @@ int ssc_mpc_select_action(int32_t P, int32_t N, int32_t H, int32_t d, int32_t ac
     hipLaunchKernelGGL(mpc_select_kernel, dim3((P + 63) / 64), dim3(64), 0, as_stream(stream), P, N, H, d, act, d_A,
                        d_S, d_best_idx, noise_amount, seed, problem_id0, t, d_action, d_best_path);
     return check_launch("ssc_mpc_select_action");
+}
+
+int ssc_nav_compact(int64_t n, const uint8_t *d_mode, int32_t *d_list, int32_t *d_count, ssc_stream_t stream) {
+    SSC_REQUIRE(n >= 0 && n <= 0x7fffffffLL, "ssc_nav_compact: n = %lld", (long long)n);
+    if (n == 0) return SSC_OK;
+    SSC_REQUIRE(d_mode && d_list && d_count, "ssc_nav_compact: NULL device pointer");
+    hipLaunchKernelGGL(nav_compact_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), n, d_mode, d_list, d_count);
+    return check_launch("ssc_nav_compact");
 }
 
 }  // extern "C"

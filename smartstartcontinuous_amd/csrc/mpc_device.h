@@ -11,6 +11,7 @@ struct MpcArgs {
     const int32_t *wp_off, *cur_idx;
     const int32_t *plan_of, *wp_len;   // optional plan pool (ssc_mpc_problems): problem p follows plan plan_of[p]
     const uint8_t *active;             // optional: problems whose byte is 0 are not scored (one-launch scorer)
+    const int32_t *live_list, *n_live; // optional compact work list (one-launch scorer): groups serve live_list[0 .. *n_live)
     float theta, gamma, hpf;
     int32_t per_row;
     int32_t nblk;  // blocks per problem
@@ -44,6 +45,7 @@ __device__ __forceinline__ bool nav_observe_one(const MpcArgs &a, int p, const f
 #pragma unroll
     for (int k = 0; k < SSC_MAX_STATE; ++k) inv_r[k] = (k < d) ? 1.0f / a.radii[q * d + k] : 0.0f;
     const float *wp = a.wp + (int64_t)off * d;
+    idx = min(idx, max(W - 1, 0));   // a re-published (shorter) plan under a live env: see load_window (mpc.hip)
     const float dc = ell_dist(x, wp + idx * d, inv_r, d);                        // :364
     const float dn = ell_dist(x, wp + min(idx + 1, W - 1) * d, inv_r, d);        // :365
     const bool move = (dc <= a.theta || dn <= dc) && idx != W - 1;               // :491-496

@@ -428,6 +428,12 @@ int ssc_replay_sample(uint64_t seed, uint64_t counter0, int64_t size, int32_t n_
     if (batch_size > 64) {
         int tsize = 1024;
         while (tsize < 2 * batch_size) tsize <<= 1;
+        if ((size_t)tsize * 8 + 256 > 64 * 1024) {   // dynamic table + the kernel's static LDS pass the default 64 KB limit (batch > 2048)
+            if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(replay_sample_big_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, tsize * 8),
+                                   "hipFuncSetAttribute(replay_sample_big_kernel)"))
+                return rc;
+        }
         hipLaunchKernelGGL(replay_sample_big_kernel, dim3(n_batches), dim3(kSampleBlock), (size_t)tsize * 8, as_stream(stream), seed,
                            counter0, size, batch_size, tsize, d_idx);
         return check_launch("ssc_replay_sample");

@@ -611,12 +611,14 @@ struct SsStepArgs {
     float ou_mu, ou_sig_sqrt_dt, ou_theta_dt, act_low, act_high;
     uint8_t *mode_log;
     int64_t mode_log_stride;
+    int32_t *n_live;   // ssc_smartstart_step::d_n_live: zeroed here for the next step's ssc_nav_compact
 };
 
 template <class EnvT, bool SS = false>
 __global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT::Const ec, RolloutArgs ra, MpcStepArgs ma, SsStepArgs sa) {
     constexpr int OBS = EnvT::OBS;
     const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (SS && gi == 0 && sa.n_live != nullptr) *sa.n_live = 0;   // simulation and scoring of this step are behind us in the stream
     const bool active = gi < ra.n;
     const int64_t i = active ? gi : ra.n - 1;
     const uint64_t t = *ma.d_t;
@@ -965,6 +967,7 @@ extern "C" int ssc_smartstart_rollout_step(const ssc_env_params *p, const ssc_mp
     sa.ou_mu = ss->ou.mu; sa.ou_sig_sqrt_dt = ss->ou.sigma * sqrtf(ss->ou.dt); sa.ou_theta_dt = ss->ou.theta * ss->ou.dt;
     sa.act_low = ss->act_low; sa.act_high = ss->act_high;
     sa.mode_log = ss->d_mode_log; sa.mode_log_stride = ss->mode_log_stride ? ss->mode_log_stride : n;
+    sa.n_live = ss->d_n_live;
     SSC_REQUIRE(sa.mode_log_stride >= n, "ssc_smartstart_rollout_step: mode log stride < n");
     hipStream_t s = as_stream(stream);
     if (p->kind == SSC_ENV_MOUNTAINCAR) {

@@ -282,9 +282,11 @@ class DynamicsModel:
         return S
 
 
-def mpc_sampling(N, low, high, seed, problem_id0=0, t=0, t_base=None, active=None):
+def mpc_sampling(N, low, high, seed, problem_id0=0, t=0, t_base=None, active=None, live_list=None, n_live=None):
     """``ssc_mpc_sampling``: the candidate action sequences of an MPC step as a specification (NND_MB_agent.py:500-501).
-    ``active``: optional uint8 device tensor, one byte per problem -- rows of problems marked 0 need not be simulated."""
+    ``active``: optional uint8 device tensor, one byte per problem -- rows of problems marked 0 need not be simulated.
+    ``live_list`` / ``n_live``: the compact list of live problems and its device count (``ssc_nav_compact``): the fused
+    small-network kernel then spends threads on those problems' rows only."""
     sp = _ffi.MpcSampling()
     low = np.asarray(low, np.float32).reshape(-1)
     high = np.asarray(high, np.float32).reshape(-1)
@@ -294,7 +296,9 @@ def mpc_sampling(N, low, high, seed, problem_id0=0, t=0, t_base=None, active=Non
     sp.seed, sp.problem_id0, sp.t = int(seed), int(problem_id0), int(t)
     sp.d_t_base = None if t_base is None else t_base.data_ptr()
     sp.d_problem_active = None if active is None else active.data_ptr()
-    sp._keep = (t_base, active)
+    if live_list is not None and n_live is not None:
+        sp.d_live_list, sp.d_n_live = live_list.data_ptr(), n_live.data_ptr()
+    sp._keep = (t_base, active, live_list, n_live)
     return sp
 
 
@@ -382,15 +386,31 @@ class PlanPool:
         self.published = 0
         self.active = None      # optional uint8 [n_envs]: only problems marked non-zero are simulated / scored
 
-    def publish(self, plans):
+    def publish(self, plans, now=None, min_age=None):
         """``plans``: list of (waypoints [W, d], distances_left [W], radii [d]) -- the per-episode quantities of
         NND_MB_agent.start_new_episode_plan (NND_MB_agent.py:375-423).  They go into the next slots and become the
-        plans on offer; the slots they replace were offered ``n_slots / len(plans)`` refreshes ago."""
+        plans on offer; the slots they replace were offered ``n_slots / len(plans)`` refreshes ago.
+        ``now`` (env-steps so far) and ``min_age`` (the longest episode): a slot that went off offer fewer than ``min_age``
+        steps ago may still be followed by an env -- overwriting it is reported once (RuntimeWarning; the kernels clamp
+        the waypoint index, so such an env heads for the new plan's goal instead of reading outside it)."""
         if not plans:
             return
         if len(plans) > self.n_slots:
             raise ValueError("more plans than slots")
         first = self._next
+        if now is not None:
+            ages = self.__dict__.setdefault("_off_offer_at", {})
+            if min_age is not None and not getattr(self, "_warned", False):
+                young = [q for q in ((first + j) % self.n_slots for j in range(len(plans))) if q in ages and now - ages[q] < min_age]
+                if young:
+                    import warnings
+                    warnings.warn("PlanPool: slot %d is re-published %d env-steps after it went off offer (< %d, the longest "
+                                  "episode): the pool (%d slots) is too small for this refresh cadence" %
+                                  (young[0], now - ages[young[0]], min_age, self.n_slots), RuntimeWarning, stacklevel=2)
+                    self._warned = True
+            for q in getattr(self, "_on_offer", []):       # the plans on offer until now go off offer
+                ages[q] = now
+            self._on_offer = [(first + j) % self.n_slots for j in range(len(plans))]
         wpv, lv = self.wp.view(self.n_slots, self.w_max, self.d), self.left.view(self.n_slots, self.w_max)
         for j, (w, l, r) in enumerate(plans):
             w = np.asarray(w, np.float32)
@@ -417,6 +437,8 @@ class PlanPool:
         s.per_row_projection = int(self.per_row)
         s.plan_of, s.wp_len = self.plan_of.data_ptr(), self.wp_len.data_ptr()
         s.active = None if self.active is None else self.active.data_ptr()
+        if getattr(self, "live_list", None) is not None:       # compact work list of the live problems (ssc_nav_compact)
+            s.live_list, s.n_live = self.live_list.data_ptr(), self.n_live.data_ptr()
         return s
 
 

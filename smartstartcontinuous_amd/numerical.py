@@ -152,7 +152,9 @@ def path_shortcutter(path, distance_func, theta, native=True):
     With the elliptical distance of this module the work is done by libssc's host routine (``native=False``: numpy)."""
     a = np.ascontiguousarray(path, dtype=np.float64)
     radii = getattr(distance_func, "radii", None)
-    if native and radii is not None and a.ndim == 2 and 1 <= a.shape[1] <= 8 and a.shape[1] == len(radii):
+    # (d < 8: the native routine sums the squared terms in index order, like np.sum over a last axis shorter than numpy's
+    # 8-accumulator pairwise unrolling; at d == 8 numpy associates differently and a pair within an ulp of theta could flip)
+    if native and radii is not None and a.ndim == 2 and 1 <= a.shape[1] < 8 and a.shape[1] == len(radii):
         return _native_path_shortcut(a, radii, theta)
     dist = distance_func(a[:, None, :], a[None, :, :])
     pairs = np.transpose(np.where(np.triu(dist <= theta, k=2)))

@@ -46,7 +46,11 @@ class ReplayBuffer:
 
     @next_episode_number.setter
     def next_episode_number(self, value):
+        # the reference assigns the counter and leaves the VALUES in episode_starting_indices alone (clear() :105-107,
+        # load() :131): re-express the absolute starts so that the view keeps reading the same numbers
+        view = [a - self._base for a in self._starts]
         self._base = self._added - int(value)
+        self._starts = deque(v + self._base for v in view)
 
     # ------------------------------------------------------------------ storage helpers --
     def _alloc(self, s, a):
@@ -137,8 +141,9 @@ class ReplayBuffer:
         return np.concatenate([s, self._s2[self._phys(self._len - 1)][None, :]], axis=0)
 
     def clear(self):
+        """replay_buffer.py:105-107: the records go, next_episode_number = 0, episode_starting_indices keeps its values."""
         self._head = self._len = 0
-        self._base = self._added      # next_episode_number = 0; the starts are kept, like the reference's clear()
+        self.next_episode_number = 0
 
     # ------------------------------------------------------------------------ episodes --
     def start_new_episode(self, observing_agent):

@@ -246,6 +246,13 @@ class VecSmartStart:
         self.nav.start_idx.zero_()
         self.mode = torch.zeros(env.n, dtype=torch.uint8, device=dev)
         self.pool.active = self.mode     # the MPC launches skip the envs that are not navigating (where the kernels can)
+        # ... and spend their threads on the navigating envs only: every step starts by compacting ``mode`` into a list
+        # (``ssc_nav_compact``); simulation (fused small-network kernel) and scoring (one-launch scorer) then cover
+        # list[0 .. count) with the launch geometry of all envs (HIP-graph safe: blocks past the count exit at once).
+        # The step kernel -- the last launch of a step -- leaves the counter at zero for the next step.
+        self.live_list = torch.zeros(env.n, dtype=torch.int32, device=dev)
+        self.n_live = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.pool.live_list, self.pool.n_live = self.live_list, self.n_live
         self.actor_out = torch.zeros((env.n, 1), dtype=torch.float32, device=dev)
         self.d_eta = torch.tensor([self.eta], dtype=torch.float32, device=dev)
         self.d_eps = torch.tensor([0.0], dtype=torch.float32, device=dev)
@@ -305,7 +312,7 @@ class VecSmartStart:
                 continue
             plans.append(self.plan_from_path(path.double().cpu().numpy()))
         if plans:
-            self.pool.publish(plans)
+            self.pool.publish(plans, now=self.env.t, min_age=(self.env.spec.max_episode_steps or 1000))
             self.last_radii = plans[0][2]
             self.selections += 1
         return chosen
@@ -320,6 +327,7 @@ class VecSmartStart:
         n = a.decaying_ou_action_noise
         ss.ou.mu, ss.ou.sigma, ss.ou.theta, ss.ou.dt = float(a.ou["mu"]), float(a.ou["sigma"]), float(a.ou["theta"]), float(n.dt)
         ss.act_low, ss.act_high = float(e.action_space.low[0]), float(e.action_space.high[0])
+        ss.d_n_live = self.n_live.data_ptr()
         if self.log_modes:
             if self.mode_log is None or self.mode_log.shape != (chunk_k, e.n):
                 self.mode_log = torch.zeros((chunk_k, e.n), dtype=torch.uint8, device=e.device)
@@ -332,9 +340,11 @@ class VecSmartStart:
         env, b, lib = self.env, self.nav, _ffi.lib()
         fb = b._fused_buffers(env.device)
         with torch.cuda.device(env.device):
+            _ffi.check(lib.ssc_nav_compact(env.n, _ffi.ptr(self.mode), _ffi.ptr(self.live_list), _ffi.ptr(self.n_live), _stream()))
             _ffi.check(lib.ssc_actor_forward(ctypes.byref(self.agent._desc), env.n, _ffi.ptr(fb["plan"]),
                                              _ffi.ptr(self.actor_out), _stream()))
-        sp = nav.mpc_sampling(b.N, b.low, b.high, b.seed, b.problem_id0, 0, t_base=fb["t"], active=self.mode)
+        sp = nav.mpc_sampling(b.N, b.low, b.high, b.seed, b.problem_id0, 0, t_base=fb["t"], active=self.mode,
+                              live_list=self.live_list, n_live=self.n_live)
         S = self.model.do_forward_sim_sampled(fb["plan"], sp, b.P * b.N, b.H, out=b._S, A_out=fb["A"])
         st = self.pool.as_struct(b.N, b.H)
         navs = _ffi.MpcNavState(self.pool.cur_idx.data_ptr(), b.start_idx.data_ptr(), b.actions_done.data_ptr(),
@@ -359,7 +369,7 @@ class VecSmartStart:
         e, b = self.env, self.nav
         fb = b._fused_buffers(e.device)
         return [e.s0, e.s1, e.steps, e.ep_ret, e.ou_x, e.stats, self.pool.cur_idx, self.pool.plan_of, b.actions_done,
-                b.at_goal, self.mode, fb["plan"], fb["t"], fb["k"]]
+                b.at_goal, self.mode, fb["plan"], fb["t"], fb["k"], self.n_live]
 
     def rollout(self, K, out, ring=None, graph=True):
         """K steps of every env into the TransitionChunk ``out`` (one graph replay per step when ``graph``)."""

@@ -225,6 +225,40 @@ def replay_buffer_kats():
     print("replay kats ok")
 
 
+def replay_buffer_clear_kats():
+    """clear() and a direct assignment of next_episode_number on the reference's ReplayBuffer (replay_buffer.py:105-107,
+    :131): the VALUES in episode_starting_indices stay, only the counter moves.  Trace of (len, next_episode_number,
+    episode_starting_indices) after every operation of a fixed script."""
+    rb = load_by_path("ref_replay_buffer", "smartstart/RLAgents/replay_buffer.py")
+    agent = object()
+    buf = rb.ReplayBuffer(agent, 40)
+    ops, trace = [], []
+    k = 0
+
+    def snap(op):
+        ops.append(op)
+        trace.append([len(buf.buffer), buf.next_episode_number] + list(buf.episode_starting_indices) +
+                     [-99] * (16 - len(buf.episode_starting_indices)))
+    script = [("ep", 7), ("ep", 5), ("clear", 0), ("ep", 4), ("ep", 9), ("set", 3), ("ep", 6), ("ep", 30), ("clear", 0), ("ep", 3)]
+    for kind, arg in script:
+        if kind == "ep":
+            buf.start_new_episode(agent)
+            snap(0)
+            for _ in range(arg):
+                buf.add(agent, np.array([k, 0.0]), np.array([0.0]), 0.0, False, np.array([k + 1, 0.0]))
+                k += 1
+                snap(1)
+        elif kind == "clear":
+            buf.clear()
+            snap(2)
+        else:
+            buf.next_episode_number = arg
+            snap(3)
+    np.savez_compressed(os.path.join(OUT, "replay_buffer_clear_kats.npz"), script_kind=np.array([["ep", "clear", "set"].index(a) for a, _ in script]),
+                        script_arg=np.array([b for _, b in script]), ops=np.asarray(ops), trace=np.asarray(trace, np.int64))
+    print("replay clear kats ok:", len(ops), "operations")
+
+
 def summary_json_fixture():
     """One of the reference's own Summary dumps (data/**/*.json, written by Summary.save,
     smartstart/utilities/datacontainers.py:288-326), trimmed to its first 60 episode records so that the

@@ -251,3 +251,30 @@ def test_vec_smartstart_dynamics_model_aggregation(ssc):
     y32 = smart.model.forward(X[:512], precision="f32")
     y16 = smart.model.forward(X[:512], precision="bf16_mfma")
     assert float((y32 - y16).abs().max()) < 5e-2 * max(1.0, float(y32.abs().max()))
+
+
+def test_plan_pool_too_small_for_the_refresh_cadence_is_reported_and_harmless(ssc):
+    """``n_slots`` is sized from the constructor's ``chunk_steps``; rolling SHORTER chunks (or a hand-sized pool)
+    re-publishes a slot under envs that still follow it.  ``PlanPool.publish`` reports that once (RuntimeWarning) and the
+    kernels clamp the waypoint index to the new plan, so nothing is read outside a plan: after every chunk each navigating
+    env's index lies inside the plan it follows, and every logged value is finite."""
+    n, K, max_steps = 96, 4, 17
+    env, agent, w, _, smart = _setup(ssc, n, max_steps, 1.0, 31, N=32, H=3, chunk=64, n_plans=3)
+    assert smart.pool.n_slots == 9                                   # 3 plans x (ceil(17 / 64) + 2): sized for 64-step chunks
+    rng = np.random.default_rng(5)
+    chunk = ssc.TransitionChunk(2, K, n, "cuda")
+    with pytest.warns(RuntimeWarning, match="too small for this refresh cadence"):
+        for c in range(12):                                          # a refresh every 4 steps: a slot comes round after 12 < 17 steps
+            plans = _plans(rng, 3, 0)
+            if c % 2:                                                # alternate long and short plans: indices beyond the new length
+                plans = [(p[:3], l[:3], r) for p, l, r in plans]
+            smart.pool.publish(plans, now=env.t, min_age=max_steps)
+            smart.rollout(K, chunk)
+            torch.cuda.synchronize()
+            mode = smart.mode.cpu().numpy().astype(bool)
+            cur = smart.pool.cur_idx.cpu().numpy()
+            wlen = smart.pool.wp_len.cpu().numpy()[smart.pool.plan_of.cpu().numpy()]
+            assert (cur[mode] < wlen[mode]).all() and (cur >= 0).all()
+            for col in (chunk.obs, chunk.act, chunk.rew, chunk.obs2):
+                assert bool(torch.isfinite(col).all())
+    assert int(mode.sum()) > 0 or int(smart.mode_log.sum()) > 0       # envs did navigate

@@ -84,6 +84,55 @@ def test_replay_buffer_matches_reference_trace(golden_dir):
     assert len(buf) == 50 and buf.buffer[-1][0][0] == k - 1 and buf.buffer[0][0][0] == k - 50
 
 
+def test_replay_buffer_clear_and_counter_assignment_match_reference_trace(golden_dir):
+    """clear() and ``next_episode_number = v`` (replay_buffer.py:105-107, :131): the reference moves the counter and keeps
+    the VALUES of episode_starting_indices; tests/golden/replay_buffer_clear_kats.npz holds its (len, counter, starts)
+    after every operation of the script make_goldens.py:replay_buffer_clear_kats ran through it."""
+    g = np.load(f"{golden_dir}/replay_buffer_clear_kats.npz")
+    agent = object()
+    buf = ReplayBuffer(agent, 40)
+    k, i = 0, 0
+
+    def check(op):
+        nonlocal i
+        row = g["trace"][i]
+        assert int(g["ops"][i]) == op
+        starts = [int(v) for v in row[2:] if v != -99]
+        assert (len(buf.buffer), buf.next_episode_number, list(buf.episode_starting_indices)) == (int(row[0]), int(row[1]), starts), (i, op)
+        i += 1
+    for kind, arg in zip(g["script_kind"], g["script_arg"]):
+        if kind == 0:
+            buf.start_new_episode(agent)
+            check(0)
+            for _ in range(int(arg)):
+                buf.add(agent, np.array([k, 0.0]), np.array([0.0]), 0.0, False, np.array([k + 1, 0.0]))
+                k += 1
+                check(1)
+        elif kind == 1:
+            buf.clear()
+            check(2)
+        else:
+            buf.next_episode_number = int(arg)
+            check(3)
+    assert i == len(g["ops"]) == 74
+
+
+def test_path_shortcutter_takes_the_numpy_route_at_eight_dimensions():
+    """d == 8 is where np.sum over the last axis switches to its 8-accumulator pairwise unrolling: the native routine (strict
+    index order) is used for d < 8 only, so both routes give the numpy decisions -- checked with pairs placed within an
+    ulp of theta."""
+    from smartstartcontinuous_amd import numerical as num
+    rng = np.random.default_rng(3)
+    for d in (3, 7, 8):
+        radii = rng.uniform(0.5, 2.0, d)
+        dist = num.elliptical_euclidean_distance_function_generator(radii)
+        path = np.cumsum(rng.normal(size=(60, d)) * 0.3, axis=0)
+        path[20] = path[5] + radii * np.sqrt(1.0 / d) * (1.0 - 1e-16)        # a pair at distance theta = 1 to within an ulp
+        a = num.path_shortcutter(path, dist, 1.0)
+        b = num.path_shortcutter(path, dist, 1.0, native=False)
+        assert np.array_equal(a, b), d
+
+
 def test_rltrain_loop_with_fake_env_and_agent():
     """rlTrain control flow (rlTrain.py:63-114) with CPU stand-ins: break on done, max_steps cap,
     agent call order, Summary records."""
