@@ -409,6 +409,11 @@ typedef struct ssc_smartstart_step {
     int64_t mode_log_stride;     /* row stride of d_mode_log (0: P) */
     int32_t *d_n_live;           /* optional: the counter of ssc_nav_compact, zeroed by this launch (the last one of a step) so
                                     that the next step's compaction starts from 0 without a launch of its own */
+    const ssc_actor_desc *actor; /* optional (host pointer): the base agent's actor.  When given and its shape is one the
+                                    step kernel carries (act_dim 1; fp32 64-32, or bf16 MFMA with h1 <= 128 and h2 <= 64) the
+                                    kernel evaluates the actor on each env's own state itself -- the same device code as
+                                    ssc_actor_forward, bit-identical -- and d_actor_out is not read (may be NULL): one
+                                    launch and its boundary less per step.  Other shapes: d_actor_out as before. */
 } ssc_smartstart_step;
 
 /* The envs that are navigating (d_mode[i] != 0) as a compact list: d_list[0 .. *d_count) = their indices (any order),

@@ -97,7 +97,7 @@ class MpcProblems(Structure):
 class SmartStartStep(Structure):
     _fields_ = [("mode", c_void_p), ("plan_of", c_void_p), ("d_actor_out", c_void_p), ("d_eta", c_void_p),
                 ("d_ou_epsilon", c_void_p), ("d_pool", c_void_p), ("ou", OuDesc), ("act_low", c_float), ("act_high", c_float),
-                ("d_mode_log", c_void_p), ("mode_log_stride", c_int64), ("d_n_live", c_void_p)]
+                ("d_mode_log", c_void_p), ("mode_log_stride", c_int64), ("d_n_live", c_void_p), ("actor", c_void_p)]
 
 
 class MpcSampling(Structure):

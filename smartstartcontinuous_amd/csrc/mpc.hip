@@ -447,18 +447,32 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_small_kernel(MpcArgs a, SelectA
     SSC_MPC_DISPATCH_D(a, mpc_small_body<G>(a, sel, S, scores, best_idx, best_score));
 }
 
-// The navigating envs as a compact list (ssc_nav_compact): wave ballot + prefix, one atomic per wave for its base.
-__global__ __launch_bounds__(256) void nav_compact_kernel(int64_t n, const uint8_t *__restrict__ mode, int32_t *__restrict__ list,
-                                                          int32_t *__restrict__ count) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// The navigating envs as a compact list (ssc_nav_compact): ballot + prefix inside a wave, the 16 wave counts of a block
+// scanned in LDS, ONE atomic per 1024 envs for the block's base (an atomic per wave -- 1024 of them on one address at
+// 65 536 envs -- made this a 10 us kernel; 64 of them make it a 2 us one).
+constexpr int kCompactBlock = 1024;
+__global__ __launch_bounds__(kCompactBlock) void nav_compact_kernel(int64_t n, const uint8_t *__restrict__ mode, int32_t *__restrict__ list,
+                                                                    int32_t *__restrict__ count) {
+    __shared__ int32_t wave_cnt[kCompactBlock / 64];
+    __shared__ int32_t block_base;
+    const int64_t i = (int64_t)blockIdx.x * kCompactBlock + threadIdx.x;
     const bool nav = i < n && mode[i] != 0;
     const uint64_t b = __builtin_amdgcn_ballot_w64(nav);
-    if (b == 0) return;   // wave-uniform
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(count, __builtin_popcountll(b));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (nav) list[base + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = __builtin_popcountll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < kCompactBlock / 64; ++w) {
+            const int32_t c = wave_cnt[w];
+            wave_cnt[w] = total;      // exclusive prefix
+            total += c;
+        }
+        block_base = total > 0 ? atomicAdd(count, total) : 0;
+    }
+    __syncthreads();
+    if (nav) list[block_base + wave_cnt[wave] + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = (int32_t)i;
 }
 
 struct ActBounds {
@@ -685,7 +699,7 @@ int ssc_nav_compact(int64_t n, const uint8_t *d_mode, int32_t *d_list, int32_t *
     SSC_REQUIRE(n >= 0 && n <= 0x7fffffffLL, "ssc_nav_compact: n = %lld", (long long)n);
     if (n == 0) return SSC_OK;
     SSC_REQUIRE(d_mode && d_list && d_count, "ssc_nav_compact: NULL device pointer");
-    hipLaunchKernelGGL(nav_compact_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), n, d_mode, d_list, d_count);
+    hipLaunchKernelGGL(nav_compact_kernel, dim3(blocks_for(n, kCompactBlock)), dim3(kCompactBlock), 0, as_stream(stream), n, d_mode, d_list, d_count);
     return check_launch("ssc_nav_compact");
 }
 
