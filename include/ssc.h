@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSC_VERSION 106 /* 0.1.6: ssc_nav_compact + live lists in ssc_mpc_sampling / ssc_mpc_problems; 0.1.5: ssc_ou_desc.d_epsilon, ssc_decay_schedule, ssc_replay_append_shard; 0.1.4: ssc_path_shortcut; 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
+#define SSC_VERSION 107 /* 0.1.7: LayerNorm (ssc_actor_desc / ssc_critic_desc ln*, ssc_ddpg_desc.layer_norm); 0.1.6: ssc_nav_compact + live lists in ssc_mpc_sampling / ssc_mpc_problems; 0.1.5: ssc_ou_desc.d_epsilon, ssc_decay_schedule, ssc_replay_append_shard; 0.1.4: ssc_path_shortcut; 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
 
 typedef void *ssc_stream_t; /* hipStream_t */
 
@@ -77,6 +77,11 @@ typedef struct ssc_actor_desc {
                                                  DDPG_editted feeds its networks tf.clip_by_value(obs, observation_range)
                                                  (ddpg_editted.py:106-109, observation_range = (-5, 5) in every run);
                                                  0: no clip (bare Actor_Editted.__call__) */
+    /* layer_norm=True (models_editted.py:45-46, 50-51; the class default, unused by the shipped runs):
+     * tc.layers.layer_norm(center=True, scale=True) [third-party TF 1.5: over the units of a row, variance epsilon 1e-12]
+     * behind each hidden dense layer, in front of its activation.  gamma / beta of layer 1 [h1] and layer 2 [h2], device;
+     * all four NULL: no LayerNorm.  LayerNorm networks run on the fp32 kernels (`precision` must be SSC_PREC_F32). */
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
 } ssc_actor_desc;
 
 /* Exploration noise of DDPG_editted.pi (ddpg_editted.py:266-271):
@@ -409,11 +414,6 @@ typedef struct ssc_smartstart_step {
     int64_t mode_log_stride;     /* row stride of d_mode_log (0: P) */
     int32_t *d_n_live;           /* optional: the counter of ssc_nav_compact, zeroed by this launch (the last one of a step) so
                                     that the next step's compaction starts from 0 without a launch of its own */
-    const ssc_actor_desc *actor; /* optional (host pointer): the base agent's actor.  When given and its shape is one the
-                                    step kernel carries (act_dim 1; fp32 64-32, or bf16 MFMA with h1 <= 128 and h2 <= 64) the
-                                    kernel evaluates the actor on each env's own state itself -- the same device code as
-                                    ssc_actor_forward, bit-identical -- and d_actor_out is not read (may be NULL): one
-                                    launch and its boundary less per step.  Other shapes: d_actor_out as before. */
 } ssc_smartstart_step;
 
 /* The envs that are navigating (d_mode[i] != 0) as a compact list: d_list[0 .. *d_count) = their indices (any order),
@@ -440,6 +440,7 @@ typedef struct ssc_critic_desc {
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     int32_t last_layer_tanh;
     float obs_clip;             /* as in ssc_actor_desc (ddpg_editted.py:106-109); 0: no clip */
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b; /* LayerNorm (models_editted.py:85-86, 91-92) as in ssc_actor_desc; NULL: none */
 } ssc_critic_desc;
 
 /* q[m] = Critic(obs[m][obs_dim], act[m][act_dim]) -- the batched get_q_value of
@@ -482,6 +483,11 @@ typedef struct ssc_ddpg_desc {
     float beta1, beta2, epsilon;                          /* MpiAdam: 0.9, 0.999, 1e-8 (ddpg_editted.py:176,198) */
     float obs_clip;                                       /* > 0: obs0 / obs1 clipped to [-obs_clip, obs_clip] before every
                                                              network (ddpg_editted.py:106-109); 0: no clip */
+    int32_t layer_norm;                                   /* 1: actor and critic carry LayerNorm (models_editted.py:45-46,50-51,
+                                                             85-86,91-92): every flat vector is then
+                                                             [W1|b1|beta1|gamma1|W2|b2|beta2|gamma2|W3|b3] (TF trainable_vars order;
+                                                             tc.layers.layer_norm creates beta before gamma) and the step runs on
+                                                             the multi-workgroup kernels (ssc_ddpg_train_ws) */
 } ssc_ddpg_desc;
 
 /* Replay storage the batches are drawn from: row-major device arrays of `capacity` records

@@ -42,7 +42,8 @@ class ActorDesc(Structure):
     _fields_ = [("obs_dim", c_int32), ("h1", c_int32), ("h2", c_int32), ("act_dim", c_int32),
                 ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
                 ("W3", c_void_p), ("b3", c_void_p),
-                ("last_layer_tanh", c_int32), ("precision", c_int32), ("obs_clip", c_float)]
+                ("last_layer_tanh", c_int32), ("precision", c_int32), ("obs_clip", c_float),
+                ("ln1_g", c_void_p), ("ln1_b", c_void_p), ("ln2_g", c_void_p), ("ln2_b", c_void_p)]
 
 
 class OuDesc(Structure):
@@ -97,7 +98,7 @@ class MpcProblems(Structure):
 class SmartStartStep(Structure):
     _fields_ = [("mode", c_void_p), ("plan_of", c_void_p), ("d_actor_out", c_void_p), ("d_eta", c_void_p),
                 ("d_ou_epsilon", c_void_p), ("d_pool", c_void_p), ("ou", OuDesc), ("act_low", c_float), ("act_high", c_float),
-                ("d_mode_log", c_void_p), ("mode_log_stride", c_int64), ("d_n_live", c_void_p), ("actor", c_void_p)]
+                ("d_mode_log", c_void_p), ("mode_log_stride", c_int64), ("d_n_live", c_void_p)]
 
 
 class MpcSampling(Structure):
@@ -109,7 +110,8 @@ class MpcSampling(Structure):
 class CriticDesc(Structure):
     _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("h1", c_int32), ("h2", c_int32),
                 ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
-                ("W3", c_void_p), ("b3", c_void_p), ("last_layer_tanh", c_int32), ("obs_clip", c_float)]
+                ("W3", c_void_p), ("b3", c_void_p), ("last_layer_tanh", c_int32), ("obs_clip", c_float),
+                ("ln1_g", c_void_p), ("ln1_b", c_void_p), ("ln2_g", c_void_p), ("ln2_b", c_void_p)]
 
 
 class MlpTrainDesc(Structure):
@@ -127,7 +129,7 @@ class DdpgDesc(Structure):
                 ("adam_m_actor", c_void_p), ("adam_v_actor", c_void_p), ("adam_m_critic", c_void_p),
                 ("adam_v_critic", c_void_p), ("adam_t", c_void_p),
                 ("gamma", c_float), ("tau", c_float), ("actor_lr", c_float), ("critic_lr", c_float),
-                ("beta1", c_float), ("beta2", c_float), ("epsilon", c_float), ("obs_clip", c_float)]
+                ("beta1", c_float), ("beta2", c_float), ("epsilon", c_float), ("obs_clip", c_float), ("layer_norm", c_int32)]
 
 
 class ReplayView(Structure):

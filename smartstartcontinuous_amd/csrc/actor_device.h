@@ -25,7 +25,9 @@ struct ActorWeights {
     int32_t obs_dim, h1, h2;
     int32_t last_layer_tanh;
     float obs_clip;  // > 0: clip the observation to [-obs_clip, obs_clip] first (ddpg_editted.py:106-109); 0: no clip
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;  // LayerNorm gamma / beta of the two hidden layers (ssc_actor_desc); null: none
 };
+
 
 // tf.clip_by_value(obs, -c, c) of DDPG_editted's network inputs; c <= 0 leaves x alone (wave-uniform select)
 __device__ __forceinline__ float clip_obs(float x, float c) { return c > 0.0f ? fminf(fmaxf(x, -c), c) : x; }

@@ -612,34 +612,15 @@ struct SsStepArgs {
     uint8_t *mode_log;
     int64_t mode_log_stride;
     int32_t *n_live;   // ssc_smartstart_step::d_n_live: zeroed here for the next step's ssc_nav_compact
-    ActorWeights aw;   // ssc_smartstart_step::actor, when the kernel evaluates the base agent's actor itself (Net != NoActor)
 };
 
-struct NoActor {};
-
-// Net (SmartStart step only): NoActor -- the base agent's action comes from sa.actor_out (a launch of ssc_actor_forward in front
-// of this one) -- or one of the actor classes of actor_device.h, evaluated here on the env's own observation: the same
-// device code as ssc_actor_forward's kernels, so the same bits, without that launch and its boundary.
-template <class EnvT, bool SS = false, class Net = NoActor>
+template <class EnvT, bool SS = false>
 __global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT::Const ec, RolloutArgs ra, MpcStepArgs ma, SsStepArgs sa) {
     constexpr int OBS = EnvT::OBS;
-    constexpr bool FUSED_ACTOR = !std::is_same<Net, NoActor>::value;
     const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (SS && gi == 0 && sa.n_live != nullptr) *sa.n_live = 0;   // simulation and scoring of this step are behind us in the stream
     const bool active = gi < ra.n;
     const int64_t i = active ? gi : ra.n - 1;
-    float fused_a = 0.0f;
-    if constexpr (FUSED_ACTOR) {   // whole blocks / waves run the (block-cooperative or wave-collective) forward: lanes past n shadow env n - 1
-        EnvT e0;
-        e0.load(ra.st.s0[i], ra.st.s1[i]);
-        float o[OBS];
-        e0.observe(o);
-#pragma unroll
-        for (int c = 0; c < OBS; ++c) o[c] = clip_obs(o[c], sa.aw.obs_clip);
-        Net net;
-        net.init(sa.aw);
-        fused_a = net.forward(o);
-    }
     const uint64_t t = *ma.d_t;
     const int32_t k = *ma.d_k;
     float rew = 0.0f;
@@ -672,7 +653,7 @@ __global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT:
         } else {
             // DDPG_Baselines_agent.get_action (:206-240): actor + epsilon * OU, clip, scale twice -- ActorPolicy::act's
             // arithmetic and noise stream; the OU state moves on these steps only (the agent is not asked while navigating)
-            a = FUSED_ACTOR ? fused_a : sa.actor_out[i];
+            a = sa.actor_out[i];
             const float eps = fmaxf(*sa.d_eps, 0.0f);
             if (eps > 0.0f) {
                 const u32x4 w = rng_words(ra.seed, ra.env_id0 + (uint64_t)i, t >> 2, TAG_OU);
@@ -972,7 +953,7 @@ extern "C" int ssc_smartstart_rollout_step(const ssc_env_params *p, const ssc_mp
                                      state, log, ring, d_stats, env_seed, env_id0, d_t, d_k, d_ticket, d_plan_state, ra, ma))
         return rc;
     SSC_REQUIRE(ss != nullptr, "ssc_smartstart_rollout_step: NULL step descriptor");
-    SSC_REQUIRE(ss->mode && ss->plan_of && (ss->d_actor_out || ss->actor) && ss->d_eta && ss->d_ou_epsilon && ss->d_pool,
+    SSC_REQUIRE(ss->mode && ss->plan_of && ss->d_actor_out && ss->d_eta && ss->d_ou_epsilon && ss->d_pool,
                 "ssc_smartstart_rollout_step: NULL device pointer in the step descriptor");
     SSC_REQUIRE(pr->plan_of != nullptr && pr->plan_of == ss->plan_of && pr->wp_len != nullptr,
                 "ssc_smartstart_rollout_step: the problem set must use the plan pool (plan_of == ss->plan_of, wp_len)");
@@ -988,37 +969,14 @@ extern "C" int ssc_smartstart_rollout_step(const ssc_env_params *p, const ssc_mp
     sa.mode_log = ss->d_mode_log; sa.mode_log_stride = ss->mode_log_stride ? ss->mode_log_stride : n;
     sa.n_live = ss->d_n_live;
     SSC_REQUIRE(sa.mode_log_stride >= n, "ssc_smartstart_rollout_step: mode log stride < n");
-    // which actor class (if any) the step kernel evaluates itself: 0 none, 1 fp32 64-32, 2 MFMA <= 64-32, 3 MFMA <= 128-64
-    int fuse = 0;
-    const int obs_dim = (p->kind == SSC_ENV_MOUNTAINCAR) ? 2 : 3;
-    if (const ssc_actor_desc *a = ss->actor) {
-        SSC_REQUIRE(a->W1 && a->b1 && a->W2 && a->b2 && a->W3 && a->b3, "ssc_smartstart_rollout_step: NULL actor weight pointer");
-        SSC_REQUIRE(a->obs_dim == obs_dim, "ssc_smartstart_rollout_step: the actor takes %d observations, the env gives %d", a->obs_dim, obs_dim);
-        if (a->act_dim == 1) {
-            if (a->precision == SSC_PREC_F32 && a->h1 == 64 && a->h2 == 32) fuse = 1;
-            else if (a->precision == SSC_PREC_BF16_MFMA && a->h1 <= 64 && a->h2 <= 32) fuse = 2;
-            else if (a->precision == SSC_PREC_BF16_MFMA && a->h1 <= 128 && a->h2 <= 64) fuse = 3;
-        }
-        if (fuse) sa.aw = ActorWeights{a->W1, a->b1, a->W2, a->b2, a->W3, a->b3, a->obs_dim, a->h1, a->h2, a->last_layer_tanh, a->obs_clip};
-    }
-    SSC_REQUIRE(fuse != 0 || ss->d_actor_out != nullptr, "ssc_smartstart_rollout_step: this actor shape needs d_actor_out (ssc_actor_forward)");
     hipStream_t s = as_stream(stream);
-    const dim3 grid(blocks_for(n)), block(kBlock);
-#define SSC_SS_LAUNCH(ENV, OBSN, CONST)                                                                                                  \
-    do {                                                                                                                                 \
-        if (fuse == 1) hipLaunchKernelGGL((mpc_rollout_step_kernel<ENV, true, ActorF32<OBSN, 64, 32>>), grid, block, 0, s, CONST, ra, ma, sa); \
-        else if (fuse == 2) hipLaunchKernelGGL((mpc_rollout_step_kernel<ENV, true, ActorMfma<OBSN, 2, 1>>), grid, block, 0, s, CONST, ra, ma, sa); \
-        else if (fuse == 3) hipLaunchKernelGGL((mpc_rollout_step_kernel<ENV, true, ActorMfma<OBSN, 4, 2>>), grid, block, 0, s, CONST, ra, ma, sa); \
-        else hipLaunchKernelGGL((mpc_rollout_step_kernel<ENV, true>), grid, block, 0, s, CONST, ra, ma, sa);                              \
-    } while (0)
     if (p->kind == SSC_ENV_MOUNTAINCAR) {
         if (int rc = validate_mc_params(p, "ssc_smartstart_rollout_step")) return rc;
-        SSC_SS_LAUNCH(McEnv, 2, make_mc_const(*p));
+        hipLaunchKernelGGL((mpc_rollout_step_kernel<McEnv, true>), dim3(blocks_for(n)), dim3(kBlock), 0, s, make_mc_const(*p), ra, ma, sa);
     } else if (p->kind == SSC_ENV_PENDULUM) {
-        SSC_SS_LAUNCH(PendEnv, 3, make_pend_const(*p));
+        hipLaunchKernelGGL((mpc_rollout_step_kernel<PendEnv, true>), dim3(blocks_for(n)), dim3(kBlock), 0, s, make_pend_const(*p), ra, ma, sa);
     } else {
         return set_error(SSC_EINVAL, "ssc_smartstart_rollout_step: unknown env kind %d", p->kind);
     }
-#undef SSC_SS_LAUNCH
     return check_launch("ssc_smartstart_rollout_step");
 }

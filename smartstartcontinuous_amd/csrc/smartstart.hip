@@ -16,12 +16,14 @@ struct CriticW {
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     int32_t obs_dim, act_dim, h1, h2, last_tanh;
     float obs_clip;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;   // LayerNorm (models_editted.py:85-86, 91-92); null: none
 };
 
 // one row per lane; layer-1 activations (+ the action, models_editted.py:89) parked in LDS as [unit][lane]
 __global__ __launch_bounds__(64) void critic_kernel(CriticW w, int64_t m, const float *__restrict__ obs,
                                                     const float *__restrict__ act, float *__restrict__ q) {
-    extern __shared__ float hs[];  // [(h1 + act_dim)][64]
+    extern __shared__ float hs[];  // [(h1 + act_dim)][64] (+ [h2][64] with LayerNorm)
+    const bool ln = w.ln1_g != nullptr;
     const int lane = threadIdx.x;
     const int64_t gi = (int64_t)blockIdx.x * 64 + lane;
     const bool active = gi < m;
@@ -37,16 +39,32 @@ __global__ __launch_bounds__(64) void critic_kernel(CriticW w, int64_t m, const 
 #pragma unroll
         for (int c = 0; c < SSC_MAX_STATE; ++c)
             if (c < w.obs_dim) acc = fmaf(o[c], w.W1[c * w.h1 + j], acc);
-        hs[j * 64 + lane] = fmaxf(acc, 0.0f);  // models_editted.py:87
+        hs[j * 64 + lane] = ln ? acc : fmaxf(acc, 0.0f);  // models_editted.py:87
+    }
+    if (ln) {   // :85-86
+        float mean, rstd;
+        layer_norm_stats(hs + lane, w.h1, 64, mean, rstd);
+        for (int j = 0; j < w.h1; ++j)
+            hs[j * 64 + lane] = fmaxf(fmaf((hs[j * 64 + lane] - mean) * rstd, w.ln1_g[j], w.ln1_b[j]), 0.0f);
     }
     for (int a = 0; a < w.act_dim; ++a) hs[(w.h1 + a) * 64 + lane] = act[i * w.act_dim + a];  // :89
     const int in2 = w.h1 + w.act_dim;
+    float *h2s = hs + in2 * 64;
     float out = w.b3[0];
     for (int j = 0; j < w.h2; ++j) {
         float acc = w.b2[j];
         for (int k = 0; k < in2; ++k) acc = fmaf(hs[k * 64 + lane], w.W2[k * w.h2 + j], acc);
+        if (ln) { h2s[j * 64 + lane] = acc; continue; }
         const float h2 = w.last_tanh ? tanhf(acc) : fmaxf(acc, 0.0f);  // :95-98
         out = fmaf(h2, w.W3[j], out);                                    // :100 (no output tanh)
+    }
+    if (ln) {   // :91-92
+        float mean, rstd;
+        layer_norm_stats(h2s + lane, w.h2, 64, mean, rstd);
+        for (int j = 0; j < w.h2; ++j) {
+            const float n2 = fmaf((h2s[j * 64 + lane] - mean) * rstd, w.ln2_g[j], w.ln2_b[j]);
+            out = fmaf(w.last_tanh ? tanhf(n2) : fmaxf(n2, 0.0f), w.W3[j], out);
+        }
     }
     if (active) q[i] = out;
 }
@@ -195,8 +213,13 @@ int ssc_critic_forward(const ssc_critic_desc *c, int64_t m, const float *d_obs, 
     if (m == 0) return SSC_OK;
     SSC_REQUIRE(c->W1 && c->b1 && c->W2 && c->b2 && c->W3 && c->b3 && d_obs && d_act && d_q,
                 "ssc_critic_forward: NULL device pointer");
-    const CriticW w{c->W1, c->b1, c->W2, c->b2, c->W3, c->b3, c->obs_dim, c->act_dim, c->h1, c->h2, c->last_layer_tanh, c->obs_clip};
-    const size_t lds = (size_t)(c->h1 + c->act_dim) * 64 * sizeof(float);
+    const CriticW w{c->W1, c->b1, c->W2, c->b2, c->W3, c->b3, c->obs_dim, c->act_dim, c->h1, c->h2, c->last_layer_tanh, c->obs_clip,
+                    c->ln1_g, c->ln1_b, c->ln2_g, c->ln2_b};
+    const bool ln = c->ln1_g != nullptr;
+    SSC_REQUIRE(ln == (c->ln1_b != nullptr) && ln == (c->ln2_g != nullptr) && ln == (c->ln2_b != nullptr),
+                "ssc_critic_forward: the four LayerNorm pointers come together");
+    const size_t lds = (size_t)(c->h1 + c->act_dim + (ln ? c->h2 : 0)) * 64 * sizeof(float);
+    if (lds > 160 * 1024) return set_error(SSC_EUNSUPPORTED, "ssc_critic_forward: h1 %d + h2 %d too wide for the LayerNorm kernel", c->h1, c->h2);
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),

@@ -252,4 +252,18 @@ __device__ __forceinline__ void half_swap(float a, float b, float &lo_lo, float 
     hi_hi = b;
 }
 
+// tc.layers.layer_norm(center=True, scale=True) [third-party TF 1.5] over n values x[i * stride]: mean and biased variance
+// (tf.nn.moments) summed in index order, variance epsilon 1e-12 -> (mean, 1 / sqrt(var + eps))
+__device__ __forceinline__ void layer_norm_stats(const float *x, int n, int stride, float &mean, float &rstd) {
+    float s = 0.0f;
+    for (int i = 0; i < n; ++i) s += x[i * stride];
+    mean = s / (float)n;
+    float v = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const float d = x[i * stride] - mean;
+        v = fmaf(d, d, v);
+    }
+    rstd = 1.0f / sqrtf(v / (float)n + 1e-12f);
+}
+
 }  // namespace ssc

@@ -213,10 +213,11 @@ class VecSmartStart:
     ``n_plans`` best candidates' episodic paths into plans (radii, optional shortcutting, waypoints, distances_left --
     NND_MB_agent.start_new_episode_plan's host geometry) and publishes them in a :class:`navigator.PlanPool`; the envs
     finishing during the chunk draw from those.  ``n_plans = 1`` is the reference's argmax for every episode that starts
-    before the next refresh.  One step = four launches -- compaction of the navigating envs (``ssc_nav_compact``), forward
-    simulation drawing its own candidates, scoring (one launch for N <= 64 candidates, two above), and
-    ``ssc_smartstart_rollout_step``, which also evaluates the base agent's actor for the shipped network shapes (other shapes:
-    an ``ssc_actor_forward`` launch in front) -- captured once as a HIP graph and replayed K times per chunk.
+    before the next refresh.  One step = five launches -- compaction of the navigating envs (``ssc_nav_compact``), actor
+    forward, forward simulation drawing its own candidates, scoring (one launch for N <= 64 candidates, two above), and
+    ``ssc_smartstart_rollout_step`` -- captured once as a HIP graph and replayed K times per chunk.  (Evaluating the actor
+    inside the step kernel was built and measured in round 4: 42.5 us against 21.3 + 10.8 us for the two launches -- the
+    step kernel is a one-wave-per-SIMD latency chain and the actor's weight fetch lengthens it; NOTEBOOK section 10.)
     """
 
     def __init__(self, env, agent, dyn_model, eta=0.5, eta_decay_factor=1.0, n_ss=1000, exploitation_param=1.,
@@ -330,22 +331,11 @@ class VecSmartStart:
         ss.ou.mu, ss.ou.sigma, ss.ou.theta, ss.ou.dt = float(a.ou["mu"]), float(a.ou["sigma"]), float(a.ou["theta"]), float(n.dt)
         ss.act_low, ss.act_high = float(e.action_space.low[0]), float(e.action_space.high[0])
         ss.d_n_live = self.n_live.data_ptr()
-        if self._actor_in_step():
-            ss.actor = ctypes.addressof(a._desc)      # the step kernel evaluates the actor itself (no ssc_actor_forward launch)
         if self.log_modes:
             if self.mode_log is None or self.mode_log.shape != (chunk_k, e.n):
                 self.mode_log = torch.zeros((chunk_k, e.n), dtype=torch.uint8, device=e.device)
             ss.d_mode_log, ss.mode_log_stride = self.mode_log.data_ptr(), e.n
         return ss
-
-    def _actor_in_step(self):
-        """The actor shapes ``ssc_smartstart_rollout_step`` carries itself (include/ssc.h, ssc_smartstart_step.actor)."""
-        d = self.agent._desc
-        if d.act_dim != 1:
-            return False
-        if d.precision == _ffi.SSC_PREC_F32:
-            return (d.h1, d.h2) == (64, 32)
-        return d.precision == _ffi.SSC_PREC_BF16_MFMA and d.h1 <= 128 and d.h2 <= 64
 
     def fused_step(self, chunk, ring):
         """Enqueue ONE step for every env (five launches); step index and log row are device counters."""
@@ -354,9 +344,8 @@ class VecSmartStart:
         fb = b._fused_buffers(env.device)
         with torch.cuda.device(env.device):
             _ffi.check(lib.ssc_nav_compact(env.n, _ffi.ptr(self.mode), _ffi.ptr(self.live_list), _ffi.ptr(self.n_live), _stream()))
-            if not self._actor_in_step():
-                _ffi.check(lib.ssc_actor_forward(ctypes.byref(self.agent._desc), env.n, _ffi.ptr(fb["plan"]),
-                                                 _ffi.ptr(self.actor_out), _stream()))
+            _ffi.check(lib.ssc_actor_forward(ctypes.byref(self.agent._desc), env.n, _ffi.ptr(fb["plan"]),
+                                             _ffi.ptr(self.actor_out), _stream()))
         sp = nav.mpc_sampling(b.N, b.low, b.high, b.seed, b.problem_id0, 0, t_base=fb["t"], active=self.mode,
                               live_list=self.live_list, n_live=self.n_live)
         S = self.model.do_forward_sim_sampled(fb["plan"], sp, b.P * b.N, b.H, out=b._S, A_out=fb["A"])

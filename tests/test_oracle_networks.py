@@ -198,6 +198,75 @@ def test_ddpg_train_step_matches_torch_autograd():
         assert adam2["t_actor"] == 1 and adam2["t_critic"] == 1
 
 
+def ln_params(rng, in_dim, h1, h2, out, extra=0):
+    """Random actor / critic parameters WITH LayerNorm (gamma around 1, beta around 0: not the initial 1 / 0, so that both
+    enter the gradients non-trivially); ``extra``: the critic's action rows of W2."""
+    return dict(W1=rng.normal(size=(in_dim, h1)) * 0.5, b1=rng.normal(size=h1) * 0.1, ln1_b=rng.normal(size=h1) * 0.1,
+                ln1_g=1.0 + 0.2 * rng.normal(size=h1), W2=rng.normal(size=(h1 + extra, h2)) * 0.3, b2=rng.normal(size=h2) * 0.1,
+                ln2_b=rng.normal(size=h2) * 0.1, ln2_g=1.0 + 0.2 * rng.normal(size=h2), W3=rng.normal(size=(h2, out)) * 0.3,
+                b3=rng.normal(size=out) * 0.1)
+
+
+def test_layer_norm_ddpg_train_step_matches_torch_autograd():
+    """layer_norm=True (models_editted.py:45-46,50-51,85-86,91-92; the class default): the oracle's manual LayerNorm
+    forward / backward inside ddpg_train_step against torch autograd through torch.nn.functional.layer_norm with
+    tc.layers.layer_norm's epsilon (1e-12), parameters in TF order (kernel, bias, beta, gamma per layer)."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(11)
+    for llt in (True, False):
+        aw, cw = ln_params(rng, 3, 24, 12, 1), ln_params(rng, 3, 20, 16, 1, extra=1)
+        taw = {k: v + 0.01 * rng.normal(size=v.shape) for k, v in aw.items()}
+        tcw = {k: v + 0.01 * rng.normal(size=v.shape) for k, v in cw.items()}
+        B = 40
+        batch = (rng.normal(size=(B, 3)), rng.uniform(-1, 1, (B, 1)), rng.normal(size=B), rng.random(B) < 0.1, rng.normal(size=(B, 3)))
+        assert O.param_keys(aw) == O.LN_KEYS and O.flatten_params(aw).size == 3 * 24 + 24 * 3 + 24 * 12 + 12 * 3 + 12 + 1
+        na, nc = O.flatten_params(aw).size, O.flatten_params(cw).size
+        adam = dict(m_actor=np.zeros(na), v_actor=np.zeros(na), t_actor=0, m_critic=np.zeros(nc), v_critic=np.zeros(nc), t_critic=0)
+        a2, c2, ta2, tc2, adam2, closs, aloss = O.ddpg_train_step(aw, cw, taw, tcw, adam, batch, last_layer_tanh=llt)
+        T = lambda d: {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in d.items()}
+        pa, pc = T(aw), T(cw)
+        s, a, r, t, s2 = (torch.tensor(np.asarray(x, np.float64)) for x in batch)
+        act_fn = torch.tanh if llt else torch.relu
+        ln = lambda x, p, w: F.layer_norm(x, (x.shape[-1],), p[w + "_g"], p[w + "_b"], eps=1e-12)
+
+        def actor(p, x):
+            h = torch.relu(ln(x @ p["W1"] + p["b1"], p, "ln1"))
+            return torch.tanh(act_fn(ln(h @ p["W2"] + p["b2"], p, "ln2")) @ p["W3"] + p["b3"])
+
+        def critic(p, x, u):
+            h = torch.cat([torch.relu(ln(x @ p["W1"] + p["b1"], p, "ln1")), u], dim=1)
+            return act_fn(ln(h @ p["W2"] + p["b2"], p, "ln2")) @ p["W3"] + p["b3"]
+        # forward functions agree with the oracle's public ones
+        lnp = lambda p: ((p["ln1_g"], p["ln1_b"]), (p["ln2_g"], p["ln2_b"]))
+        core = lambda p: {k: p[k] for k in O.ACTOR_KEYS}
+        assert np.allclose(O.actor_forward(batch[0], **core(aw), last_layer_tanh=llt, layer_norm=lnp(aw)), actor(pa, s).detach().numpy(), atol=1e-12)
+        assert np.allclose(O.critic_forward(batch[0], batch[1], **core(cw), last_layer_tanh=llt, layer_norm=lnp(cw)),
+                           critic(pc, s, a).detach().numpy(), atol=1e-12)
+        with torch.no_grad():
+            y = r[:, None] + (1 - t[:, None]) * 0.99 * critic(T(tcw), s2, actor(T(taw), s2))
+        closs_t = ((critic(pc, s, a) - y) ** 2).mean()
+        gc = torch.autograd.grad(closs_t, [pc[k] for k in O.LN_KEYS])
+        aloss_t = -critic(pc, s, actor(pa, s)).mean()
+        ga = torch.autograd.grad(aloss_t, [pa[k] for k in O.LN_KEYS])
+        assert abs(closs - closs_t.item()) < 1e-12 and abs(aloss - aloss_t.item()) < 1e-12
+
+        def adam1(p, g, lr):
+            a_ = lr * np.sqrt(1 - 0.999) / (1 - 0.9)
+            return p - a_ * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-8)
+        for i, k in enumerate(O.LN_KEYS):
+            gck, gak = gc[i].numpy(), ga[i].numpy()
+            # (Adam's first step is ~ -lr * sign(g): compare where the gradient is not within rounding of zero)
+            okc, oka = np.abs(gck) > 1e-10, np.abs(gak) > 1e-10
+            assert np.allclose(c2[k][okc], adam1(cw[k], gck, 1e-3)[okc], rtol=1e-7, atol=1e-12), k
+            assert np.allclose(a2[k][oka], adam1(aw[k], gak, 1e-4)[oka], rtol=1e-7, atol=1e-12), k
+            assert np.allclose(ta2[k], 0.999 * taw[k] + 0.001 * a2[k]) and np.allclose(tc2[k], 0.999 * tcw[k] + 0.001 * c2[k])
+        # the gradients themselves, through the Adam moments (m = 0.1 g after the first step)
+        gflat_c = np.concatenate([g.numpy().reshape(-1) for g in gc])
+        gflat_a = np.concatenate([g.numpy().reshape(-1) for g in ga])
+        assert np.allclose(adam2["m_critic"], 0.1 * gflat_c, rtol=1e-9, atol=1e-14)
+        assert np.allclose(adam2["m_actor"], 0.1 * gflat_a, rtol=1e-9, atol=1e-14)
+
+
 def test_mlp_train_step_matches_torch_autograd_and_adam():
     """oracle.mlp_train_step (manual backprop + tf-style Adam) against torch autograd + torch.optim.Adam
     (same update rule as tf.train.AdamOptimizer up to where epsilon enters -- compared after ONE step where
