@@ -129,18 +129,32 @@ def init_actor_weights(obs_dim, h1, h2, nb_actions, generator=None):
 
 
 PARAM_KEYS = ("W1", "b1", "W2", "b2", "W3", "b3")
+# layer_norm=True (models_editted.py:45-46, 50-51, 85-86, 91-92): tc.layers.layer_norm creates beta, then gamma
+LN_PARAM_KEYS = ("W1", "b1", "ln1_b", "ln1_g", "W2", "b2", "ln2_b", "ln2_g", "W3", "b3")
+
+
+def param_keys(weights):
+    return LN_PARAM_KEYS if "ln1_g" in weights else PARAM_KEYS
+
+
+def with_layer_norm(weights):
+    """The same network with tc.layers.layer_norm's initial parameters (gamma = 1, beta = 0) behind both hidden layers."""
+    h1, h2 = weights["W1"].shape[1], weights["W2"].shape[1]
+    return dict(weights, ln1_b=torch.zeros(h1), ln1_g=torch.ones(h1), ln2_b=torch.zeros(h2), ln2_g=torch.ones(h2))
 
 
 def flatten_params(weights, device, extra=0):
-    """One flat fp32 tensor in TensorFlow trainable_vars order [W1|b1|W2|b2|W3|b3] plus a dict of VIEWS
-    into it, so that kernels reading the dict see what the learner kernel wrote into the flat array.
+    """One flat fp32 tensor in TensorFlow trainable_vars order [W1|b1|W2|b2|W3|b3] (with LayerNorm:
+    [W1|b1|beta1|gamma1|W2|b2|beta2|gamma2|W3|b3]) plus a dict of VIEWS into it, so that kernels reading the dict see what
+    the learner kernel wrote into the flat array.
     ``extra`` zero-initialised floats follow the parameters in the same allocation (flat[-extra:])."""
-    parts = [torch.as_tensor(weights[k], dtype=torch.float32).reshape(-1) for k in PARAM_KEYS]
+    keys = param_keys(weights)
+    parts = [torch.as_tensor(weights[k], dtype=torch.float32).reshape(-1) for k in keys]
     if extra:
         parts.append(torch.zeros(int(extra), dtype=torch.float32))
     flat = torch.cat(parts).to(device).contiguous()
     views, o = {}, 0
-    for k in PARAM_KEYS:
+    for k in keys:
         shape = tuple(torch.as_tensor(weights[k]).shape)
         n = int(np.prod(shape))
         views[k] = flat[o:o + n].view(shape)
@@ -162,9 +176,12 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         args = dict(locals())
         self.param_dict = {k: (v if isinstance(v, (int, float, bool, str, type(None))) else "Not serializable")
                            for k, v in args.items() if k not in ("self", "__class__")}   # :135-137
-        if layer_norm or normalize_observations or normalize_returns or enable_popart:
-            raise NotImplementedError("layer_norm / observation & return normalisation / popart are not on the "
+        if normalize_observations or normalize_returns or enable_popart:
+            raise NotImplementedError("observation & return normalisation / popart are not on the "
                                       "accelerated path (every shipped run uses False)")
+        self.layer_norm = bool(layer_norm)      # models_editted.py:45-46, 50-51, 85-86, 91-92 (fp32 kernels)
+        if self.layer_norm:
+            precision = "f32"
         self.env = env
         self.device = torch.device(device)
         self.lib = _ffi.lib()
@@ -186,8 +203,11 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         nb_actions = env.action_space.shape[-1]
         obs_dim = env.observation_space.shape[-1]
         gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
-        self.set_weights(init_actor_weights(obs_dim, actor_h1, actor_h2, nb_actions, gen))
-        self.set_critic_weights(init_critic_weights(obs_dim, critic_h1, critic_h2, nb_actions, gen))
+        aw, cw = init_actor_weights(obs_dim, actor_h1, actor_h2, nb_actions, gen), init_critic_weights(obs_dim, critic_h1, critic_h2, nb_actions, gen)
+        if self.layer_norm:
+            aw, cw = with_layer_norm(aw), with_layer_norm(cw)
+        self.set_weights(aw)
+        self.set_critic_weights(cw)
         self.decaying_ou_action_noise = DecayingOrnsteinUhlenbeckActionNoise(
             ou_epsilon, ou_min_epsilon, ou_epsilon_decay_factor, mu=ou_mu * np.ones(nb_actions),
             sigma=float(ou_sigma) * np.ones(nb_actions), theta=ou_theta)   # :152-157
@@ -216,6 +236,8 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         d.last_layer_tanh = int(self.lastLayerTanh)
         d.precision = _ffi.SSC_PREC_F32 if self.precision == "f32" else _ffi.SSC_PREC_BF16_MFMA
         d.obs_clip = float(self.observation_range[1])
+        if "ln1_g" in w:
+            d.ln1_g, d.ln1_b, d.ln2_g, d.ln2_b = (w[k].data_ptr() for k in ("ln1_g", "ln1_b", "ln2_g", "ln2_b"))
         self._desc = d
 
     def set_critic_weights(self, weights):
@@ -232,6 +254,8 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         c.W1, c.b1, c.W2, c.b2, c.W3, c.b3 = (w[k].data_ptr() for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
         c.last_layer_tanh = int(self.lastLayerTanh)
         c.obs_clip = float(self.observation_range[1])
+        if "ln1_g" in w:
+            c.ln1_g, c.ln1_b, c.ln2_g, c.ln2_b = (w[k].data_ptr() for k in ("ln1_g", "ln1_b", "ln2_g", "ln2_b"))
         self._critic_desc = c
 
     def critic(self, obs, act):
@@ -272,6 +296,8 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         """The same action path as a fused-rollout policy (current epsilon).  ``device_epsilon``: the kernel reads
         epsilon from ``self.d_epsilon`` (kept current by a :class:`rl_train.DecaySchedule`) instead of the host value."""
         n = self.decaying_ou_action_noise
+        if "ln1_g" in self.weights:
+            precision = "f32"                    # LayerNorm networks run on the fp32 kernels
         return ActorPolicy(self.weights, last_layer_tanh=self.lastLayerTanh, precision=precision or "bf16_mfma",
                            ou_mu=float(self.ou["mu"]), ou_sigma=float(self.ou["sigma"]), ou_theta=float(self.ou["theta"]),
                            ou_dt=n.dt, ou_epsilon=float(max(n.epsilon, 0)), obs_clip=float(self.observation_range[1]),
@@ -329,6 +355,7 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         d.gamma, d.tau, d.actor_lr, d.critic_lr = self.gamma, self.tau, self.actor_lr, self.critic_lr
         d.beta1, d.beta2, d.epsilon = 0.9, 0.999, 1e-8          # ddpg_editted.py:176,198
         d.obs_clip = float(self.observation_range[1])
+        d.layer_norm = int("ln1_g" in self.weights)
         return d
 
     def train_on(self, s, a, r, t, s2, batch_idx, n_iters):

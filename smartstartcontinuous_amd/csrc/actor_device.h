@@ -42,9 +42,12 @@ struct ActorF32 {
     // ds_read_b128: reading them through the kernel-argument pointers inside the step loop forces
     // hipcc to re-issue ~300 global loads per env-step (the log stores may alias them).
     static constexpr int OFF_B1 = OBS * H1, OFF_W2 = OFF_B1 + H1, OFF_B2 = OFF_W2 + H1 * H2;
-    static constexpr int OFF_W3 = OFF_B2 + H2, OFF_B3 = OFF_W3 + H2, TOTAL = OFF_B3 + 4;
-    const float *lw;  // LDS image: W1[OBS][H1] | b1 | W2[H1][H2] | b2 | W3[H2] | b3
+    static constexpr int OFF_W3 = OFF_B2 + H2, OFF_B3 = OFF_W3 + H2;
+    // LayerNorm gamma / beta of the two hidden layers (models_editted.py:45-46, 50-51), when the network has them
+    static constexpr int OFF_G1 = OFF_B3 + 4, OFF_BE1 = OFF_G1 + H1, OFF_G2 = OFF_BE1 + H1, OFF_BE2 = OFF_G2 + H2, TOTAL = OFF_BE2 + H2;
+    const float *lw;  // LDS image: W1[OBS][H1] | b1 | W2[H1][H2] | b2 | W3[H2] | b3 | gamma1 | beta1 | gamma2 | beta2
     int last_tanh;
+    bool ln;
 
     // block-cooperative: every thread of the block must call it
     __device__ void init(const ActorWeights &w) {
@@ -57,9 +60,30 @@ struct ActorF32 {
             image[OFF_W3 + e] = w.W3[e];
         }
         if (threadIdx.x == 0) image[OFF_B3] = w.b3[0];
+        ln = w.ln1_g != nullptr;
+        if (ln) {
+            for (int e = threadIdx.x; e < H1; e += blockDim.x) { image[OFF_G1 + e] = w.ln1_g[e]; image[OFF_BE1 + e] = w.ln1_b[e]; }
+            for (int e = threadIdx.x; e < H2; e += blockDim.x) { image[OFF_G2 + e] = w.ln2_g[e]; image[OFF_BE2 + e] = w.ln2_b[e]; }
+        }
         __syncthreads();
         lw = image;
         last_tanh = w.last_layer_tanh;
+    }
+
+    // tc.layers.layer_norm over the N values of this lane's row (registers): index-order sums like layer_norm_stats
+    template <int N>
+    static __device__ __forceinline__ void norm_stats(const float (&x)[N], float &mean, float &rstd) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) s += x[i];
+        mean = s / (float)N;
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float d = x[i] - mean;
+            v = fmaf(d, d, v);
+        }
+        rstd = 1.0f / sqrtf(v / (float)N + 1e-12f);
     }
 
     __device__ float forward(const float (&obs)[OBS]) const {
@@ -76,9 +100,35 @@ struct ActorF32 {
                 for (int q = 0; q < 4; ++q) acc[q] = fmaf(obs[i], wv[q], acc[q]);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) h1[j + q] = fmaxf(acc[q], 0.0f);  // models_editted.py:47
+            for (int q = 0; q < 4; ++q) h1[j + q] = ln ? acc[q] : fmaxf(acc[q], 0.0f);  // models_editted.py:47
         }
         float out = lw[OFF_B3];
+        if (ln) {   // block-uniform: the LayerNorm network (models_editted.py:45-46, 50-51)
+            float mean, rstd;
+            norm_stats<H1>(h1, mean, rstd);
+#pragma unroll
+            for (int j = 0; j < H1; ++j) h1[j] = fmaxf(fmaf((h1[j] - mean) * rstd, lw[OFF_G1 + j], lw[OFF_BE1 + j]), 0.0f);
+            float z2[H2];
+#pragma unroll 2
+            for (int j = 0; j < H2; j += 4) {
+                f4 acc = *reinterpret_cast<const f4 *>(lw + OFF_B2 + j);
+#pragma unroll
+                for (int i = 0; i < H1; ++i) {
+                    const f4 wv = *reinterpret_cast<const f4 *>(lw + OFF_W2 + i * H2 + j);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(h1[i], wv[q], acc[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z2[j + q] = acc[q];
+            }
+            norm_stats<H2>(z2, mean, rstd);
+#pragma unroll
+            for (int j = 0; j < H2; ++j) {
+                const float n2 = fmaf((z2[j] - mean) * rstd, lw[OFF_G2 + j], lw[OFF_BE2 + j]);
+                out = fmaf(last_tanh ? tanh_fast(n2) : fmaxf(n2, 0.0f), lw[OFF_W3 + j], out);
+            }
+            return tanh_fast(out);
+        }
 #pragma unroll 2
         for (int j = 0; j < H2; j += 4) {
             f4 acc = *reinterpret_cast<const f4 *>(lw + OFF_B2 + j);

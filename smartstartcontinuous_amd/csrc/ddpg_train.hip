@@ -685,7 +685,8 @@ static int ddpg_train_any(const char *who, const ssc_ddpg_desc *d, const ssc_rep
                 "%s: bad hidden sizes", who);
     const char *force_i = getenv("SSC_DDPG_INTERPRETER"), *force_w = getenv("SSC_DDPG_WIDE");
     const bool want_interp = force_i && force_i[0] == '1', want_wide = force_w && force_w[0] == '1' && have_ws;
-    const bool narrow = d->batch_size == kB && d->actor_h1 <= 64 && d->actor_h2 <= 64 && d->critic_h1 <= 64 && d->critic_h2 <= 64;
+    // (LayerNorm networks run on the multi-workgroup kernels only)
+    const bool narrow = !d->layer_norm && d->batch_size == kB && d->actor_h1 <= 64 && d->actor_h2 <= 64 && d->critic_h1 <= 64 && d->critic_h2 <= 64;
     if (!have_ws && !narrow)
         return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: batch_size %d / hidden layers wider than 64 run the multi-workgroup "
                                            "kernels, which need a workspace: call ssc_ddpg_train_ws", d->batch_size);

@@ -29,7 +29,8 @@ namespace ssc {
 constexpr int kWR = 16;           // batch rows per workgroup
 constexpr int kWThreads = 512;    // 8 waves: two per SIMD, so one wave's L2 operand loads hide under the other's MFMAs
 constexpr int kWWaves = kWThreads / 64;
-constexpr int kMaxGemm = 24, kMaxLevel = 12, kMaxWg = 12;
+constexpr int kMaxGemm = 24, kMaxLevel = 12, kMaxWg = 12, kMaxLn = 16, kLnPerLevel = 4;
+constexpr int kLnParts = kWThreads / kWR;   // threads per batch row in the LayerNorm passes
 
 enum : int { EPI_NONE = 0, EPI_RELU, EPI_TANH, EPI_MASK_RELU, EPI_MASK_TANH };
 
@@ -49,6 +50,17 @@ struct WGrad {
     int32_t gW, gb;                   // offsets into the flat gradient vector (actor first, then critic)
 };
 
+// LayerNorm (models_editted.py:45-46, 50-51, 85-86, 91-92) over the M units of a [M][16 rows] block, applied after the
+// contractions of a level:
+//   forward   x <- act((x - mean) * rstd * gamma + beta) in place; x-hat and 1/sigma are kept for the backward pass of the
+//             trained networks (xhat_off / rstd_off >= 0);
+//   backward  x holds dL/d(LayerNorm output) (the activation's derivative already applied by the contraction's epilogue) and
+//             becomes dL/dz = rstd * (dxh - mean_u(dxh) - xhat * mean_u(dxh * xhat)), dxh = x * gamma; gamma / beta gradients
+//             (sums over the workgroup's 16 rows) go to the gradient slice when gG >= 0.
+struct WLn {
+    int32_t bwd, x_off, xhat_off, rstd_off, g_off, b_off, M, act, gG, gB;
+};
+
 // The per-level tables.  They reach the kernel as arguments, but a scalar load from the kernel-argument segment that
 // misses the (cold) scalar cache costs ~500 cycles and the job dispatch walks these tables level by level -- two to
 // three dependent misses per level, ten levels: more than the arithmetic of a 64-32 network.  Every workgroup
@@ -56,7 +68,9 @@ struct WGrad {
 // (lds_uniform: broadcast read + v_readfirstlane, so that dispatch and addressing still run on the scalar unit).
 struct WideTables {
     int32_t level_first[kMaxLevel + 1];
-    int32_t n_seg, n_big, pad_;
+    int32_t ln_first[kMaxLevel + 1];   // LayerNorm ops that follow the contractions of a level
+    int32_t n_seg, n_big, off_scr;     // off_scr: LDS scratch of the LayerNorm reductions, [kLnPerLevel][2][kLnParts][16]
+    WLn ln[kMaxLn];
     WGemm gemm[kMaxGemm];
     WGrad wg[kMaxWg];
     // Everything of the four parameter vectors except their h1 x h2 blocks (first layers, biases, output layers, the
@@ -65,7 +79,7 @@ struct WideTables {
     struct { const float *src; int32_t dst, n; } seg[8];
     struct { const float *src; int32_t n, pad; } big[4];
 };
-static_assert(sizeof(WideTables) % 4 == 0 && sizeof(WideTables) <= 512 * 4, "one dword per thread copies the tables");
+static_assert(sizeof(WideTables) % 4 == 0 && sizeof(WideTables) <= 2 * kWThreads * 4, "two dwords per thread copy the tables");
 
 struct WideArgs {
     ssc_replay_view rp;
@@ -218,6 +232,105 @@ __device__ __forceinline__ void wgrad_tile(const WGrad &w, const float *lds, flo
     }
 }
 
+// The LayerNorm ops behind one level (<= kLnPerLevel of them, all between the same barriers).  Thread t serves batch row
+// t & 15 and the units u = part, part + 32, ... (part = t >> 4); the per-row reductions go through LDS partials summed by
+// every thread in part order, so the result does not depend on which wave did what.
+__device__ __forceinline__ void ln_level(const WideTables *T, int first, int end, float *lds, float *__restrict__ gout, int tid) {
+    const int row = tid & (kWR - 1), part = tid >> 4;
+    float *scr = lds + T->off_scr;
+    auto post = [&](int slot, float a, float b) {   // this thread's partial sums (the barriers around it are the caller's)
+        scr[((slot * 2 + 0) * kLnParts + part) * kWR + row] = a;
+        scr[((slot * 2 + 1) * kLnParts + part) * kWR + row] = b;
+    };
+    auto total = [&](int slot, int which) {
+        float s = 0.0f;
+#pragma unroll 8
+        for (int q = 0; q < kLnParts; ++q) s += scr[((slot * 2 + which) * kLnParts + q) * kWR + row];
+        return s;
+    };
+    float mean[kLnPerLevel], rstd[kLnPerLevel];
+    // pass 1: forward -> sum of x; backward -> sums of dxh and dxh * xhat
+    for (int li = first; li < end; ++li) {
+        const WLn L = lds_uniform(&T->ln[li]);
+        float s0 = 0.0f, s1 = 0.0f;
+        for (int u = part; u < L.M; u += kLnParts) {
+            const float x = lds[L.x_off + u * kWR + row];
+            if (L.bwd) {
+                const float dxh = x * lds[L.g_off + u];
+                s0 += dxh;
+                s1 = fmaf(dxh, lds[L.xhat_off + u * kWR + row], s1);
+            } else {
+                s0 += x;
+            }
+        }
+        post(li - first, s0, s1);
+    }
+    __syncthreads();
+    for (int li = first; li < end; ++li) {
+        const int M = __builtin_amdgcn_readfirstlane(T->ln[li].M);
+        mean[li - first] = total(li - first, 0) / (float)M;
+        rstd[li - first] = total(li - first, 1) / (float)M;      // backward: mean_u(dxh * xhat)
+    }
+    __syncthreads();
+    // pass 2 (forward only): sum of (x - mean)^2
+    bool any_fwd = false;
+    for (int li = first; li < end; ++li) {
+        const WLn L = lds_uniform(&T->ln[li]);
+        if (L.bwd) continue;
+        any_fwd = true;
+        float v = 0.0f;
+        for (int u = part; u < L.M; u += kLnParts) {
+            const float dlt = lds[L.x_off + u * kWR + row] - mean[li - first];
+            v = fmaf(dlt, dlt, v);
+        }
+        post(li - first, v, 0.0f);
+    }
+    if (any_fwd) {   // block-uniform
+        __syncthreads();
+        for (int li = first; li < end; ++li) {
+            const WLn L = lds_uniform(&T->ln[li]);
+            if (!L.bwd) rstd[li - first] = 1.0f / sqrtf(total(li - first, 0) / (float)L.M + 1e-12f);   // tc.layers.layer_norm's epsilon
+        }
+    }
+    // pass 3: the element-wise result
+    for (int li = first; li < end; ++li) {
+        const WLn L = lds_uniform(&T->ln[li]);
+        if (L.bwd) {
+            const float r = lds[L.rstd_off + row], m0 = mean[li - first], m1 = rstd[li - first];
+            // gamma / beta gradients first (they read the incoming deltas): one thread per unit, the 16 rows in order
+            if (L.gG >= 0) {
+                for (int u = tid; u < L.M; u += kWThreads) {
+                    float sg = 0.0f, sb = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < kWR; ++q) {
+                        const float dn = lds[L.x_off + u * kWR + q];
+                        sg = fmaf(dn, lds[L.xhat_off + u * kWR + q], sg);
+                        sb += dn;
+                    }
+                    gout[L.gG + u] = sg;
+                    gout[L.gB + u] = sb;
+                }
+                __syncthreads();      // (block-uniform: L is)
+            }
+            for (int u = part; u < L.M; u += kLnParts) {
+                const float xh = lds[L.xhat_off + u * kWR + row];
+                const float dxh = lds[L.x_off + u * kWR + row] * lds[L.g_off + u];
+                lds[L.x_off + u * kWR + row] = r * (dxh - m0 - xh * m1);
+            }
+        } else {
+            const float m = mean[li - first], r = rstd[li - first];
+            if (L.rstd_off >= 0 && part == 0) lds[L.rstd_off + row] = r;
+            for (int u = part; u < L.M; u += kLnParts) {
+                const float xh = (lds[L.x_off + u * kWR + row] - m) * r;
+                if (L.xhat_off >= 0) lds[L.xhat_off + u * kWR + row] = xh;
+                const float n = fmaf(xh, lds[L.g_off + u], lds[L.b_off + u]);
+                lds[L.x_off + u * kWR + row] = L.act == EPI_TANH ? tanh_fast(n) : fmaxf(n, 0.0f);
+            }
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(kWThreads) void ddpg_wide_grad_kernel(WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef SSC_WIDE_DIAG
@@ -232,7 +345,8 @@ __global__ __launch_bounds__(kWThreads) void ddpg_wide_grad_kernel(WideArgs a) {
         typedef const __attribute__((address_space(4))) char *karg_bytes;
         typedef const __attribute__((address_space(4))) uint32_t *karg_words;
         const karg_words src = (karg_words)((karg_bytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WideArgs, tab));
-        if (tid < (int)(sizeof(WideTables) / 4)) reinterpret_cast<uint32_t *>(lds + a.off_tab)[tid] = src[tid];
+#pragma unroll
+        for (int e = tid; e < (int)(sizeof(WideTables) / 4); e += kWThreads) reinterpret_cast<uint32_t *>(lds + a.off_tab)[e] = src[e];
     }
 #endif
     __syncthreads();
@@ -367,6 +481,10 @@ __global__ __launch_bounds__(kWThreads) void ddpg_wide_grad_kernel(WideArgs a) {
             }
             __syncthreads();
         }
+        {
+            const int l_first = __builtin_amdgcn_readfirstlane(T->ln_first[lv]), l_end = __builtin_amdgcn_readfirstlane(T->ln_first[lv + 1]);
+            if (l_first < l_end) ln_level(T, l_first, l_end, lds, gout, tid);
+        }
 #ifdef SSC_WIDE_DIAG
         stamp[n_stamp++] = __builtin_amdgcn_s_memtime();
 #endif
@@ -463,18 +581,24 @@ __global__ void ddpg_wide_finish_kernel(int32_t *adam_t, int32_t n_iters) {
 
 struct WNet {
     int in, h1, h2, out, extra;   // extra: rows concatenated to the first hidden layer (critic: act_dim)
+    int ln;                       // 1: [W1|b1|beta1|gamma1|W2|b2|beta2|gamma2|W3|b3] (ssc_ddpg_desc::layer_norm)
     int oW1() const { return 0; }
     int ob1() const { return in * h1; }
-    int oW2() const { return ob1() + h1; }
+    int obe1() const { return ob1() + h1; }           // LayerNorm beta, then gamma (ln only)
+    int og1() const { return obe1() + h1; }
+    int oW2() const { return ob1() + h1 + (ln ? 2 * h1 : 0); }
     int ob2() const { return oW2() + (h1 + extra) * h2; }
-    int oW3() const { return ob2() + h2; }
+    int obe2() const { return ob2() + h2; }
+    int og2() const { return obe2() + h2; }
+    int oW3() const { return ob2() + h2 + (ln ? 2 * h2 : 0); }
     int ob3() const { return oW3() + h2 * out; }
     int total() const { return ob3() + out; }
 };
 
 static int wide_blocks(const ssc_ddpg_desc *d) { return (d->batch_size + kWR - 1) / kWR; }
 static int wide_params(const ssc_ddpg_desc *d) {
-    const WNet A{d->obs_dim, d->actor_h1, d->actor_h2, d->act_dim, 0}, C{d->obs_dim, d->critic_h1, d->critic_h2, 1, d->act_dim};
+    const int ln = d->layer_norm ? 1 : 0;
+    const WNet A{d->obs_dim, d->actor_h1, d->actor_h2, d->act_dim, 0, ln}, C{d->obs_dim, d->critic_h1, d->critic_h2, 1, d->act_dim, ln};
     return A.total() + C.total();
 }
 
@@ -490,9 +614,13 @@ int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int
     const size_t need = ddpg_wide_workspace_bytes(d);
     SSC_REQUIRE(d_workspace != nullptr && workspace_bytes >= need,
                 "ssc_ddpg_train_ws: workspace %zu < %zu bytes (ssc_ddpg_train_workspace_bytes)", workspace_bytes, need);
-    const WNet A{d->obs_dim, d->actor_h1, d->actor_h2, d->act_dim, 0}, C{d->obs_dim, d->critic_h1, d->critic_h2, 1, d->act_dim};
+    const int ln = d->layer_norm ? 1 : 0;
+    const WNet A{d->obs_dim, d->actor_h1, d->actor_h2, d->act_dim, 0, ln}, C{d->obs_dim, d->critic_h1, d->critic_h2, 1, d->act_dim, ln};
     const int od = d->obs_dim, ad = d->act_dim;
     const int act2 = d->last_layer_tanh ? EPI_TANH : EPI_RELU, mask2 = d->last_layer_tanh ? EPI_MASK_TANH : EPI_MASK_RELU;
+    // with LayerNorm the contractions of the hidden layers leave the pre-normalisation sums and the LayerNorm op applies
+    // the activation (ln_level)
+    const int epi1 = ln ? EPI_NONE : EPI_RELU, epi2 = ln ? EPI_NONE : act2;
     WideArgs g{};
     g.rp = *rp; g.batch = d->batch_size; g.obs_dim = od; g.act_dim = ad; g.gamma = d->gamma; g.obs_clip = d->obs_clip;
     // ---- LDS carve: rows of 16 floats ([unit][row]) ------------------------------------------------------------------
@@ -506,6 +634,14 @@ int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int
     const int Z2H = take(C.h2);                            // W2[:h1]^T relu(layer 1) + b2, shared by Q(s, a) and Q(s, pi(s)); later dZB2
     const int C2 = take(C.h2), CB2 = take(C.h2);
     const int U1 = take(A.h1), U2 = take(A.h2), PI = take(ad), DPI = take(ad);
+    // LayerNorm: x-hat of every normalised layer a gradient flows through, one 1/sigma row each, and the reduction scratch
+    int XC1 = -1, XC2 = -1, XCB2 = -1, XU1 = -1, XU2 = -1, RS = -1;
+    if (ln) {
+        XC1 = take(C.h1); XC2 = take(C.h2); XCB2 = take(C.h2); XU1 = take(A.h1); XU2 = take(A.h2);
+        RS = take(5);
+        g.tab.off_scr = p;
+        p += kLnPerLevel * 2 * kLnParts * kWR;
+    }
     const int DU1 = TA1, DU2 = TA2, DZ1 = TC1, DZ2 = TZ2, DZB2 = Z2H;
     const int TPI = TC1 + C.h1 * kWR, ACT = C1 + C.h1 * kWR;
     g.off_S = S; g.off_S2 = S2; g.off_ACT = ACT; g.off_TACT = TPI; g.off_RT = RT;
@@ -536,8 +672,23 @@ int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int
     const size_t lds = (size_t)p * sizeof(float);
     if (lds > 160 * 1024)
         return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: these layer sizes need %zu B of LDS per workgroup (160 KB available)", lds);
-    int ng = 0, nl = 0;
-    auto level = [&]() { g.tab.level_first[nl++] = ng; };
+    int ng = 0, nl = 0, nln = 0;
+    auto level = [&]() { g.tab.ln_first[nl] = nln; g.tab.level_first[nl++] = ng; };
+    // LayerNorm ops behind the current level's contractions; net n's gamma / beta of hidden layer `layer`
+    auto ln_fwd = [&](int n, int layer, int x_off, int act, int xhat_off, int rstd_off) {
+        if (!ln) return;
+        const WNet &N = *nets[n];
+        WLn &L = g.tab.ln[nln++];
+        L = WLn{0, x_off, xhat_off, rstd_off, img(n, layer == 1 ? N.og1() : N.og2()), img(n, layer == 1 ? N.obe1() : N.obe2()),
+                layer == 1 ? N.h1 : N.h2, act, -1, -1};
+    };
+    auto ln_bwd = [&](int n, int layer, int x_off, int xhat_off, int rstd_off, int gbase) {   // gbase < 0: no parameter gradients
+        if (!ln) return;
+        const WNet &N = *nets[n];
+        WLn &L = g.tab.ln[nln++];
+        L = WLn{1, x_off, xhat_off, rstd_off, img(n, layer == 1 ? N.og1() : N.og2()), -1, layer == 1 ? N.h1 : N.h2, EPI_NONE,
+                gbase < 0 ? -1 : gbase + (layer == 1 ? N.og1() : N.og2()), gbase < 0 ? -1 : gbase + (layer == 1 ? N.obe1() : N.obe2())};
+    };
     // net n, flat offset wflat of A(0, 0); big = true: the h1 x h2 block, streamed from L2
     auto gemm = [&](int n, int wflat, bool big, int sm, int sk, int M, int K, int bias_flat, int b_off, int out_off, int epi,
                     int add_off = -1, int aux_off = -1) {
@@ -549,46 +700,64 @@ int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int
         x.add_off = add_off; x.aux_off = aux_off;
     };
     const int RQ = RT + RT_Q * kWR, RQT = RT + RT_QT * kWR, RQPI = RT + RT_QPI * kWR, RDQ = RT + RT_DQ * kWR, RDQB = RT + RT_DQB * kWR;
+    const int nA_ = A.total();
     // L0: the first layer of all four networks
     level();
-    gemm(TA, A.oW1(), false, 1, A.h1, A.h1, od, A.ob1(), S2, TA1, EPI_RELU);
-    gemm(TC, C.oW1(), false, 1, C.h1, C.h1, od, C.ob1(), S2, TC1, EPI_RELU);
-    gemm(CR, C.oW1(), false, 1, C.h1, C.h1, od, C.ob1(), S, C1, EPI_RELU);
-    gemm(AC, A.oW1(), false, 1, A.h1, A.h1, od, A.ob1(), S, U1, EPI_RELU);
+    gemm(TA, A.oW1(), false, 1, A.h1, A.h1, od, A.ob1(), S2, TA1, epi1);
+    gemm(TC, C.oW1(), false, 1, C.h1, C.h1, od, C.ob1(), S2, TC1, epi1);
+    gemm(CR, C.oW1(), false, 1, C.h1, C.h1, od, C.ob1(), S, C1, epi1);
+    gemm(AC, A.oW1(), false, 1, A.h1, A.h1, od, A.ob1(), S, U1, epi1);
+    ln_fwd(TA, 1, TA1, EPI_RELU, -1, -1);
+    ln_fwd(TC, 1, TC1, EPI_RELU, -1, -1);
+    ln_fwd(CR, 1, C1, EPI_RELU, XC1, RS + 0 * kWR);
+    ln_fwd(AC, 1, U1, EPI_RELU, XU1, RS + 3 * kWR);
     // L1: the h1 x h2 contractions; the critics' second layer without its action rows (they need pi' / pi)
     level();
-    gemm(TA, A.oW2(), true, 1, A.h2, A.h2, A.h1, A.ob2(), TA1, TA2, act2);
-    gemm(AC, A.oW2(), true, 1, A.h2, A.h2, A.h1, A.ob2(), U1, U2, act2);
+    gemm(TA, A.oW2(), true, 1, A.h2, A.h2, A.h1, A.ob2(), TA1, TA2, epi2);
+    gemm(AC, A.oW2(), true, 1, A.h2, A.h2, A.h1, A.ob2(), U1, U2, epi2);
     gemm(CR, C.oW2(), true, 1, C.h2, C.h2, C.h1, C.ob2(), C1, Z2H, EPI_NONE);
     gemm(TC, C.oW2(), true, 1, C.h2, C.h2, C.h1, C.ob2(), TC1, TZ2, EPI_NONE);
+    ln_fwd(TA, 2, TA2, act2, -1, -1);
+    ln_fwd(AC, 2, U2, act2, XU2, RS + 4 * kWR);
     // L2: pi'(s2), pi(s), Q(s, a) layer 2 = act(head + W2[h1:]^T a)
     level();
     gemm(TA, A.oW3(), false, 1, ad, ad, A.h2, A.ob3(), TA2, TPI, EPI_TANH);
     gemm(AC, A.oW3(), false, 1, ad, ad, A.h2, A.ob3(), U2, PI, EPI_TANH);
-    gemm(CR, C.oW2() + C.h1 * C.h2, false, 1, C.h2, C.h2, ad, -1, ACT, C2, act2, Z2H);
+    gemm(CR, C.oW2() + C.h1 * C.h2, false, 1, C.h2, C.h2, ad, -1, ACT, C2, epi2, Z2H);
+    ln_fwd(CR, 2, C2, act2, XC2, RS + 1 * kWR);
     // L3: Q'(s2, pi') layer 2, Q(s, pi(s)) layer 2, Q(s, a)
     level();
-    gemm(TC, C.oW2() + C.h1 * C.h2, false, 1, C.h2, C.h2, ad, -1, TPI, TZ2, act2, TZ2);
-    gemm(CR, C.oW2() + C.h1 * C.h2, false, 1, C.h2, C.h2, ad, -1, PI, CB2, act2, Z2H);
+    gemm(TC, C.oW2() + C.h1 * C.h2, false, 1, C.h2, C.h2, ad, -1, TPI, TZ2, epi2, TZ2);
+    gemm(CR, C.oW2() + C.h1 * C.h2, false, 1, C.h2, C.h2, ad, -1, PI, CB2, epi2, Z2H);
     gemm(CR, C.oW3(), false, 1, 1, 1, C.h2, C.ob3(), C2, RQ, EPI_NONE);
+    ln_fwd(TC, 2, TZ2, act2, -1, -1);
+    ln_fwd(CR, 2, CB2, act2, XCB2, RS + 2 * kWR);
     // L4: Q'(s2, pi'(s2)) and Q(s, pi(s)); then target_Q, the losses and the output deltas
     level();
     gemm(TC, C.oW3(), false, 1, 1, 1, C.h2, C.ob3(), TZ2, RQT, EPI_NONE);
     gemm(CR, C.oW3(), false, 1, 1, 1, C.h2, C.ob3(), CB2, RQPI, EPI_NONE);
     g.td_level = nl - 1;
     // L5: dz2 = (W3 dq) * act'(z2) for the critic loss, the same through Q(s, pi(s)) for the actor loss
+    // (with LayerNorm the contraction leaves dL/d(LayerNorm output) and the op behind it turns it into dL/dz; the actor-loss
+    // path goes through the critic's normalisation too but leaves its gamma / beta alone)
     level();
     gemm(CR, C.oW3(), false, 1, 1, C.h2, 1, -1, RDQ, DZ2, mask2, -1, C2);
     gemm(CR, C.oW3(), false, 1, 1, C.h2, 1, -1, RDQB, DZB2, mask2, -1, CB2);
+    ln_bwd(CR, 2, DZ2, XC2, RS + 1 * kWR, nA_);
+    ln_bwd(CR, 2, DZB2, XCB2, RS + 2 * kWR, -1);
     // L6: critic layer-1 deltas; d(-mean Q)/d(action) through the actor's output tanh
     level();
     gemm(CR, C.oW2(), true, C.h2, 1, C.h1, C.h2, -1, DZ2, DZ1, EPI_MASK_RELU, -1, C1);
     gemm(CR, C.oW2() + C.h1 * C.h2, false, C.h2, 1, ad, C.h2, -1, DZB2, DPI, EPI_MASK_TANH, -1, PI);
+    ln_bwd(CR, 1, DZ1, XC1, RS + 0 * kWR, nA_);
     // L7, L8: back through the actor
     level();
     gemm(AC, A.oW3(), false, ad, 1, A.h2, ad, -1, DPI, DU2, mask2, -1, U2);
+    ln_bwd(AC, 2, DU2, XU2, RS + 4 * kWR, 0);
     level();
     gemm(AC, A.oW2(), true, A.h2, 1, A.h1, A.h2, -1, DU2, DU1, EPI_MASK_RELU, -1, U1);
+    ln_bwd(AC, 1, DU1, XU1, RS + 3 * kWR, 0);
+    g.tab.ln_first[nl] = nln;
     g.tab.level_first[nl] = ng;
     g.n_gemm = ng; g.n_level = nl;
     // gradients, flat [actor | critic], TF trainable_vars order inside a net

@@ -550,8 +550,10 @@ static int dispatch_policy(const typename EnvT::Const &ec, const ssc_policy_desc
     if (a.precision == SSC_PREC_F32) {
         if (a.h1 == 64 && a.h2 == 32)
             return launch_rollout<EnvT, ActorPolicy<ActorF32<OBS, 64, 32>, OBS>>(ec, pa, ra, stream);
+        if (a.h1 == 64 && a.h2 == 64)      // Actor_Editted's own default sizes (models_editted.py:23)
+            return launch_rollout<EnvT, ActorPolicy<ActorF32<OBS, 64, 64>, OBS>>(ec, pa, ra, stream);
         return set_error(SSC_EUNSUPPORTED,
-                         "ssc_rollout: fused fp32 actor supports h1-h2 = 64-32 (got %d-%d); use the bf16 MFMA "
+                         "ssc_rollout: fused fp32 actor supports h1-h2 = 64-32 and 64-64 (got %d-%d); use the bf16 MFMA "
                          "path or step the env with ssc_actor_forward + ssc_*_step",
                          a.h1, a.h2);
     }
@@ -841,7 +843,13 @@ extern "C" int ssc_rollout(const ssc_env_params *p, const ssc_policy_desc *polic
         const ssc_actor_desc &a = policy->actor;
         SSC_REQUIRE(a.W1 && a.b1 && a.W2 && a.b2 && a.W3 && a.b3, "ssc_rollout: NULL actor weight pointer");
         SSC_REQUIRE(a.h1 > 0 && a.h2 > 0, "ssc_rollout: bad actor sizes");
-        pa.actor = ActorWeights{a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.obs_dim, a.h1, a.h2, a.last_layer_tanh, a.obs_clip};
+        pa.actor = ActorWeights{a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.obs_dim, a.h1, a.h2, a.last_layer_tanh, a.obs_clip,
+                                a.ln1_g, a.ln1_b, a.ln2_g, a.ln2_b};
+        const bool ln = a.ln1_g != nullptr;
+        SSC_REQUIRE(ln == (a.ln1_b != nullptr) && ln == (a.ln2_g != nullptr) && ln == (a.ln2_b != nullptr),
+                    "ssc_rollout: the four LayerNorm pointers come together");
+        if (ln && a.precision != SSC_PREC_F32)
+            return set_error(SSC_EUNSUPPORTED, "ssc_rollout: LayerNorm actors run on the fp32 policy (precision SSC_PREC_F32)");
         pa.ou_mu = policy->ou.mu;
         pa.ou_sigma = policy->ou.sigma;
         pa.ou_theta = policy->ou.theta;

@@ -322,6 +322,8 @@ class VecEnv:
         a = pd.actor
         a.obs_dim, a.h1, a.h2, a.act_dim = obs_dim, h1, h2, 1
         a.W1, a.b1, a.W2, a.b2, a.W3, a.b3 = (w[k].data_ptr() for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
+        if "ln1_g" in w:                        # LayerNorm actor (models_editted.py:45-46, 50-51)
+            a.ln1_g, a.ln1_b, a.ln2_g, a.ln2_b = (w[k].data_ptr() for k in ("ln1_g", "ln1_b", "ln2_g", "ln2_b"))
         a.last_layer_tanh = int(policy.last_layer_tanh)
         a.obs_clip = float(policy.obs_clip)
         a.precision = {"f32": _ffi.SSC_PREC_F32, "bf16_mfma": _ffi.SSC_PREC_BF16_MFMA}[policy.precision]
