@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--refresh-every", type=int, default=1, help="chunks between smart-start selections (vec mode)")
     ap.add_argument("--nav-precision", choices=("f32", "bf16_mfma"), default="f32", help="forward-simulation path of the navigator (vec mode; f32 = the fused VALU kernel for one small hidden layer)")
     ap.add_argument("--kde-max-states", type=int, default=500000, help="bound the KDE's data set by a strided subsample of the ring (vec mode; default: the reference's replay capacity; 0 = every state)")
+    ap.add_argument("--sequential-selection", action="store_true", help="vec mode: select, then roll (default: the selection of a chunk overlaps its rollout and its plans go on offer one chunk later)")
     ap.add_argument("--replay-capacity", type=int, default=None, help="records in the device ring (default: two full episodes per env)")
     args = ap.parse_args()
     np.random.seed(args.seed)
@@ -90,7 +91,8 @@ def vec(args, dyn_model):
                               seed=args.seed, log_modes=True, kde_max_states=args.kde_max_states or None)
     nav_steps = []
     cap = args.replay_capacity or 2 * args.envs * args.max_steps     # a smart-start path needs its episode's start in the ring
-    kw = dict(chunk_steps=args.chunk_steps, train_iters=args.train_iters, replay_capacity=cap, refresh_every=args.refresh_every)
+    kw = dict(chunk_steps=args.chunk_steps, train_iters=args.train_iters, replay_capacity=cap, refresh_every=args.refresh_every,
+              overlap_selection=not args.sequential_selection)
     ssc.rl_train_vec_smartstart(env, smart, 2, **kw)   # warm-up: allocations, graph capture
     torch.cuda.synchronize()
     t0 = time.perf_counter()

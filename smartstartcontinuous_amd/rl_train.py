@@ -423,7 +423,7 @@ def rl_train_vec_ddpg(env, agent, num_chunks, chunk_steps=256, replay_capacity=1
 
 def rl_train_vec_smartstart(env, smart, num_chunks, chunk_steps=64, replay_capacity=1 << 20, train_iters=None,
                             replay_last_steps=None, seed=0, ring_capacity=1 << 20, refresh_every=1, graph=True,
-                            on_chunk=None, aggregate_every=0, aggregate_kwargs=None):
+                            on_chunk=None, aggregate_every=0, aggregate_kwargs=None, overlap_selection=False):
     """The vectorised SmartStart loop: rlTrain (rlTrain.py:63-114) with ``SmartStartContinuous(DDPG_Baselines_agent)``
     (smartexplorationcontinuous.py:307-376) for all envs of ``env`` at once, everything in HBM.  Per chunk:
     smart-start selection on the device replay ring -> plans on offer (``smart.refresh_plans``, every ``refresh_every``
@@ -433,6 +433,13 @@ def rl_train_vec_smartstart(env, smart, num_chunks, chunk_steps=64, replay_capac
     SmartStartContinuous.end_episode :372-376).  ``aggregate_every`` > 0 retrains the navigator's dynamics model on the
     ring every that many chunks (``smart.train_dynamics_model``: the reference does it every
     ``num_episodes_for_aggregation`` planned episodes, NND_MB_agent.py:420-423).  ``smart``: :class:`smartstart.VecSmartStart`.
+
+    ``overlap_selection=True``: the selection of chunk c runs WHILE chunk c rolls -- its kernels (candidates, Q(s, pi(s)),
+    KDE, UCB) on a side stream that fills the gaps between the rollout's launches, its host part (episodic paths, path
+    shortcutting, waypoints) while the GPU works through the queued steps -- and the plans it produces go on offer for chunk
+    c + 1 (published on the rollout's stream behind chunk c: deterministic).  The selection then sees the ring as of chunk
+    c - 1 and its plans are used one chunk later than in the sequential loop; the chunk costs max(rollout, selection)
+    instead of their sum.
     Returns (Summary, losses per chunk, replay)."""
     import torch
     from .replay_buffer import DeviceReplayBuffer
@@ -444,14 +451,32 @@ def rl_train_vec_smartstart(env, smart, num_chunks, chunk_steps=64, replay_capac
     replay = DeviceReplayBuffer(replay_capacity, env.obs_dim, 1, env.device, seed=seed, track_episodes=True,
                                 n_envs=env.n, max_path_len=(env.spec.max_episode_steps or 1000) + 1)
     losses, generations = [], 0.0
+    if overlap_selection:
+        main = torch.cuda.current_stream(env.device)
+        with torch.cuda.device(env.device):
+            side = torch.cuda.Stream(env.device)
+        learned = torch.cuda.Event()
     for c in range(num_chunks):
         if aggregate_every and c > 0 and c % aggregate_every == 0:
             smart.train_dynamics_model(replay, **(aggregate_kwargs or {}))
-        if c % refresh_every == 0:
-            smart.refresh_plans(replay)
-        out = smart.rollout(chunk_steps, chunk, ring=ring, graph=graph)
+        plans = None
+        if overlap_selection:
+            out = smart.rollout(chunk_steps, chunk, ring=ring, graph=graph)         # chunk c is queued; the host is free
+            if c % refresh_every == 0 and c > 0:
+                side.wait_event(learned)                                            # the ring and the networks as of chunk c - 1
+                with torch.cuda.stream(side):
+                    plans = smart.select_plans(replay)                              # kernels on the side stream, host geometry meanwhile
+                main.wait_stream(side)                                              # (already complete: the host read its results)
+            if plans:
+                smart.publish_plans(plans)                                          # main stream, behind chunk c: on offer from chunk c + 1
+        else:
+            if c % refresh_every == 0:
+                smart.refresh_plans(replay)
+            out = smart.rollout(chunk_steps, chunk, ring=ring, graph=graph)
         replay.append_chunk(out, reward_scale=agent.reward_scale, last_steps=replay_last_steps)
         l = agent.train_from(replay, train_iters)
+        if overlap_selection:
+            learned.record(main)
         if l is not None:
             losses.append(l)
         if on_chunk is not None:

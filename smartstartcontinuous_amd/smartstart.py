@@ -286,9 +286,11 @@ class VecSmartStart:
         wp = np.asarray(get_start_waypoints_final_states_steps(path, self.steps_per_waypoint))
         return wp, distances_left(wp, dist), radii
 
-    def refresh_plans(self, replay):
-        """One smart-start selection on the device ring (get_smart_start_path, :223-305) -> ``n_plans`` plans on offer.
-        Returns the chosen buffer indices (device tensor) or None when the ring holds no complete episode start yet."""
+    def select_plans(self, replay):
+        """One smart-start selection on the device ring (get_smart_start_path, :223-305) -> up to ``n_plans`` plans
+        (waypoints, distances_left, radii) as host arrays, or None when the ring holds no complete episode start yet.
+        The device part runs on the CURRENT stream (rl_train_vec_smartstart(overlap_selection=True) makes that a side
+        stream) and the host reads its results; nothing here writes what a rollout in flight reads."""
         if len(replay) == 0:
             return None
         idx = replay.get_possible_smart_start_indices(self.n_ss)                                  # :243-246
@@ -308,17 +310,31 @@ class VecSmartStart:
             chosen = idx[best.long()]
         else:
             chosen = idx[torch.topk(ucb, min(self.n_plans, ucb.numel())).indices]
+        self.last_chosen = chosen
         plans = []
         for c in chosen.reshape(-1):
             path = replay.get_episodic_path_to_buffer_index(c.reshape(1))
             if path is None or path.shape[0] < 2:
                 continue
             plans.append(self.plan_from_path(path.double().cpu().numpy()))
+        return plans
+
+    def publish_plans(self, plans):
+        """Put ``plans`` on offer (writes the pool on the current stream)."""
         if plans:
             self.pool.publish(plans, now=self.env.t, min_age=(self.env.spec.max_episode_steps or 1000))
             self.last_radii = plans[0][2]
             self.selections += 1
-        return chosen
+
+    def refresh_plans(self, replay):
+        """``select_plans`` + ``publish_plans``.  Returns the chosen buffer indices (device tensor) or None when the ring
+        holds no complete episode start yet."""
+        self.last_chosen = None
+        plans = self.select_plans(replay)
+        if plans is None:
+            return None
+        self.publish_plans(plans)
+        return self.last_chosen
 
     # ------------------------------------------------------------------------------ steps --
     def _step_struct(self, chunk_k):

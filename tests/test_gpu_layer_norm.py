@@ -92,7 +92,7 @@ def test_layer_norm_actor_in_the_fused_rollout(ssc, env_name, h2):
     assert float(chunk.done.sum()) >= 300                       # episodes ended and restarted inside the chunk
 
 
-@pytest.mark.parametrize("obs_dim,h1,h2,B,llts", [(2, 64, 32, 64, (True, False)), (2, 64, 64, 256, (True,)), (3, 200, 100, 64, (True,)),
+@pytest.mark.parametrize("obs_dim,h1,h2,B,llts", [(2, 64, 32, 64, (True, False)), (2, 64, 64, 256, (True,)), (3, 128, 64, 64, (True,)),
                                                    (3, 128, 64, 1024, (True,)), (8, 37, 19, 77, (False,))])
 def test_layer_norm_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2, B, llts, monkeypatch):
     """ssc_ddpg_train_ws with ssc_ddpg_desc.layer_norm: parameters in TF order [W1|b1|beta1|gamma1|W2|b2|beta2|gamma2|W3|b3],
@@ -101,6 +101,18 @@ def test_layer_norm_ddpg_train_kernel_vs_oracle(ssc, obs_dim, h1, h2, B, llts, m
     monkeypatch.delenv("SSC_DDPG_WIDE", raising=False)
     monkeypatch.delenv("SSC_DDPG_INTERPRETER", raising=False)
     _ddpg_kernel_vs_oracle(ssc, obs_dim, h1, h2, B=B, llts=llts, cap=3000, layer_norm=True)
+
+
+def test_layer_norm_learner_says_when_a_tile_does_not_fit(ssc):
+    """The x-hat rows the LayerNorm backward pass keeps make a 16-row tile of the 200-100 networks 181 KB: refused with the
+    byte count (the shapes with LayerNorm that fit go up to 128-64; the reference's LayerNorm default is 64-64)."""
+    from smartstartcontinuous_amd import _ffi
+    agent, _, _ = _agent(ssc, 2, 200, 100, True)
+    z = torch.zeros(64, 2, device="cuda")
+    idx = torch.zeros((1, 64), dtype=torch.int32, device="cuda")
+    with pytest.raises(_ffi.SscError) as ei:
+        agent.train_on(z, z[:, :1].contiguous(), z[:, 0].contiguous(), torch.zeros(64, dtype=torch.uint8, device="cuda"), z, idx, 1)
+    assert ei.value.code == _ffi.SSC_EUNSUPPORTED and "LDS" in str(ei.value)
 
 
 def test_layer_norm_agent_runs_rltrain_and_the_vector_loop(ssc):

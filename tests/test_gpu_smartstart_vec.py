@@ -278,3 +278,30 @@ def test_plan_pool_too_small_for_the_refresh_cadence_is_reported_and_harmless(ss
             for col in (chunk.obs, chunk.act, chunk.rew, chunk.obs2):
                 assert bool(torch.isfinite(col).all())
     assert int(mode.sum()) > 0 or int(smart.mode_log.sum()) > 0       # envs did navigate
+
+
+def test_rl_train_vec_smartstart_overlapped_selection(ssc):
+    """``overlap_selection=True``: the selection of a chunk runs on a side stream while the chunk rolls and its plans go on
+    offer one chunk later.  Deterministic (two runs agree: every cross-stream hand-over -- ring and networks into the
+    selection, plans back onto the rollout's stream -- is ordered by events), plans still come from recorded episodes, envs
+    navigate, and the first plans appear one refresh later than in the sequential loop."""
+    def run(overlap):
+        n, K, chunks = 512, 16, 12
+        env, agent, w, _, smart = _setup(ssc, n, 24, 0.9, 2, N=32, H=3, chunk=K, n_plans=2)
+        agent.training_enabled = True
+        agent.batch_size, agent.num_train_iterations = 64, 3
+        nav_steps, published = [], []
+
+        def on_chunk(c, out, sm):
+            nav_steps.append(int(sm.mode_log.sum()))
+            published.append(sm.pool.published)
+        summary, losses, replay = ssc.rl_train_vec_smartstart(env, smart, chunks, chunk_steps=K, replay_capacity=1 << 16, train_iters=3,
+                                                              on_chunk=on_chunk, overlap_selection=overlap)
+        torch.cuda.synchronize()
+        return sorted(summary.episodes), nav_steps, published, replay.s.clone(), agent.actor_flat.clone(), smart.selections
+    a, b, seq = run(True), run(True), run(False)
+    assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert sum(a[1]) > 200 and a[5] >= 5                              # envs navigate on the overlapped loop's plans
+    first = lambda pub: next(i for i, v in enumerate(pub) if v > 0)
+    # sequential: plans published before chunk 2 rolls (on_chunk index 2); overlapped: selected during chunk 2, on offer from chunk 3
+    assert first(a[2]) == first(seq[2]) and a[1][first(a[2])] == 0 and sum(seq[1][:first(seq[2]) + 1]) >= 0
