@@ -469,18 +469,6 @@ struct ActorMfmaLds {
 //  * Everything from the hidden contraction on is ActorMfma<2,2,1,2>'s code; LAST_TANH is a template
 //    parameter so that the forward pass is ONE basic block (the scheduler can then run the caller's
 //    independent work -- noise generation -- under the MFMAs).
-#ifndef SSC_ACT_ABL
-#define SSC_ACT_ABL 0      // diagnostic ablations (tools/exp_actor_abl.py); results are WRONG when set
-#endif
-#ifndef SSC_ACT_PACKED
-#define SSC_ACT_PACKED 1
-#endif
-#ifndef SSC_ACT_SHARED_RCP
-#define SSC_ACT_SHARED_RCP 0
-#endif
-#ifndef SSC_ACT_STAGED
-#define SSC_ACT_STAGED 0
-#endif
 template <bool LAST_TANH>
 struct ActorMfma2 {
     static constexpr int kLanesPerEnv = 1;
@@ -575,80 +563,15 @@ struct ActorMfma2 {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     i32x4 packed;  // relu (models_editted.py:47) + bf16 convert
-#if SSC_ACT_ABL == 2
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) packed[j] = __builtin_bit_cast(int, d[et][ut][8 * s + 2 * j]);
-#elif SSC_ACT_STAGED
-                    // stage by stage over the 8 values of a k-step: every convert is issued before the first max,
-                    // so that no instruction waits on the one right in front of it (one wave per SIMD: a dependent
-                    // VALU pair costs ~2.6 cycles more than an independent one)
-                    uint32_t cv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) cv[j] = pack_bf16(d[et][ut][8 * s + 2 * j], d[et][ut][8 * s + 2 * j + 1]);
-                    asm volatile("" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ssc_s16x2 q = __builtin_bit_cast(ssc_s16x2, cv[j]);
-                        q = __builtin_elementwise_max(q, (ssc_s16x2)(0));
-                        packed[j] = __builtin_bit_cast(int, q);
-                    }
-#else
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         packed[j] = relu_pack_bf16(d[et][ut][8 * s + 2 * j], d[et][ut][8 * s + 2 * j + 1]);
-#endif
                     acc2[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ut][s], __builtin_bit_cast(bf16x8, packed),
                                                                        acc2[et], 0, 0, 0);
                 }
             }
         }
         float part[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};  // two partial sums per env tile: shorter dependent chains
-#if SSC_ACT_STAGED && SSC_ACT_ABL != 1
-        if (LAST_TANH) {
-            // 8 values at a time, stage by stage (exp x8, +1 x8, rcp x8, fma x8): each transcendental result is
-            // consumed at least 7 instructions after it was issued
-#pragma unroll
-            for (int et = 0; et < 2; ++et)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float e[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) e[q] = __builtin_amdgcn_exp2f(acc2[et][8 * b + q]);
-                    asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]));
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) e[q] += 1.0f;
-                    asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]));
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) e[q] = __builtin_amdgcn_rcpf(e[q]);
-                    asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]));
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) part[et][q & 1] = fmaf(e[q], w3[8 * b + q], part[et][q & 1]);
-                }
-        } else
-#endif
-#if SSC_ACT_SHARED_RCP && SSC_ACT_ABL != 1
-        if (LAST_TANH) {
-            // A/B variant (round-2 review, item 5): ONE reciprocal per PAIR of tanh -- r = 1 / ((1 + ea)(1 + eb)),
-            // 1 / (1 + ea) = r (1 + eb), 1 / (1 + eb) = r (1 + ea) -- i.e. 3 transcendentals per pair instead of 4, paid
-            // for with one v_mul and one v_pk_mul.  No overflow guard ((1 + ea)(1 + eb) overflows for pre-activations
-            // whose sum exceeds ~44): this build only measures the upper bound of the gain; see DESIGN.md section 4.3.
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            f32x2 p2[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
-#pragma unroll
-            for (int reg = 0; reg < 16; reg += 2)
-#pragma unroll
-                for (int et = 0; et < 2; ++et) {
-                    f32x2 e = {__builtin_amdgcn_exp2f(acc2[et][reg]), __builtin_amdgcn_exp2f(acc2[et][reg + 1])};
-                    e += f32x2{1.0f, 1.0f};
-                    const float r = __builtin_amdgcn_rcpf(e.x * e.y);
-                    const f32x2 inv = f32x2{e.y, e.x} * f32x2{r, r};
-                    p2[et] = __builtin_elementwise_fma(inv, f32x2{w3[reg], w3[reg + 1]}, p2[et]);
-                }
-            part[0][0] = p2[0].x; part[0][1] = p2[0].y;
-            part[1][0] = p2[1].x; part[1][1] = p2[1].y;
-        } else
-#endif
-#if SSC_ACT_PACKED && SSC_ACT_ABL != 1
         if (LAST_TANH) {
             // the "+ 1" and the w3-weighted sum as packed fp32 ops (v_pk_add_f32 / v_pk_fma_f32: two values per issue
             // slot); the partial sums keep their order (even registers in .x, odd ones in .y): bit-identical results
@@ -666,17 +589,12 @@ struct ActorMfma2 {
             part[0][0] = p2[0].x; part[0][1] = p2[0].y;
             part[1][0] = p2[1].x; part[1][1] = p2[1].y;
         } else
-#endif
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
             for (int et = 0; et < 2; ++et) {
                 const float v = acc2[et][reg];
-#if SSC_ACT_ABL == 1
-                const float h = v;
-#else
                 const float h = LAST_TANH ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v) + 1.0f) : fmaxf(v, 0.0f);
-#endif
                 part[et][reg & 1] = fmaf(h, w3[reg], part[et][reg & 1]);
             }
         // lanes 0-31 need tile 0's lo + hi halves, lanes 32-63 tile 1's: one swap + one add

@@ -32,8 +32,11 @@
 #include "ssc_device.h"
 #include "ssc_host.h"
 
-#ifndef SSC_DYN_BARRIER_KEEP_LDS_READS
-#define SSC_DYN_BARRIER_KEEP_LDS_READS 1
+// SSC_DYN_STAMPS (diagnostic builds only: tools/variants/dyn_mfma_clk.hip -> tools/_build/libssc_clk.so, read by
+// tools/exp_dyn_clock.py; never defined in libssc.so): every block overwrites S[48 * block ..] with {s_memtime, s_memrealtime}
+// deltas of its step loop and the cycles of its phases, for one wave of each group -- the RESULTS ARE WRONG in such a build.
+#ifndef SSC_DYN_STAMPS
+#define SSC_DYN_STAMPS 0
 #endif
 
 namespace ssc {
@@ -49,29 +52,10 @@ constexpr int kDynThreads = 512;
 constexpr int kNW = kDynThreads / 64;
 constexpr int kMaxIn = 12;        // network inputs (state + action)
 constexpr int kMaxKS1 = 2;        // layer-1 k-steps of 32 slots: 2 bias slots + 3 per input
-#ifndef SSC_DYN_LAG_BARRIER_PAIR
-#define SSC_DYN_LAG_BARRIER_PAIR 1
-#endif
-#ifndef SSC_DYN_LAG_X1
-#define SSC_DYN_LAG_X1 11
-#endif
-#ifndef SSC_DYN_LAG_G0_DMA
-#define SSC_DYN_LAG_G0_DMA 1   // 0: both wave groups issue (A/B: tools/gpu_c4_ab.sh)
-#endif
-#ifndef SSC_DYN_LAG_G1_TILE_PRIO
-#define SSC_DYN_LAG_G1_TILE_PRIO 0
-#endif
-#ifndef SSC_DYN_LAG_PRIO
-#define SSC_DYN_LAG_PRIO 3
-#endif
-constexpr int kLagBarrierPair = SSC_DYN_LAG_BARRIER_PAIR;   // LAG kernel: layer-1 unit pair behind which group 0 takes its phase barrier
-// Diagnostic builds for tools/exp_dyn_clock.py (results are WRONG when set; never in libssc.so):
-//  1 no W2 stream (LDS-DMA never issued), 2 no ring barrier: price the tile-boundary work (tools/gpu_c4_ab.sh)
-// 16 clock stamps: every block overwrites S[32*block .. +31] with {d_memtime, d_memrealtime} of its step loop and
-//    the cycles of its phases, for one wave of each group
-#ifndef SSC_DYN_ABLATE
-#define SSC_DYN_ABLATE 0
-#endif
+// LAG kernel tuning, each the winner of a same-box interleaved A/B (NOTEBOOK sections 9.1, 9.7; the variants are in git history):
+constexpr int kLagBarrierPair = 1;   // layer-1 unit pair behind which group 0 takes its phase barrier
+constexpr int kLagX1 = 11;           // fragment at which group 1 takes its tile barrier
+constexpr int kLagPrio = 3;          // issue priority of a wave inside its per-step phase
 
 // LDS-DMA: one wave-instruction copies 64 x 16 B = 1 KiB global -> LDS with no VGPR staging
 // (buffer_load_dwordx4 ... lds).  LDS destination = wave-uniform base + lane*16; source = buffer base +
@@ -336,13 +320,13 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const bool fwd_mode = MODE < 0 ? g.fwd_mode != 0 : MODE == 2;
     const bool sample = MODE < 0 ? g.sample != 0 : MODE == 1;
-    const uint64_t stamp_entry = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
+    const uint64_t stamp_entry = SSC_DYN_STAMPS ? __builtin_amdgcn_s_memrealtime() : 0;
     constexpr int MT = 2 * UT;          // 16-unit tiles of a hidden layer
     constexpr int A2_TILE = UT * 2048;  // W2^T fragments of one 32-unit output tile: NF fragments of 1 KiB
     constexpr int NBUF = LAG ? 4 : dyn_a2_bufs<UT, NFC>();
     constexpr bool STREAM = (NFC == 2) && (UT > 4);
     constexpr bool CMP = (KIN == 4);                            // compact lane-group layer 1 (l1_compact)
-    constexpr bool G0DMA = LAG && (SSC_DYN_LAG_G0_DMA != 0);    // LAG: wave group 0 issues every LDS-DMA piece
+    constexpr bool G0DMA = LAG;                                  // LAG: wave group 0 issues every LDS-DMA piece
     constexpr int A1_BYTES = CMP ? MT * 512 : KS1 * MT * 1024;   // layer-1 fragments: 8 B per lane when compact
     constexpr int A2_CHUNKS = A2_TILE / 1024;           // LDS-DMA pieces per tile
     constexpr int PPW = (A2_CHUNKS + kNW - 1) / kNW;    // pieces per wave per tile
@@ -578,10 +562,10 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
 #pragma unroll
         for (int q = 0; q < RING; ++q) ring[q] = *reinterpret_cast<const bf16x8 *>(l_a2 + (q * 64 + lane) * 16);
     }
-    const uint64_t stamp_c0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memtime() : 0;
-    const uint64_t stamp_r0 = (SSC_DYN_ABLATE & 16) ? __builtin_amdgcn_s_memrealtime() : 0;
+    const uint64_t stamp_c0 = SSC_DYN_STAMPS ? __builtin_amdgcn_s_memtime() : 0;
+    const uint64_t stamp_r0 = SSC_DYN_STAMPS ? __builtin_amdgcn_s_memrealtime() : 0;
     uint64_t ph[6] = {0, 0, 0, 0, 0, 0};  // diagnostic: cycles in input code / layer 1 / hidden tiles / step tail / phase barrier / tile barriers
-#define SSC_STAMP(var) uint64_t var = 0; if (SSC_DYN_ABLATE & 16) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define SSC_STAMP(var) uint64_t var = 0; if (SSC_DYN_STAMPS) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     int vt = 0;  // steps this block has run over all its row tiles: the W2 ring and its barriers go on across row tiles
     // Row tiles of a walking block: its first two are blockIdx.x and blockIdx.x + gridDim.x, every later one comes from a
     // counter all blocks share (the CUs do not run at one clock -- XCDs differ by several per cent under this load -- so
@@ -606,7 +590,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
         if constexpr (CMP) {
             // The phase is what the other wave of this SIMD has to bridge with W2 tiles: it runs at raised issue priority
             // (set behind the last hidden tile, dropped again in front of the first one) ...
-            if (LAG && vt == 0) __builtin_amdgcn_s_setprio(SSC_DYN_LAG_PRIO);
+            if (LAG && vt == 0) __builtin_amdgcn_s_setprio(kLagPrio);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 float xv;
@@ -751,7 +735,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                     // tile 15 of the step before) reaches it; in step 0 group 1 takes its first one here as well and
                     // then issues its pieces of tile 2 (later steps: in tile 15 of the step before)
                     if (p == kLagBarrierPair && (group == 0 || vt == 0)) {
-                        if (!(SSC_DYN_ABLATE & 2)) {
+                        {
                             SSC_STAMP(stamp_p0)
                             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile 1 landed
                             asm volatile("" ::: "memory");
@@ -763,16 +747,14 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                         if (group == 1 && !G0DMA) {
 #pragma unroll
                             for (int q = 0; q < PPW; ++q)
-                                if (!(SSC_DYN_ABLATE & 1))
-                                    lds_dma_1k(a2_rsrc, lane * 16, 2 * A2_TILE + (wave + q * kNW) * 1024, l_a2 + 2 * A2_TILE + (wave + q * kNW) * 1024);
+                                lds_dma_1k(a2_rsrc, lane * 16, 2 * A2_TILE + (wave + q * kNW) * 1024, l_a2 + 2 * A2_TILE + (wave + q * kNW) * 1024);
                         }
                     }
                 }
             }
         }
         if constexpr (LAG) {   // tiles: group 0 at priority 0; group 1 (the one the barriers wait for) may be given more
-            if (SSC_DYN_LAG_G1_TILE_PRIO != 0 && group == 1) __builtin_amdgcn_s_setprio(SSC_DYN_LAG_G1_TILE_PRIO);
-            else __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
         }
         // the actions of the next step: issued here, behind layer 1's scheduling fences, so that the loads fly
         // under the hidden tiles (hoisted to the top of the step they were waited for at once)
@@ -818,7 +800,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 // the phase that follows takes barrier #16, which wants them landed (step 0: loaded by the prologue)
                 constexpr bool LAST = decltype(first_tag)::value == 2;
                 // barrier fragment of group 0 / group 1 (LAG: group 1's may sit anywhere behind the end of the tile before)
-                constexpr int X0 = NF - RING - 1, X1 = LAG ? SSC_DYN_LAG_X1 : X0 - NF / 2;
+                constexpr int X0 = NF - RING - 1, X1 = LAG ? kLagX1 : X0 - NF / 2;
                 static_assert(!STREAM || (UT == 16 && X1 + 2 + 4 * (PPW - 1) < NF), "LDS-DMA issue slots");
                 const int nsel = LAG ? ((jt + 1) & 3) : STREAM ? (bsel == 2 ? 0 : bsel + 1) : ((jt + 1) & (UT - 1));
                 const unsigned char *buf = l_a2 + (LAG ? (jt & 3) : STREAM ? bsel : jt) * A2_TILE + lane * 16;
@@ -850,10 +832,9 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                             // its slack): all 32 pieces of tile jt + 1 in tile jt, eight per wave at fragments 1, 3, .. 15
                             if (GROUP == 0 && !FIRST && f >= 1 && f <= 15 && (f & 1)) {
                                 const int piece = (wave + 4 * (f >> 1)) * 1024;
-                                if (!(SSC_DYN_ABLATE & 1))
-                                    lds_dma_1k(a2_rsrc, lane * 16, ((jt + 1) & (UT - 1)) * A2_TILE + piece, l_a2 + ((jt + 1) & 3) * A2_TILE + piece);
+                                lds_dma_1k(a2_rsrc, lane * 16, ((jt + 1) & (UT - 1)) * A2_TILE + piece, l_a2 + ((jt + 1) & 3) * A2_TILE + piece);
                             }
-                            if (LAST && f > X0 && !(SSC_DYN_ABLATE & 1)) {   // the next step's tile 1: two pieces per fragment
+                            if (LAST && f > X0) {   // the next step's tile 1: two pieces per fragment
 #pragma unroll
                                 for (int h = 0; h < 2; ++h) {
                                     const int piece = (wave + 4 * (2 * (f - X0 - 1) + h)) * 1024;
@@ -863,18 +844,16 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                         } else {
                         if (!FIRST && f >= f0 && (f - f0) % 4 == 0 && (f - f0) / 4 < PPW) {
                             const int p = (f - f0) / 4;
-                            if (!(SSC_DYN_ABLATE & 1))   // ablation 1: no W2 stream (wrong results; prices the LDS-DMA issue)
-                                lds_dma_1k(a2_rsrc, lane * 16, dma_src + p * kNW * 1024, dma_dst + p * kNW * 1024);
+                            lds_dma_1k(a2_rsrc, lane * 16, dma_src + p * kNW * 1024, dma_dst + p * kNW * 1024);
                         }
-                        if (LAST && f > X0 && f - X0 - 1 < PPW && !(SSC_DYN_ABLATE & 1)) {
+                        if (LAST && f > X0 && f - X0 - 1 < PPW) {
                             const int p = f - X0 - 1;
                             lds_dma_1k(a2_rsrc, lane * 16, 1 * A2_TILE + (wave + p * kNW) * 1024, l_a2 + 1 * A2_TILE + (wave + p * kNW) * 1024);
                         }
                         }
-                        if (!FIRST && !(SSC_DYN_ABLATE & 2) && f == (GROUP ? X1 : X0)) {  // barrier tl (ablation 2: none)
+                        if (!FIRST && f == (GROUP ? X1 : X0)) {  // barrier tl
                             SSC_STAMP(stamp_t0)
                             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tl+1 landed
-#if SSC_DYN_BARRIER_KEEP_LDS_READS
                             // A bare s_barrier: __syncthreads() also waits for lgkmcnt(0), i.e. drains the fragment ring
                             // (the read issued one instruction ago included) in every tile.  Nothing here needs that: the
                             // reads of tile tl-1 have all been consumed by MFMAs (LDS reads return in order), the reads in
@@ -883,9 +862,6 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                             asm volatile("" ::: "memory");
                             __builtin_amdgcn_s_barrier();
                             asm volatile("" ::: "memory");
-#else
-                            __syncthreads();
-#endif
                             SSC_STAMP(stamp_t1)
                             ph[5] += stamp_t1 - stamp_t0;
                         }
@@ -909,9 +885,9 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 for (int jt = 0; jt < UT; ++jt) tile_body(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, jt);
             }
             // the phase ahead (state update, input code, layer 1) is what the other wave of this SIMD has to bridge
-            if constexpr (LAG) __builtin_amdgcn_s_setprio(SSC_DYN_LAG_PRIO);
+            if constexpr (LAG) __builtin_amdgcn_s_setprio(kLagPrio);
             SSC_STAMP(stamp_d)
-            if (SSC_DYN_ABLATE & 16) { ph[0] += stamp_l - stamp_a; ph[1] += stamp_b - stamp_l; ph[2] += stamp_d - stamp_b; ph[3] -= stamp_d; }
+            if (SSC_DYN_STAMPS) { ph[0] += stamp_l - stamp_a; ph[1] += stamp_b - stamp_l; ph[2] += stamp_d - stamp_b; ph[3] -= stamp_d; }
         } else {
 #pragma unroll
             for (int p = 0; p < UT; ++p) {
@@ -946,7 +922,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
                 for (int k = 0; k < DS; ++k) st[nt][k] = st[nt][k] + (z[k] * z_std[k] + z_mean[k]);  // :234-237 (0 for k >= d)
             }
         }
-        if ((SSC_DYN_ABLATE & 16) && NFC == 2) { SSC_STAMP(stamp_e) ph[3] += stamp_e; }
+        if (SSC_DYN_STAMPS && NFC == 2) { SSC_STAMP(stamp_e) ph[3] += stamp_e; }
     }
     if (!fwd_mode) {
 #pragma unroll
@@ -973,7 +949,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
     else setup_rows(g, tile, std::false_type{});
     }
     // LAG: group 1's last tile holds barrier #16 H; group 0 meets it here (no phase follows its last tile)
-    if (LAG && group == 0 && g.H > 0 && !(SSC_DYN_ABLATE & 2)) {
+    if (LAG && group == 0 && g.H > 0) {
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_barrier();
     }
@@ -985,7 +961,7 @@ __global__ __launch_bounds__(kDynThreads, 2) void dyn_mfma_sim_kernel(DynSimArgs
             __hip_atomic_store(g.tile_ctr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (SSC_DYN_ABLATE & 16) {
+    if (SSC_DYN_STAMPS) {
         const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c0, dr = __builtin_amdgcn_s_memrealtime() - stamp_r0;
         if (lane == 0 && (wave == 0 || wave == 4)) {  // per block 2 x 24 dwords (wave 0, wave 4): {dc, dr}, 4 phase sums, entry and loop-start realtime, 2 barrier sums
             uint32_t *o = reinterpret_cast<uint32_t *>(g.S) + 48 * blockIdx.x + 24 * group;

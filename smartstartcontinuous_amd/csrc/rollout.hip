@@ -21,12 +21,6 @@
 #include "ssc_device.h"
 #include "ssc_host.h"
 
-#ifndef SSC_ROLLOUT_PLAIN
-#define SSC_ROLLOUT_PLAIN 0
-#endif
-#ifndef SSC_ROLLOUT_STAGGER
-#define SSC_ROLLOUT_STAGGER 0
-#endif
 
 namespace ssc {
 
@@ -319,11 +313,7 @@ struct Rollout {
             // VGPR offset against the wave-uniform row base is the SGPR-base form of global_store (no VALU op).
             uint32_t vo = voff;
             asm volatile("" : "+v"(vo));
-#if SSC_ROLLOUT_PLAIN   // diagnostic variant: plain instead of non-temporal fp32 stores
-#define SSC_STORE_F32(val, ptr) (*(ptr) = (val))
-#else
 #define SSC_STORE_F32(val, ptr) __builtin_nontemporal_store((val), (ptr))
-#endif
 #pragma unroll
             for (int c = 0; c < OBS; ++c) SSC_STORE_F32(obs[c], lane_ptr(ra.log.obs[c] + row, vo));
             SSC_STORE_F32(a, lane_ptr(ra.log.act + row, vo));
@@ -423,13 +413,6 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec
         for (; k < ra.K; ++k)
             r.step(r.pol.act(r.obs, ra.seed, r.env_id, ra.step0 + (uint64_t)k, k == k_tail), k);
     } else if constexpr (PolT::kFusedActor) {
-#if SSC_ROLLOUT_STAGGER
-        {   // diagnostic variant: spread the waves' step phases over one step period
-            const uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-            const uint32_t d = __builtin_amdgcn_readfirstlane((int)(__builtin_bitreverse32(w) >> 27));
-            for (uint32_t q = 0; q < d; ++q) __builtin_amdgcn_s_sleep(1);
-        }
-#endif
         // Four steps per iteration: one Philox evaluation (counter t >> 2) serves them (ou_gaussian_from_words),
         // and the evaluation for the NEXT four is split 3 + 3 + 2 + 2 rounds over the four step bodies.
         uint64_t t = ra.step0;
@@ -438,12 +421,6 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec
         if (k + 4 <= ra.K) {
             if (k != 0) cur = rng_words(ra.seed, r.env_id, t >> 2, TAG_OU);
             for (; k + 4 <= ra.K; k += 4, t += 4) {
-#if SSC_ACT_ABL == 3
-                r.step(r.pol.act(r.obs, 0.5f), k);
-                r.step(r.pol.act(r.obs, -0.25f), k + 1);
-                r.step(r.pol.act(r.obs, 0.125f), k + 2);
-                r.step(r.pol.act(r.obs, -1.0f), k + 3);
-#else
                 PhiloxPipe nx;
                 nx.start(ra.seed, r.env_id, (t >> 2) + 1, TAG_OU);
                 nx.rounds<3>(); nx.pin();
@@ -457,7 +434,6 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(typename EnvT::Const ec
                 nx.rounds<2>(); nx.pin();
                 r.step(r.pol.act(r.obs, r1 * s1), k + 3);
                 cur = nx.get();
-#endif
             }
         } else if (k < ra.K && k != 0) {
             cur = rng_words(ra.seed, r.env_id, t >> 2, TAG_OU);

@@ -298,10 +298,10 @@ def test_rollout_pendulum_teacher_forced(ssc, policy):
 
 
 def test_rollout_actor_full_size_properties(ssc):
-    """BASELINE config 3 at full size (65 536 envs x 256 steps, actor 64-32 on the bf16 MFMA + OU noise):
+    """BASELINE config 3 at full size (65 536 envs x 1024 steps -- the chunk the bench leg launches --, actor 64-32 on the bf16 MFMA + OU noise):
     size-independent properties on the device, the logged action equal to the standalone actor kernel plus a
     noise term bounded by the OU process, bit-for-bit repeatability, and a 128-env slice replayed by the oracle."""
-    n, K, seed = 65536, 256, 1234
+    n, K, seed = 65536, 1024, 1234
     w = actor_weights(2, 64, 32, seed=1234, w3_scale=0.5)
     wt = {k: torch.as_tensor(v) for k, v in w.items()}
 
@@ -321,7 +321,12 @@ def test_rollout_actor_full_size_properties(ssc):
     goal = chunk.obs2[0] >= 0.45
     r = goal.float() * 100.0 - 0.1 * chunk.act * chunk.act
     assert float((r - chunk.rew).abs().max()) <= 1e-4
-    assert bool((done == goal).all())                                             # 256 < 999: no time-limit resets yet
+    # done = goal or TimeLimit(999): steps since the env's previous done (or the chunk's start), on the device
+    idx = torch.arange(K, device=done.device, dtype=torch.int32)[:, None].expand(K, n)
+    last = torch.cummax(torch.where(done, idx, torch.full_like(idx, -1)), dim=0).values
+    prev = torch.cat([torch.full_like(last[:1], -1), last[:-1]])                   # index of the previous done, -1: none yet
+    elapsed = idx - prev
+    assert bool((done == (goal | (elapsed == 999))).all()) and int((done & ~goal).sum()) > 0
     stats = env.stats.cpu().numpy()
     assert stats[2] == n * K and stats[3] == int(done.sum().item())
     # same seed, same ids -> the same bits

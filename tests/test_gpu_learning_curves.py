@@ -166,11 +166,14 @@ def test_edited_env_curve_fixture(golden_dir):
 
 @pytest.mark.gpu
 def test_ddpg_on_the_edited_env_quiets_down_like_the_reference_runs(golden_dir):
-    """One seed x 80 episodes x 1000 steps of rlTrain(DDPG_Baselines_agent) on Continuous_MountainCarEnv_Editted(0.4): like the
+    """Three seeds x 80 episodes x 1000 steps of rlTrain(DDPG_Baselines_agent) on Continuous_MountainCarEnv_Editted(0.4): like the
     reference's 12 runs no episode reaches the goal, and the median return of episodes 0..39 and 40..79 follows the
     reference's curve -- which pins the OU process (mu, sigma, theta, dt, per-episode reset, epsilon decay), the clip and
-    how fast the learner pulls the actor's output to zero.  (17 seeds of this engine: 16 inside / next to the bands, one
-    that saturates the actor instead, profiles/r03/curves/; the bands are widened by a quarter of their width.)"""
+    how fast the learner pulls the actor's output to zero.  The process has a second, rarer outcome that the reference's own
+    archives show at the same rate (3 of the 40 runs of ddpg_lr_experiment, 1 of its 48 edited-env
+    SmartStart runs; 4 of this engine's 41): the actor SATURATES (|a| = 1, return ~ -90 from the first window on).  The
+    acceptance rule is two-sided: every seed is either inside the bands (widened by a quarter of their width) or a clean
+    saturated run, at most one of the three is saturated, and the in-band seeds' mean is inside the bands."""
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU: the HIP path has no fallback")
     import sys
@@ -180,12 +183,16 @@ def test_ddpg_on_the_edited_env_quiets_down_like_the_reference_runs(golden_dir):
     b = edited_env_bands(golden_dir)
     slack = 0.25 * (b["hi"] - b["lo"])
     meds = []
-    for seed in (4004,):                      # 22 s; 17 seeds: profiles/r03/curves/edited_ddpg*.txt
+    for seed in (4004, 4005, 4006):           # 22 s each; 17 seeds: profiles/r03/curves/edited_ddpg*.txt
         ep, _ = run("edited", 80, seed, None, "f32", None, smart=False)
         assert ep.shape == (80, 2) and (ep[:, 0] == 1000).all(), "an episode ended before the time limit"
         meds.append([np.median(ep[0:40, 1]), np.median(ep[40:80, 1])])
         print("seed %d: median return of episodes 0-39 %.1f, 40-79 %.1f" % (seed, *meds[-1]), flush=True)
     meds = np.asarray(meds)
     print("reference: per-window [min, max] of the 12 runs' medians", b["lo"], b["hi"])
-    assert ((meds >= b["lo"] - slack - 2.5) & (meds <= b["hi"] + slack)).all(), (meds, b["lo"], b["hi"])
-    assert (b["lo"] - slack <= meds.mean(axis=0)).all() and (meds.mean(axis=0) <= b["hi"] + slack).all(), (meds, b["lo"], b["hi"])
+    in_band = ((meds >= b["lo"] - slack - 2.5) & (meds <= b["hi"] + slack)).all(axis=1)
+    saturated = (meds <= -60.0).all(axis=1)                 # |a| = 1 throughout: -0.1 * 1000 per episode, less the clipped noise
+    assert (in_band | saturated).all(), (meds, b["lo"], b["hi"])
+    assert saturated.sum() <= 1 and in_band.sum() >= 2, (meds, saturated)
+    m = meds[in_band].mean(axis=0)
+    assert (b["lo"] - slack <= m).all() and (m <= b["hi"] + slack).all(), (meds, b["lo"], b["hi"])

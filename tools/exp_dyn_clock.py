@@ -1,4 +1,4 @@
-"""In-kernel clock of dyn_mfma_sim_kernel (diagnostic build -DSSC_DYN_ABLATE=16, tools/_build/libssc_clk.so):
+"""In-kernel clock of dyn_mfma_sim_kernel (diagnostic build tools/variants/dyn_mfma_clk.hip -> tools/_build/libssc_clk.so, `make -C tools`):
 after ~2 s of back-to-back launches, Delta s_memtime / Delta s_memrealtime x 100 MHz per block."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
