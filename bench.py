@@ -316,6 +316,10 @@ def bench_config4(args, torch, emit=True):
     except Exception as e:           # noqa: BLE001
         res["roofline"]["gemm_probe"] = {"error": repr(e)}
     # SURVEY.md section 8(d) names H = 20 (the class default horizon, NND_MB_agent.py:62) beside H = 4: the same launch, 20 steps
+    if getattr(args, "no_h20", False):
+        if emit:
+            print(json.dumps(res), flush=True)
+        return res
     H20 = 20
     S20 = torch.empty((H20 + 1, M, d), device="cuda")
     sp20 = nav.mpc_sampling(N, [-2.0], [2.0], 1234, 0, 0)
@@ -757,6 +761,7 @@ def main():
                     help="config 2, one GPU: skip the BASELINE configs[2] / configs[3] lines attached as `other_configs`")
     ap.add_argument("--no-per-env", action="store_true", help="--config 4: skip the one-navigator-per-env leg")
     ap.add_argument("--per-env-only", action="store_true", help="--config 4: ONLY the one-navigator-per-env leg (profiling runs)")
+    ap.add_argument("--no-h20", action="store_true", help="--config 4: skip the horizon-20 leg (profiling runs: its launches carry the same kernel name)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based): 2 = headline random-policy rollout (default), "
                          "3 = + DDPG actor MFMA, 4 = NND_MB 2x500 forward sim + MPC; 5 = (not a BASELINE config) the MPC step in "

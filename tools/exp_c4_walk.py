@@ -15,7 +15,10 @@ model, d, a = make((4, 500, 500, 3))
 model.precision = "bf16_mfma"
 flop_row = 2.0 * (4 * 500 + 500 * 500 + 500 * 3)
 out = {"lib": os.path.basename(F.LIB_PATH)}
+ONLY = sys.argv[2] if len(sys.argv) > 2 else None     # one case alone (profiling runs: rocprofv3 averages by kernel name)
 for name, P, N, H in (("rows_1Mi_h4", 65536, 16, 4), ("rows_64Ki_h4", 16, 4096, 4), ("rows_64Ki_h20", 16, 4096, 20), ("rows_1Mi_h1", 65536, 16, 1)):
+    if ONLY is not None and name != ONLY:
+        continue
     M = P * N
     s0 = torch.randn((P, d), device="cuda") * 0.3
     S = torch.empty((H + 1, M, d), device="cuda")

@@ -20,8 +20,8 @@ step c3_kt 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3/k
 step c3_pmc 120 rocprofv3 --pmc $SQ --output-format csv -d $OUT/c3/pmc_sq -- python3 bench.py --config 3 --no-cpu-baseline --no-single-step --no-other-configs --steps 5 --warmup 2 --steady-launches 0 --settle-launches 0 > $OUT/c3/pmc_sq.log 2>&1
 # config 4 (dynamics MLP forward sim + MPC)
 step c4_bench 240 bash -c "python3 bench.py --config 4 --cpu-budget 8 > $OUT/c4/bench.json 2> $OUT/c4/bench.err"
-step c4_kt 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4/kt -- python3 bench.py --config 4 --no-per-env --no-cpu-baseline --no-single-step --no-other-configs > $OUT/c4/kt.log 2>&1
-step c4_pmc 120 rocprofv3 --pmc $SQ --output-format csv -d $OUT/c4/pmc_sq -- python3 bench.py --config 4 --no-per-env --no-cpu-baseline --no-single-step --no-other-configs --steps 5 --warmup 2 --steady-launches 0 --settle-launches 0 > $OUT/c4/pmc_sq.log 2>&1
+step c4_kt 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4/kt -- python3 bench.py --config 4 --no-per-env --no-h20 --no-cpu-baseline --no-single-step --no-other-configs > $OUT/c4/kt.log 2>&1
+step c4_pmc 120 rocprofv3 --pmc $SQ --output-format csv -d $OUT/c4/pmc_sq -- python3 bench.py --config 4 --no-per-env --no-h20 --no-cpu-baseline --no-single-step --no-other-configs --steps 5 --warmup 2 --steady-launches 0 --settle-launches 0 > $OUT/c4/pmc_sq.log 2>&1
 # dynamics-model training steps and the data-collection kernels
 step train_kt 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train/kt -- python3 tools/exp_dyn_train.py > $OUT/train/out.txt 2>&1
 step dataset_kt 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dataset/kt -- python3 tools/exp_dataset.py > $OUT/dataset/out.txt 2>&1

@@ -25,7 +25,10 @@ def source_sha():
 def main(d):
     pmc = json.load(open(os.path.join(d, "pmc_per_kernel.json")))
     # the bench's kernel: in-kernel candidate sampling (last template argument 1) when it was profiled, else any
-    names = sorted((n for n in pmc if "dyn_mfma_sim_kernel" in n), key=lambda n: (", 1>" not in n, n))
+    # (round 4: the last template argument says whether the block walks over row tiles -- the per-env leg's kernel)
+    want_walk = len(sys.argv) > 2 and sys.argv[2] == "walk"
+    names = sorted((n for n in pmc if "dyn_mfma_sim_kernel" in n and (", true>" in n) == want_walk),
+                   key=lambda n: (", 1, " not in n, n))
     if not names:
         print("no dyn_mfma_sim_kernel in", d)
         return 1
