@@ -542,10 +542,18 @@ __global__ __launch_bounds__(256) void ddpg_wide_apply_kernel(ApplyArgs a) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int n = a.nA + a.nC;
     if (p < n) {
-        // fixed-order sum of the per-workgroup partials, 8 loads in flight
+        // fixed-order sum of the per-workgroup partials; 32 loads in flight (the sum is a chain of L2 round trips: at 8 in
+        // flight a batch of 1024 -- 64 partials -- cost eight of them, 10.6 us per iteration in the actor-learner loop)
         float g = 0.0f;
         const float *src = a.gpart + p;
         int b = 0;
+        for (; b + 32 <= a.n_blocks; b += 32) {
+            float v[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = src[(int64_t)(b + j) * n];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) g += v[j];
+        }
         for (; b + 8 <= a.n_blocks; b += 8) {
             float v[8];
 #pragma unroll
