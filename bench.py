@@ -417,6 +417,23 @@ def bench_config4_envs(args, torch, emit=True, P=N_ENVS_PER_GPU, N=16, H=4, K=40
     el = time.perf_counter() - t0
     ms_step = el / (reps * K) * 1e3
     flop_row = 2.0 * ((d + a) * 500 + 500 * 500 + 500 * d)
+    # the simulation launch of this leg alone (P * N rows = 4096 row tiles on 256 CUs: the WALKING instantiation of the
+    # kernel, round 4), settled: median of 20 launches after 0.4 s of the same launch
+    sp = nav.mpc_sampling(N, [-2.0], [2.0], 1234, 0, 0)
+    s0p = torch.as_tensor(start, dtype=torch.float32, device="cuda").contiguous()
+    Ssim = torch.empty((H + 1, P * N, d), device="cuda")
+    sim = lambda: model.do_forward_sim_sampled(s0p, sp, P * N, H, out=Ssim)
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < (0.4 if args.settle_launches > 0 else 0.0):
+        for _ in range(10):
+            sim()
+        torch.cuda.synchronize()
+    sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for x, y in sev:
+        x.record(); sim(); y.record()
+    torch.cuda.synchronize()
+    sim_ms = sorted(x.elapsed_time(y) for x, y in sev)[len(sev) // 2]
+    del Ssim
     res = {"metric": "env-steps/sec, Pendulum-v1 + NND_MB 2x500 MPC navigation, 65 536 envs (one navigator per env)",
            "value": P / (ms_step * 1e-3), "unit": "env-steps/s", "row_steps_per_s": P * N * H / (ms_step * 1e-3),
            "n_gpus": 1, "steps": reps * K, "ms_per_step": ms_step, "gpu_ms_per_step": e0.elapsed_time(e1) / (reps * K),
@@ -426,7 +443,11 @@ def bench_config4_envs(args, torch, emit=True, P=N_ENVS_PER_GPU, N=16, H=4, K=40
                                   "200-waypoint plans" % (P, N, P * N, H, K)},
            "roofline": {"bound": "mfma", "achieved": flop_row * P * N * H / (ms_step * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": flop_row * P * N * H / (ms_step * 1e-3) / 1e12 / 2500.0, "traffic": None,
-                        "note": "whole env-step (simulate + score + act/step/log) against the bf16 MFMA roof of its simulated rows"}}
+                        "note": "whole env-step (simulate + score + act/step/log) against the bf16 MFMA roof of its simulated rows",
+                        "sim_kernel": {"kernel_ms": sim_ms, "achieved": flop_row * P * N * H / (sim_ms * 1e-3) / 1e12,
+                                       "frac": flop_row * P * N * H / (sim_ms * 1e-3) / 1e12 / 2500.0,
+                                       "kernel": "ssc::dyn_mfma_sim_kernel<16,2,true,4,true,1,true> (256 blocks walking over 4096 row tiles)",
+                                       "note": "the simulation launch alone, median of 20 launches after 0.4 s of the same launch"}}}
     if emit:
         print(json.dumps(res), flush=True)
     return res
