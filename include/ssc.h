@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSC_VERSION 107 /* 0.1.7: LayerNorm (ssc_actor_desc / ssc_critic_desc ln*, ssc_ddpg_desc.layer_norm); 0.1.6: ssc_nav_compact + live lists in ssc_mpc_sampling / ssc_mpc_problems; 0.1.5: ssc_ou_desc.d_epsilon, ssc_decay_schedule, ssc_replay_append_shard; 0.1.4: ssc_path_shortcut; 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
+#define SSC_VERSION 108 /* 0.1.8: ssc_ddpg_desc.critic_l2_reg / clip_norm, ssc_mse_batches; 0.1.7: LayerNorm (ssc_actor_desc / ssc_critic_desc ln*, ssc_ddpg_desc.layer_norm); 0.1.6: ssc_nav_compact + live lists in ssc_mpc_sampling / ssc_mpc_problems; 0.1.5: ssc_ou_desc.d_epsilon, ssc_decay_schedule, ssc_replay_append_shard; 0.1.4: ssc_path_shortcut; 0.1.3: ssc_zscore_concat (0.1.2: plan pool + active mask in ssc_mpc_problems / ssc_mpc_sampling, ssc_smartstart_rollout_step) */
 
 typedef void *ssc_stream_t; /* hipStream_t */
 
@@ -246,6 +246,12 @@ int ssc_mlp_forward(const ssc_mlp_desc *mlp, int64_t m, const float *d_x, float 
  * or any divisor P of m (P problems with m/P candidate sequences each: row r starts from state r / (m/P)).
  * d_A is [m][H][act_dim]; d_S is [H+1][m][state_dim]. */
 size_t ssc_dyn_workspace_bytes(const ssc_mlp_desc *mlp, int64_t m, int precision);
+/* Dyn_Model.run_validation's loss (dynamics_model.py:173-196 with mse_ of :42): d_batch_loss[b] = mean over the
+ * `batch_elems` (= batchsize * out_dim) consecutive elements of batch b of (d_z - d_pred)^2, d_mean[0] = their mean in
+ * batch order.  d_pred: the network's outputs for the first n_batches * batchsize rows (ssc_mlp_forward). */
+int ssc_mse_batches(const float *d_pred, const float *d_z, int64_t n_batches, int64_t batch_elems, float *d_batch_loss,
+                    float *d_mean, ssc_stream_t stream);
+
 /* The MFMA path works from a packed bf16 image of the weights (and of the statistics) in the workspace.
  * ssc_dyn_forward_sim / ssc_mlp_forward with SSC_PREC_BF16_MFMA write that image on every call; a caller
  * whose weights stay put between calls -- the navigator between two Dyn_Model.train() rounds
@@ -488,6 +494,12 @@ typedef struct ssc_ddpg_desc {
                                                              [W1|b1|beta1|gamma1|W2|b2|beta2|gamma2|W3|b3] (TF trainable_vars order;
                                                              tc.layers.layer_norm creates beta before gamma) and the step runs on
                                                              the multi-workgroup kernels (ssc_ddpg_train_ws) */
+    float critic_l2_reg;                                  /* > 0: critic_loss += critic_l2_reg * sum(W^2) / 2 over the critic's
+                                                             three dense kernels (ddpg_editted.py:183-191; the name filter keeps
+                                                             all of them, models_editted.py names no layer 'output'); 0: none */
+    float clip_norm;                                      /* > 0: every variable's gradient, actor and critic, clipped to this
+                                                             2-norm (U.flatgrad(..., clip_norm), ddpg_editted.py:175, 197);
+                                                             <= 0: none.  Either option runs the multi-workgroup kernels. */
 } ssc_ddpg_desc;
 
 /* Replay storage the batches are drawn from: row-major device arrays of `capacity` records

@@ -129,7 +129,8 @@ class DdpgDesc(Structure):
                 ("adam_m_actor", c_void_p), ("adam_v_actor", c_void_p), ("adam_m_critic", c_void_p),
                 ("adam_v_critic", c_void_p), ("adam_t", c_void_p),
                 ("gamma", c_float), ("tau", c_float), ("actor_lr", c_float), ("critic_lr", c_float),
-                ("beta1", c_float), ("beta2", c_float), ("epsilon", c_float), ("obs_clip", c_float), ("layer_norm", c_int32)]
+                ("beta1", c_float), ("beta2", c_float), ("epsilon", c_float), ("obs_clip", c_float), ("layer_norm", c_int32),
+                ("critic_l2_reg", c_float), ("clip_norm", c_float)]
 
 
 class ReplayView(Structure):
@@ -203,6 +204,7 @@ _SIGNATURES = {
                                    c_size_t, c_void_p]),
     "ssc_mlp_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),
     "ssc_mlp_forward": (c_int, [POINTER(MlpDesc), c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "ssc_mse_batches": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "ssc_dyn_workspace_bytes": (c_size_t, [POINTER(MlpDesc), c_int64, c_int]),
     "ssc_dyn_prepare": (c_int, [POINTER(MlpDesc), POINTER(Norm), c_void_p, c_size_t, c_void_p]),
     "ssc_dyn_forward_sim": (c_int, [POINTER(MlpDesc), POINTER(Norm), c_int64, c_int32, c_int32, c_int32, c_void_p,

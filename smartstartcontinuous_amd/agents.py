@@ -191,8 +191,10 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         self.remaining_steps_before_train = num_steps_before_train
         self.reward_scale = reward_scale
         self.gamma, self.tau, self.actor_lr, self.critic_lr = gamma, tau, actor_lr, critic_lr
-        if critic_l2_reg or clip_norm is not None:
-            raise NotImplementedError("critic_l2_reg / clip_norm are not on the accelerated path (unused by every shipped run)")
+        # ddpg_editted.py:183-191 / :175, 197 (unused by the shipped runs; the multi-workgroup learner carries both)
+        if critic_l2_reg < 0 or (clip_norm is not None and not clip_norm > 0):
+            raise ValueError("critic_l2_reg must be >= 0 and clip_norm None or > 0")
+        self.critic_l2_reg, self.clip_norm = float(critic_l2_reg), clip_norm
         self.lastLayerTanh = bool(lastLayerTanh)
         # DDPG_editted clips what it feeds its networks to observation_range (ddpg_editted.py:66,106-109); the reference
         # agent never overrides the default (-5, 5), and it applies with normalize_observations=False too
@@ -356,6 +358,7 @@ class DDPG_Baselines_agent(ValueFuncRLAgent, ReplayBufferRLAgent):
         d.beta1, d.beta2, d.epsilon = 0.9, 0.999, 1e-8          # ddpg_editted.py:176,198
         d.obs_clip = float(self.observation_range[1])
         d.layer_norm = int("ln1_g" in self.weights)
+        d.critic_l2_reg, d.clip_norm = self.critic_l2_reg, 0.0 if self.clip_norm is None else float(self.clip_norm)
         return d
 
     def train_on(self, s, a, r, t, s2, batch_idx, n_iters):

@@ -685,11 +685,12 @@ static int ddpg_train_any(const char *who, const ssc_ddpg_desc *d, const ssc_rep
                 "%s: bad hidden sizes", who);
     const char *force_i = getenv("SSC_DDPG_INTERPRETER"), *force_w = getenv("SSC_DDPG_WIDE");
     const bool want_interp = force_i && force_i[0] == '1', want_wide = force_w && force_w[0] == '1' && have_ws;
-    // (LayerNorm networks run on the multi-workgroup kernels only)
-    const bool narrow = !d->layer_norm && d->batch_size == kB && d->actor_h1 <= 64 && d->actor_h2 <= 64 && d->critic_h1 <= 64 && d->critic_h2 <= 64;
+    SSC_REQUIRE(d->critic_l2_reg >= 0.0f, "%s: critic_l2_reg < 0", who);
+    // (LayerNorm networks, critic_l2_reg and clip_norm run on the multi-workgroup kernels only)
+    const bool narrow = !d->layer_norm && d->critic_l2_reg == 0.0f && !(d->clip_norm > 0.0f) && d->batch_size == kB && d->actor_h1 <= 64 && d->actor_h2 <= 64 && d->critic_h1 <= 64 && d->critic_h2 <= 64;
     if (!have_ws && !narrow)
-        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: batch_size %d / hidden layers wider than 64 run the multi-workgroup "
-                                           "kernels, which need a workspace: call ssc_ddpg_train_ws", d->batch_size);
+        return set_error(SSC_EUNSUPPORTED, "ssc_ddpg_train: batch_size %d / hidden layers wider than 64 / LayerNorm / critic_l2_reg / "
+                                           "clip_norm run the multi-workgroup kernels, which need a workspace: call ssc_ddpg_train_ws", d->batch_size);
     if (n_iters == 0) return SSC_OK;
     SSC_REQUIRE(d->actor && d->critic && d->target_actor && d->target_critic && d->adam_m_actor && d->adam_v_actor &&
                     d->adam_m_critic && d->adam_v_critic && d->adam_t,

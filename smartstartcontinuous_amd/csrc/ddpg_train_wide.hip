@@ -525,10 +525,75 @@ struct ApplyArgs {
     const float *gpart, *lpart;
     float *losses;      // [2] of this iteration or nullptr
     int32_t n_blocks, nA, nC, it;
+    // critic_l2_reg / clip_norm (ddpg_editted.py:175, 183-197): the summed gradient goes through `gsum` (prepare kernel)
+    float *gsum;        // [nA + nC]
+    float *regpart;     // [apply blocks] sum of squares of the block's regularised critic weights
+    int32_t reg_lo[3], reg_hi[3];   // flat [actor | critic] ranges of the critic's dense kernels W1, W2, W3
+    int32_t n_var;
+    int32_t var_lo[21];             // variable boundaries in the flat order (clip_norm is per variable); var_lo[n_var] = nA + nC
 };
 
+// fixed-order sum of the per-workgroup partials; 32 loads in flight (the sum is a chain of L2 round trips: at 8 in
+// flight a batch of 1024 -- 64 partials -- cost eight of them, 10.6 us per iteration in the actor-learner loop)
+__device__ __forceinline__ float wide_partial_sum(const ApplyArgs &a, int p, int n) {
+    float g = 0.0f;
+    const float *src = a.gpart + p;
+    int b = 0;
+    for (; b + 32 <= a.n_blocks; b += 32) {
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = src[(int64_t)(b + j) * n];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) g += v[j];
+    }
+    for (; b + 8 <= a.n_blocks; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(b + j) * n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g += v[j];
+    }
+    for (; b < a.n_blocks; ++b) g += src[(int64_t)b * n];
+    return g;
+}
+
+// sum over the 256 threads of a block, the same order every time (xor butterfly inside a wave, then the four waves in order)
+__device__ __forceinline__ float block256_sum(float x, float *red) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+    __syncthreads();                        // `red` may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// critic_l2_reg / clip_norm only: gsum = sum of the partials (+ critic_l2_reg * W on the critic's dense kernels: the
+// gradient of scale * l2_loss(W), ddpg_editted.py:183-191), and the block's share of sum W^2 for the reported loss
+__global__ __launch_bounds__(256) void ddpg_wide_prepare_kernel(ApplyArgs a) {
+    __shared__ float red[4];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int n = a.nA + a.nC;
+    float sq = 0.0f;
+    if (p < n) {
+        float g = wide_partial_sum(a, p, n);
+        bool reg = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) reg = reg || (p >= a.reg_lo[k] && p < a.reg_hi[k]);
+        if (reg && a.d.critic_l2_reg != 0.0f) {
+            const float w = a.d.critic[p - a.nA];
+            g += a.d.critic_l2_reg * w;
+            sq = w * w;
+        }
+        a.gsum[p] = g;
+    }
+    sq = block256_sum(sq, red);
+    if (threadIdx.x == 0) a.regpart[blockIdx.x] = sq;
+}
+
+template <bool PREPARED>
 __global__ __launch_bounds__(256) void ddpg_wide_apply_kernel(ApplyArgs a) {
     __shared__ AdamCfg cfg[2];
+    __shared__ float red[4];
     if (threadIdx.x < 2) {
         // MpiAdam's bias-corrected step size in f64 (1 - 0.999^t loses 5 digits in fp32); t = counter before this
         // call + iterations done + 1 (the counters themselves move once, after the last iteration)
@@ -541,27 +606,29 @@ __global__ __launch_bounds__(256) void ddpg_wide_apply_kernel(ApplyArgs a) {
     __syncthreads();
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int n = a.nA + a.nC;
+    float g = 0.0f;
+    if constexpr (PREPARED) {
+        if (p < n) g = a.gsum[p];
+        if (a.d.clip_norm > 0.0f) {
+            // tf.clip_by_norm per variable (U.flatgrad(..., clip_norm), ddpg_editted.py:175, 197): every block sums the
+            // squares of the variables its 256 parameters belong to (at most a few), in the same order in every block
+            auto var_of = [&](int q) { int v = 0; while (v + 1 < a.n_var && q >= a.var_lo[v + 1]) ++v; return v; };
+            const int last = (blockIdx.x * 256 + 255 < n ? blockIdx.x * 256 + 255 : n - 1);
+            const int v_first = var_of(blockIdx.x * 256), v_last = var_of(last), mine = p < n ? var_of(p) : -1;
+            float scale = 1.0f;
+            for (int v = v_first; v <= v_last; ++v) {
+                const int lo = a.var_lo[v], hi = a.var_lo[v + 1];
+                float s = 0.0f;
+                for (int q = lo + (int)threadIdx.x; q < hi; q += 256) { const float x = a.gsum[q]; s += x * x; }
+                const float norm = sqrtf(block256_sum(s, red));
+                if (mine == v) scale = a.d.clip_norm / fmaxf(norm, a.d.clip_norm);
+            }
+            g *= scale;
+        }
+    } else {
+        if (p < n) g = wide_partial_sum(a, p, n);
+    }
     if (p < n) {
-        // fixed-order sum of the per-workgroup partials; 32 loads in flight (the sum is a chain of L2 round trips: at 8 in
-        // flight a batch of 1024 -- 64 partials -- cost eight of them, 10.6 us per iteration in the actor-learner loop)
-        float g = 0.0f;
-        const float *src = a.gpart + p;
-        int b = 0;
-        for (; b + 32 <= a.n_blocks; b += 32) {
-            float v[32];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = src[(int64_t)(b + j) * n];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) g += v[j];
-        }
-        for (; b + 8 <= a.n_blocks; b += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(b + j) * n];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) g += v[j];
-        }
-        for (; b < a.n_blocks; ++b) g += src[(int64_t)b * n];
         const int net = p < a.nA ? 0 : 1;
         const int q = net == 0 ? p : p - a.nA;
         float *theta = net == 0 ? a.d.actor : a.d.critic, *target = net == 0 ? a.d.target_actor : a.d.target_critic;
@@ -578,7 +645,13 @@ __global__ __launch_bounds__(256) void ddpg_wide_apply_kernel(ApplyArgs a) {
     if (blockIdx.x == 0 && threadIdx.x < 2 && a.losses != nullptr) {
         float s = 0.0f;
         for (int b = 0; b < a.n_blocks; ++b) s += a.lpart[b * 2 + threadIdx.x];
-        a.losses[threadIdx.x] = s / (float)a.d.batch_size;
+        s /= (float)a.d.batch_size;
+        if (PREPARED && threadIdx.x == 0) {
+            float w2 = 0.0f;
+            for (unsigned b = 0; b < gridDim.x; ++b) w2 += a.regpart[b];
+            s += 0.5f * a.d.critic_l2_reg * w2;
+        }
+        a.losses[threadIdx.x] = s;
     }
 }
 
@@ -610,9 +683,18 @@ static int wide_params(const ssc_ddpg_desc *d) {
     return A.total() + C.total();
 }
 
+static bool wide_prepared(const ssc_ddpg_desc *d) { return d->critic_l2_reg != 0.0f || d->clip_norm > 0.0f; }
+static size_t wide_gpart_bytes(const ssc_ddpg_desc *d) { return ((size_t)wide_blocks(d) * (size_t)wide_params(d) * sizeof(float) + 255) & ~(size_t)255; }
+static size_t wide_lpart_bytes(const ssc_ddpg_desc *d) { return (((size_t)wide_blocks(d) * 2 * sizeof(float) + 255) & ~(size_t)255) + 1024; }
+
+// [gpart | lpart (+ 1 KB the diagnostic build stamps into)] and, with critic_l2_reg / clip_norm, [gsum | regpart]
 size_t ddpg_wide_workspace_bytes(const ssc_ddpg_desc *d) {
-    const size_t nb = (size_t)wide_blocks(d);
-    return ((nb * (size_t)wide_params(d) * sizeof(float) + 255) & ~(size_t)255) + ((nb * 2 * sizeof(float) + 255) & ~(size_t)255) + 1024;
+    size_t bytes = wide_gpart_bytes(d) + wide_lpart_bytes(d);
+    if (wide_prepared(d)) {
+        const size_t n = (size_t)wide_params(d);
+        bytes += ((n * sizeof(float) + 255) & ~(size_t)255) + (((n + 255) / 256 * sizeof(float) + 255) & ~(size_t)255);
+    }
+    return bytes;
 }
 
 int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
@@ -782,7 +864,7 @@ int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int
     g.n_params = nA + nC;
     const int nb = wide_blocks(d);
     g.gpart = static_cast<float *>(d_workspace);
-    g.lpart = reinterpret_cast<float *>(static_cast<char *>(d_workspace) + (((size_t)nb * g.n_params * sizeof(float) + 255) & ~(size_t)255));
+    g.lpart = reinterpret_cast<float *>(static_cast<char *>(d_workspace) + wide_gpart_bytes(d));
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(ddpg_wide_grad_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -792,12 +874,39 @@ int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int
     ApplyArgs ap{};
     ap.d = *d; ap.gpart = g.gpart; ap.lpart = g.lpart; ap.n_blocks = nb; ap.nA = nA; ap.nC = nC;
     const unsigned apply_blocks = (unsigned)((nA + nC + 255) / 256);
+    const bool prepared = wide_prepared(d);
+    if (prepared) {
+        char *tail = static_cast<char *>(d_workspace) + wide_gpart_bytes(d) + wide_lpart_bytes(d);
+        ap.gsum = reinterpret_cast<float *>(tail);
+        ap.regpart = reinterpret_cast<float *>(tail + (((size_t)(nA + nC) * sizeof(float) + 255) & ~(size_t)255));
+        // the name filter of ddpg_editted.py:184 ('kernel' in name, 'output' not in name) keeps all three dense kernels of
+        // models_editted.py's critic (none of its layers is named 'output'); biases and LayerNorm parameters stay out
+        const int lo[3] = {nA + C.oW1(), nA + C.oW2(), nA + C.oW3()}, hi[3] = {nA + C.ob1(), nA + C.ob2(), nA + C.ob3()};
+        for (int k = 0; k < 3; ++k) { ap.reg_lo[k] = lo[k]; ap.reg_hi[k] = hi[k]; }
+        int nv = 0;
+        for (int n = 0; n < 2; ++n) {
+            const WNet &N = n == 0 ? A : C;
+            const int base = n == 0 ? 0 : nA;
+            ap.var_lo[nv++] = base + N.oW1(); ap.var_lo[nv++] = base + N.ob1();
+            if (ln) { ap.var_lo[nv++] = base + N.obe1(); ap.var_lo[nv++] = base + N.og1(); }
+            ap.var_lo[nv++] = base + N.oW2(); ap.var_lo[nv++] = base + N.ob2();
+            if (ln) { ap.var_lo[nv++] = base + N.obe2(); ap.var_lo[nv++] = base + N.og2(); }
+            ap.var_lo[nv++] = base + N.oW3(); ap.var_lo[nv++] = base + N.ob3();
+        }
+        ap.n_var = nv;
+        ap.var_lo[nv] = nA + nC;
+    }
     for (int it = 0; it < n_iters; ++it) {
         g.batch_idx = d_batch_idx + (int64_t)it * d->batch_size;
         hipLaunchKernelGGL(ddpg_wide_grad_kernel, dim3(nb), dim3(kWThreads), lds, stream, g);
         ap.it = it;
         ap.losses = d_losses ? d_losses + 2 * it : nullptr;
-        hipLaunchKernelGGL(ddpg_wide_apply_kernel, dim3(apply_blocks), dim3(256), 0, stream, ap);
+        if (prepared) {
+            hipLaunchKernelGGL(ddpg_wide_prepare_kernel, dim3(apply_blocks), dim3(256), 0, stream, ap);
+            hipLaunchKernelGGL(ddpg_wide_apply_kernel<true>, dim3(apply_blocks), dim3(256), 0, stream, ap);
+        } else {
+            hipLaunchKernelGGL(ddpg_wide_apply_kernel<false>, dim3(apply_blocks), dim3(256), 0, stream, ap);
+        }
     }
     hipLaunchKernelGGL(ddpg_wide_finish_kernel, dim3(1), dim3(1), 0, stream, d->adam_t, n_iters);
     return check_launch("ssc_ddpg_train (wide)");

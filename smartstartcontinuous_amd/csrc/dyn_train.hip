@@ -499,7 +499,40 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 using namespace ssc;
 
+// Dyn_Model.run_validation (dynamics_model.py:173-196): mse_ = reduce_mean(square(z - prediction)) (:42) per batch of
+// `batch_elems` = batchsize * out_dim consecutive elements, then the mean over the batches.  One block per batch, the same
+// summation order every run.
+__global__ __launch_bounds__(256) void mse_batches_kernel(const float *__restrict__ pred, const float *__restrict__ z,
+                                                          int64_t batch_elems, float *__restrict__ batch_loss) {
+    __shared__ float red[4];
+    const float *p = pred + (int64_t)blockIdx.x * batch_elems, *t = z + (int64_t)blockIdx.x * batch_elems;
+    float s = 0.0f;
+    for (int64_t i = threadIdx.x; i < batch_elems; i += 256) { const float e = t[i] - p[i]; s += e * e; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) batch_loss[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)batch_elems;
+}
+
+__global__ void mean_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    float s = 0.0f;
+    for (int64_t i = 0; i < n; ++i) s += x[i];          // avg_loss += loss, in batch order (dynamics_model.py:188)
+    out[0] = s / (float)n;
+}
+
 extern "C" {
+
+int ssc_mse_batches(const float *d_pred, const float *d_z, int64_t n_batches, int64_t batch_elems, float *d_batch_loss,
+                    float *d_mean, ssc_stream_t stream) {
+    SSC_REQUIRE(n_batches >= 1 && n_batches <= 0x7fffffff && batch_elems >= 1, "ssc_mse_batches: n_batches %lld, batch_elems %lld",
+                (long long)n_batches, (long long)batch_elems);
+    SSC_REQUIRE(d_pred && d_z && d_batch_loss && d_mean, "ssc_mse_batches: NULL device pointer");
+    hipLaunchKernelGGL(mse_batches_kernel, dim3((unsigned)n_batches), dim3(256), 0, as_stream(stream), d_pred, d_z, batch_elems, d_batch_loss);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1), 0, as_stream(stream), d_batch_loss, n_batches, d_mean);
+    return check_hip(hipGetLastError(), "ssc_mse_batches");
+}
+
 
 size_t ssc_mlp_train_workspace_bytes(const ssc_mlp_train_desc *net, int32_t B) {
     if (net == nullptr || B <= 0 || net->n_layers < 1 || net->n_layers > SSC_MAX_LAYERS) return 0;

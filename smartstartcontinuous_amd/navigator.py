@@ -183,6 +183,27 @@ class DynamicsModel:
         # the only device -> host read of the whole training: the mean loss of the last epoch
         return float(epoch_losses[-1].mean().item()) if epoch_losses else 0.0
 
+    def run_validation(self, inputs, outputs, batchsize=512, precision="f32"):
+        """``Dyn_Model.run_validation`` (dynamics_model.py:173-196): the mean over the floor(n / batchsize) full batches of the
+        batch MSE between the network's outputs for ``inputs`` and ``outputs`` (both already normalised, like the training
+        sets); the rows behind the last full batch are not looked at.  Fewer rows than one batch divide by zero in the
+        reference (:196) and raise ZeroDivisionError here.  Returns a Python float (the reference returns the numpy scalar)."""
+        def f(a, cols):
+            if torch.is_tensor(a):
+                return a.to(device=self.device, dtype=torch.float32).reshape(-1, cols)
+            return torch.as_tensor(np.asarray(a, np.float32).reshape(-1, cols), device=self.device)
+        X, Z = f(inputs, self.in_dim), f(outputs, self.out_dim)
+        n_batches = X.shape[0] // int(batchsize)
+        if n_batches == 0:
+            raise ZeroDivisionError("run_validation: fewer rows than one batch (dynamics_model.py:196 divides by iters_in_batch = 0)")
+        rows = n_batches * int(batchsize)
+        pred = self.forward(X[:rows], precision=precision)
+        out = torch.empty(n_batches + 1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _ffi.check(self.lib.ssc_mse_batches(_ffi.ptr(pred), _ffi.ptr(Z[:rows].contiguous()), n_batches, int(batchsize) * self.out_dim,
+                                                _ffi.ptr(out), out.data_ptr() + 4 * n_batches, _stream()))
+        return float(out[n_batches].item())
+
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)

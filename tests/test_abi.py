@@ -34,7 +34,7 @@ def test_header_symbols_exported_and_bound(built):
 def test_version_and_defaults(built):
     from smartstartcontinuous_amd import _ffi
     lib = _ffi.lib()
-    assert lib.ssc_version() == 107
+    assert lib.ssc_version() == 108
     p = _ffi.default_params(_ffi.SSC_ENV_MOUNTAINCAR, 0.4, 1000)
     assert abs(p.power - 0.0006) < 1e-9 and p.max_episode_steps == 1000
     assert abs(p.goal_position - 0.45) < 1e-7 and abs(p.min_position + 1.2) < 1e-7

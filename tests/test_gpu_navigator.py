@@ -46,6 +46,29 @@ def test_mlp_forward_f32(nav, dims):
         assert np.max(np.abs(got - ref)) <= 1e-4 * scale, (dims, m)       # 1e-4 rel (fp32)
 
 
+@pytest.mark.parametrize("dims,n,batchsize", [((3, 32, 2), 1300, 512), ((4, 500, 500, 3), 2048, 512), ((3, 500, 2), 700, 100),
+                                               ((12, 64, 48, 40, 8), 515, 512)])
+def test_run_validation_vs_oracle(nav, dims, n, batchsize):
+    """Dyn_Model.run_validation (dynamics_model.py:173-196): the mean of the per-batch MSE over the full batches only, in
+    fp32 and through the MFMA forward where the network has one; fewer rows than one batch is the reference's division by zero."""
+    rng = np.random.default_rng(n + sum(dims))
+    Ws, bs = make_mlp(rng, dims)
+    d = dims[-1]
+    a = max(1, dims[0] - d)
+    model = nav.DynamicsModel(Ws, bs, make_norm(rng, d, a), state_dim=d, act_dim=a)
+    X = rng.normal(size=(n, dims[0])).astype(np.float32)
+    Z = (O.mlp_forward(X, Ws, bs) + rng.normal(size=(n, d)) * 0.3).astype(np.float32)
+    Z[n // batchsize * batchsize:] += 100.0                 # the ragged tail must not count
+    ref = O.dyn_run_validation(X.astype(np.float64), Z.astype(np.float64), Ws, bs, batchsize)
+    got = model.run_validation(X, Z, batchsize=batchsize)
+    assert isinstance(got, float) and abs(got - ref) <= 1e-5 * ref, (got, ref)
+    assert abs(model.run_validation(torch.as_tensor(X, device="cuda"), torch.as_tensor(Z, device="cuda"), batchsize=batchsize) - got) == 0.0
+    if len(dims) <= 4 and dims[0] <= 10:
+        assert abs(model.run_validation(X, Z, batchsize=batchsize, precision="bf16_mfma") - ref) <= 2e-2 * ref
+    with pytest.raises(ZeroDivisionError):
+        model.run_validation(X[:batchsize - 1], Z[:batchsize - 1], batchsize=batchsize)
+
+
 @pytest.mark.parametrize("dims,H", [((3, 32, 2), 4), ((4, 500, 500, 3), 4), ((3, 500, 2), 20)])
 def test_forward_sim_f32(nav, dims, H):
     rng = np.random.default_rng(7 + H)

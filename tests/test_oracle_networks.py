@@ -267,6 +267,52 @@ def test_layer_norm_ddpg_train_step_matches_torch_autograd():
         assert np.allclose(adam2["m_actor"], 0.1 * gflat_a, rtol=1e-9, atol=1e-14)
 
 
+def test_ddpg_l2_regularisation_and_gradient_clipping_match_torch_autograd():
+    """critic_l2_reg (ddpg_editted.py:183-191: scale * l2_loss over the critic's three dense kernels) and clip_norm
+    (:175, :197: tf.clip_by_norm per variable) in oracle.ddpg_train_step against torch autograd, with and without LayerNorm."""
+    rng = np.random.default_rng(5)
+    l2, clip = 0.03, 0.3
+    for ln in (False, True):
+        if ln:
+            aw, cw = ln_params(rng, 2, 16, 12, 1), ln_params(rng, 2, 20, 8, 1, extra=1)
+        else:
+            aw = {k: v.astype(np.float64) for k, v in actor_weights(2, 16, 12, seed=3, w3_scale=0.3).items()}
+            cw = dict(W1=rng.normal(size=(2, 20)) * 0.5, b1=rng.normal(size=20) * 0.1, W2=rng.normal(size=(21, 8)) * 0.4,
+                      b2=rng.normal(size=8) * 0.1, W3=rng.normal(size=(8, 1)) * 0.5, b3=rng.normal(size=1) * 0.1)
+        keys = O.param_keys(aw)
+        B = 32
+        batch = (rng.normal(size=(B, 2)), rng.uniform(-1, 1, (B, 1)), rng.normal(size=B) * 3, rng.random(B) < 0.1, rng.normal(size=(B, 2)))
+        na, nc = O.flatten_params(aw).size, O.flatten_params(cw).size
+        adam = dict(m_actor=np.zeros(na), v_actor=np.zeros(na), t_actor=0, m_critic=np.zeros(nc), v_critic=np.zeros(nc), t_critic=0)
+        a2, c2, _, _, adam2, closs, aloss = O.ddpg_train_step(aw, cw, aw, cw, adam, batch, critic_l2_reg=l2, clip_norm=clip)
+        import torch.nn.functional as F
+        T = lambda d: {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in d.items()}
+        pa, pc = T(aw), T(cw)
+        s, a, r, t, s2 = (torch.tensor(np.asarray(x, np.float64)) for x in batch)
+        lnf = (lambda x, p, w: F.layer_norm(x, (x.shape[-1],), p[w + "_g"], p[w + "_b"], eps=1e-12)) if ln else (lambda x, p, w: x)
+
+        def actor(p, x):
+            h = torch.relu(lnf(x @ p["W1"] + p["b1"], p, "ln1"))
+            return torch.tanh(torch.tanh(lnf(h @ p["W2"] + p["b2"], p, "ln2")) @ p["W3"] + p["b3"])
+
+        def critic(p, x, u):
+            h = torch.cat([torch.relu(lnf(x @ p["W1"] + p["b1"], p, "ln1")), u], dim=1)
+            return torch.tanh(lnf(h @ p["W2"] + p["b2"], p, "ln2")) @ p["W3"] + p["b3"]
+        with torch.no_grad():
+            y = r[:, None] + (1 - t[:, None]) * 0.99 * critic(T(cw), s2, actor(T(aw), s2))
+        closs_t = ((critic(pc, s, a) - y) ** 2).mean() + l2 * sum((pc[k] ** 2).sum() / 2 for k in ("W1", "W2", "W3"))
+        gc = torch.autograd.grad(closs_t, [pc[k] for k in keys])
+        ga = torch.autograd.grad(-critic(pc, s, actor(pa, s)).mean(), [pa[k] for k in keys])
+        assert abs(closs - closs_t.item()) < 1e-12
+        clipv = lambda g: g * (clip / max(float(g.norm()), clip))
+        gflat_c = np.concatenate([clipv(g).numpy().reshape(-1) for g in gc])
+        gflat_a = np.concatenate([clipv(g).numpy().reshape(-1) for g in ga])
+        norms = sorted(float(g.norm()) for g in list(gc) + list(ga))
+        assert norms[0] < clip < norms[-1], norms             # the clip binds for some variables only
+        assert np.allclose(adam2["m_critic"], 0.1 * gflat_c, rtol=1e-9, atol=1e-14)
+        assert np.allclose(adam2["m_actor"], 0.1 * gflat_a, rtol=1e-9, atol=1e-14)
+
+
 def test_mlp_train_step_matches_torch_autograd_and_adam():
     """oracle.mlp_train_step (manual backprop + tf-style Adam) against torch autograd + torch.optim.Adam
     (same update rule as tf.train.AdamOptimizer up to where epsilon enters -- compared after ONE step where
