@@ -39,8 +39,21 @@ bool ddpg_fixed_shape(const ssc_ddpg_desc *d);
 int ddpg_train_fixed(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
                      float *d_losses, hipStream_t stream);
 
+// the shipped shape at batches of 128, 192, ... (multiples of 64): the straight-line kernel on one 64-row tile per workgroup
+// (gradients only), then the multi-workgroup apply pass of ddpg_train_wide.hip
+bool ddpg_fixed_tiled_shape(const ssc_ddpg_desc *d);
+int ddpg_train_fixed_tiled(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
+                           float *d_losses, void *d_workspace, size_t workspace_bytes, hipStream_t stream);
+
 // ddpg_train_wide.hip: any layer sizes / batch sizes, batch tiled over workgroups
 size_t ddpg_wide_workspace_bytes(const ssc_ddpg_desc *d);
+// The apply pass over `n_blocks` gradient partials laid out [n_blocks][n_params] at the start of the workspace, loss
+// partials [n_blocks][2] behind them (ddpg_wide_partials); iteration `it` of the call; `ddpg_wide_finish` moves the
+// MpiAdam step counters once, after the last iteration.
+struct WidePartials { float *gpart, *lpart; };
+WidePartials ddpg_wide_partials(const ssc_ddpg_desc *d, void *d_workspace, int n_blocks);
+void ddpg_wide_apply(const ssc_ddpg_desc *d, void *d_workspace, int n_blocks, int it, float *d_losses_it, hipStream_t stream);
+void ddpg_wide_finish(const ssc_ddpg_desc *d, int32_t n_iters, hipStream_t stream);
 int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
                     float *d_losses, void *d_workspace, size_t workspace_bytes, hipStream_t stream);
 

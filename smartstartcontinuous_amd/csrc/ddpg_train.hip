@@ -697,6 +697,9 @@ static int ddpg_train_any(const char *who, const ssc_ddpg_desc *d, const ssc_rep
                 "%s: NULL parameter / optimiser pointer", who);
     SSC_REQUIRE(rp->s && rp->a && rp->r && rp->t && rp->s2 && rp->capacity > 0 && d_batch_idx,
                 "%s: NULL replay pointer", who);
+    // the shipped 64-32 networks at a batch of several 64-row tiles: the straight-line kernel per tile, then the apply pass
+    if (have_ws && !want_wide && !want_interp && ddpg_fixed_tiled_shape(d))
+        return ddpg_train_fixed_tiled(d, rp, d_batch_idx, n_iters, d_losses, d_ws, ws_bytes, as_stream(stream));
     if (!narrow || want_wide) return ddpg_train_wide(d, rp, d_batch_idx, n_iters, d_losses, d_ws, ws_bytes, as_stream(stream));
     if (ddpg_fixed_shape(d) && !want_interp) return ddpg_train_fixed(d, rp, d_batch_idx, n_iters, d_losses, as_stream(stream));
 

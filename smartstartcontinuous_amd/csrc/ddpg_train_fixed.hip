@@ -81,6 +81,10 @@ struct FixedArgs {
     const int32_t *batch_idx;
     float *losses;
     int32_t n_iters;
+    // TILED (a batch of several 64-row tiles, one workgroup each, ONE iteration per launch; ddpg_train_fixed_tiled):
+    float inv_b;        // 1 / batch_size
+    float *gpart;       // [tiles][actor gsize + critic gsize]: this tile's share of every gradient
+    float *lpart;       // [tiles][2]: its sums of (Q - y)^2 and -Q(s, pi(s))
 };
 
 // Diagnostic build (-DSSC_DDPG_DIAG, tools/exp_ddpg_phases.py): d_losses is [n_iters][16] and receives the cycles
@@ -236,7 +240,9 @@ __device__ __forceinline__ float small_grad(const float *lds, const SmallElem &e
     return (g4[0] + g4[1]) + (g4[2] + g4[3]);
 }
 
-template <int O, bool TANH2>
+// TILED: the same ten levels on rows [64 blockIdx.x, + 64) of a larger batch, up to the gradients -- which go to the tile's
+// slice of `gpart` instead of into MpiAdam (ddpg_wide_apply_kernel sums the slices in tile order and updates).
+template <int O, bool TANH2, bool TILED>
 __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
     using NA = Net<O, H1>;
     using NC = Net<O, H1 + 1>;
@@ -259,13 +265,17 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
     // ---- owners of the Adam moments ------------------------------------------------------------------------------
     // wide tiles (W2 rows 0..63 of both nets): wave -> (ib = wave >> 1, jb = wave & 1), lane -> 4 elements
     const int w_ib = wave >> 1, w_jb = wave & 1;
-    float mW2c[4], vW2c[4], mW2a[4], vW2a[4];
+    float mW2c[4] = {}, vW2c[4] = {}, mW2a[4] = {}, vW2a[4] = {};
+    if constexpr (!TILED) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int k = (16 * w_ib + 4 * kg + r) * H2 + 16 * w_jb + c;
-        mW2c[r] = d.adam_m_critic[NC::gW2 + k]; vW2c[r] = d.adam_v_critic[NC::gW2 + k];
-        mW2a[r] = d.adam_m_actor[NA::gW2 + k];  vW2a[r] = d.adam_v_actor[NA::gW2 + k];
+        for (int r = 0; r < 4; ++r) {
+            const int k = (16 * w_ib + 4 * kg + r) * H2 + 16 * w_jb + c;
+            mW2c[r] = d.adam_m_critic[NC::gW2 + k]; vW2c[r] = d.adam_v_critic[NC::gW2 + k];
+            mW2a[r] = d.adam_m_actor[NA::gW2 + k];  vW2a[r] = d.adam_v_actor[NA::gW2 + k];
+        }
     }
+    float *const gout = TILED ? g.gpart + (int64_t)blockIdx.x * (NA::gsize + NC::gsize) : nullptr;
+    const float inv_b = TILED ? g.inv_b : 1.0f / (float)kB;
     // small elements: lane tid owns critic element tid and actor element tid of the lists below
     SmallElem ec, ea;
     {
@@ -291,10 +301,10 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
     }
     static_assert(O * H1 + H1 + 3 * H2 + 1 <= kT, "one small critic element per lane");
     float mc = 0.0f, vc = 0.0f, ma = 0.0f, va = 0.0f;
-    if (ec.on) { mc = d.adam_m_critic[ec.gidx]; vc = d.adam_v_critic[ec.gidx]; }
-    if (ea.on) { ma = d.adam_m_actor[ea.gidx]; va = d.adam_v_actor[ea.gidx]; }
+    if (!TILED && ec.on) { mc = d.adam_m_critic[ec.gidx]; vc = d.adam_v_critic[ec.gidx]; }
+    if (!TILED && ea.on) { ma = d.adam_m_actor[ea.gidx]; va = d.adam_v_actor[ea.gidx]; }
 
-    int tA = d.adam_t[0], tC = d.adam_t[1];
+    int tA = TILED ? 0 : d.adam_t[0], tC = TILED ? 0 : d.adam_t[1];
     // running beta powers for MpiAdam's bias correction, in f64 (1 - 0.999^t loses 5 digits in fp32)
     double b1a = ipow((double)d.beta1, tA), b2a = ipow((double)d.beta2, tA);
     double b1c = ipow((double)d.beta1, tC), b2c = ipow((double)d.beta2, tC);
@@ -309,10 +319,13 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
         pf_r = g.rp.r[rec];
         pf_t = g.rp.t[rec] ? 1.0f : 0.0f;
     };
-    auto idx_of = [&](int it_) { return (int64_t)g.batch_idx[(int64_t)(it_ < g.n_iters ? it_ : g.n_iters - 1) * kB + tid]; };
+    auto idx_of = [&](int it_) {
+        if constexpr (TILED) return (int64_t)g.batch_idx[(int64_t)blockIdx.x * kB + tid];
+        else return (int64_t)g.batch_idx[(int64_t)(it_ < g.n_iters ? it_ : g.n_iters - 1) * kB + tid];
+    };
     if (tid < kB) {
         fetch_rows(idx_of(0));
-        rec_next = idx_of(1);
+        if constexpr (!TILED) rec_next = idx_of(1);
     }
     __syncthreads();   // parameter images complete
 
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
         // ---- L0: ReplayBuffer.sample_batch rows; MpiAdam step sizes --------------------------------------------------
         ++tA; ++tC;
         b1a *= (double)d.beta1; b2a *= (double)d.beta2; b1c *= (double)d.beta1; b2c *= (double)d.beta2;
-        if (tid == kB) {
+        if (!TILED && tid == kB) {
             cfg_s[0] = AdamCfg{(float)((double)d.actor_lr * sqrt(1.0 - b2a) / (1.0 - b1a)), d.beta1, d.beta2, d.epsilon};
             cfg_s[1] = AdamCfg{(float)((double)d.critic_lr * sqrt(1.0 - b2c) / (1.0 - b1c)), d.beta1, d.beta2, d.epsilon};
         }
@@ -337,8 +350,10 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
             row(R::X2 + H1)[tid] = pf_a;
             r_cur = pf_r;
             t_cur = pf_t;
-            fetch_rows(rec_next);        // rows of iteration it + 1: in flight until the next L0
-            rec_next = idx_of(it + 2);
+            if constexpr (!TILED) {
+                fetch_rows(rec_next);        // rows of iteration it + 1: in flight until the next L0
+                rec_next = idx_of(it + 2);
+            }
         }
         lds_barrier();
         LEVEL_MARK(0);
@@ -416,14 +431,14 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
             const float qt = dot32(th_tc + NC::W3, th_tc + NC::b3, row(R::TB2), b);
             const float y = r_cur + (1.0f - t_cur) * d.gamma * qt;
             const float e = row(R::Q)[b] - y;
-            row(R::DQ)[b] = 2.0f * e / (float)kB;
+            row(R::DQ)[b] = 2.0f * e * inv_b;
             row(R::LC)[b] = e * e;
         } else if (wave == 1) {   // actor loss = -mean Q(s, pi(s))  (:168)
             row(R::LA)[b] = -dot32(th_c + NC::W3, th_c + NC::b3, row(R::CB2), b);
         } else {                  // (s, pi) path: dq = -1/B, delta of critic layer 2 = W3 dq act2'(.)
             for (int e = tid - 2 * 64; e < H2 * kB; e += kT - 2 * 64) {
                 const int o = (e >> 6) * kP + (e & 63);
-                row(R::DZB2)[o] = th_c[NC::W3 + (e >> 6)] * (-1.0f / (float)kB) * act2_deriv<TANH2>(row(R::CB2)[o]);
+                row(R::DZB2)[o] = th_c[NC::W3 + (e >> 6)] * (-inv_b) * act2_deriv<TANH2>(row(R::CB2)[o]);
             }
         }
         lds_barrier();
@@ -466,15 +481,21 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
         bwd_item(th_a + NA::W2, row(R::DZ2A), row(R::U1), row(R::DZ1A), wave >> 1, wave & 1, c, kg);
         LEVEL_MARK(10);
         {
-            const AdamCfg cc = cfg_s[1];
             const f32x4m gw = wgrad_tile(row(R::X2), row(R::DZ2), w_ib, w_jb, c, kg);
             LEVEL_MARK(11);
-            adam_tile(th_c, th_tc, NC::W2 + (16 * w_ib + 4 * kg) * W2S + 16 * w_jb + c, gw, mW2c, vW2c, cc, d.tau);
-            LEVEL_MARK(12);
-            if (ec.on) {
-                float th = th_c[ec.lidx], tg = th_tc[ec.lidx];
-                adam_target(th, tg, mc, vc, small_grad(lds, ec), cc, d.tau);
-                th_c[ec.lidx] = th; th_tc[ec.lidx] = tg;
+            if constexpr (TILED) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gout[NA::gsize + NC::gW2 + (16 * w_ib + 4 * kg + r) * H2 + 16 * w_jb + c] = gw[r];
+                if (ec.on) gout[NA::gsize + ec.gidx] = small_grad(lds, ec);
+            } else {
+                const AdamCfg cc = cfg_s[1];
+                adam_tile(th_c, th_tc, NC::W2 + (16 * w_ib + 4 * kg) * W2S + 16 * w_jb + c, gw, mW2c, vW2c, cc, d.tau);
+                LEVEL_MARK(12);
+                if (ec.on) {
+                    float th = th_c[ec.lidx], tg = th_tc[ec.lidx];
+                    adam_target(th, tg, mc, vc, small_grad(lds, ec), cc, d.tau);
+                    th_c[ec.lidx] = th; th_tc[ec.lidx] = tg;
+                }
             }
         }
         LEVEL_MARK(13);
@@ -483,17 +504,25 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
 
         // ---- L9: actor gradients -> MpiAdam -> target actor; losses ------------------------------------------------------
         {
-            const AdamCfg ca = cfg_s[0];
             const f32x4m gw = wgrad_tile(row(R::U1), row(R::DZ2A), w_ib, w_jb, c, kg);
-            adam_tile(th_a, th_ta, NA::W2 + (16 * w_ib + 4 * kg) * W2S + 16 * w_jb + c, gw, mW2a, vW2a, ca, d.tau);
-            if (ea.on) {
-                float th = th_a[ea.lidx], tg = th_ta[ea.lidx];
-                adam_target(th, tg, ma, va, small_grad(lds, ea), ca, d.tau);
-                th_a[ea.lidx] = th; th_ta[ea.lidx] = tg;
+            if constexpr (TILED) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gout[NA::gW2 + (16 * w_ib + 4 * kg + r) * H2 + 16 * w_jb + c] = gw[r];
+                if (ea.on) gout[ea.gidx] = small_grad(lds, ea);
+            } else {
+                const AdamCfg ca = cfg_s[0];
+                adam_tile(th_a, th_ta, NA::W2 + (16 * w_ib + 4 * kg) * W2S + 16 * w_jb + c, gw, mW2a, vW2a, ca, d.tau);
+                if (ea.on) {
+                    float th = th_a[ea.lidx], tg = th_ta[ea.lidx];
+                    adam_target(th, tg, ma, va, small_grad(lds, ea), ca, d.tau);
+                    th_a[ea.lidx] = th; th_ta[ea.lidx] = tg;
+                }
             }
         }
 #ifndef SSC_DDPG_DIAG
-        if (tid == 0 && g.losses != nullptr) {
+        if constexpr (TILED) {
+            if (tid == 0) { g.lpart[2 * blockIdx.x + 0] = red[0]; g.lpart[2 * blockIdx.x + 1] = red[1]; }
+        } else if (tid == 0 && g.losses != nullptr) {
             g.losses[2 * it + 0] = red[0] / (float)kB;
             g.losses[2 * it + 1] = red[1] / (float)kB;
         }
@@ -502,6 +531,7 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
         LEVEL_MARK(9);
     }
 
+    if constexpr (TILED) return;
     // the forward kernels outside (ssc_actor_forward, ssc_critic_forward, rollouts) read the global arrays
     for (int e = tid; e < NA::gsize; e += kT) { const int l = NA::to_lds(e); d.actor[e] = th_a[l]; d.target_actor[e] = th_ta[l]; }
     for (int e = tid; e < NC::gsize; e += kT) { const int l = NC::to_lds(e); d.critic[e] = th_c[l]; d.target_critic[e] = th_tc[l]; }
@@ -516,16 +546,16 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
     if (tid == 0) { d.adam_t[0] = tA; d.adam_t[1] = tC; }
 }
 
-template <int O, bool TANH2>
-int launch_fixed(const FixedArgs &g, hipStream_t stream) {
+template <int O, bool TANH2, bool TILED = false>
+int launch_fixed(const FixedArgs &g, hipStream_t stream, unsigned tiles = 1) {
     const size_t lds = ((size_t)Rows<O>::total * kP + 2 * (Net<O, H1>::size + Net<O, H1 + 1>::size)) * sizeof(float);
     static_assert(((size_t)Rows<O>::total * kP + 2 * (Net<O, H1>::size + Net<O, H1 + 1>::size)) * sizeof(float) <= 160 * 1024 - 256,
                   "activation rows + parameter images must fit the LDS");
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(ddpg_train_fixed_kernel<O, TANH2>),
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(ddpg_train_fixed_kernel<O, TANH2, TILED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                        "hipFuncSetAttribute(ddpg_train_fixed_kernel)");
     if (rc) return rc;
-    hipLaunchKernelGGL((ddpg_train_fixed_kernel<O, TANH2>), dim3(1), dim3(kT), lds, stream, g);
+    hipLaunchKernelGGL((ddpg_train_fixed_kernel<O, TANH2, TILED>), dim3(tiles), dim3(kT), lds, stream, g);
     return check_launch("ssc_ddpg_train");
 }
 
@@ -536,10 +566,42 @@ bool ddpg_fixed_shape(const ssc_ddpg_desc *d) {
            d->critic_h1 == H1 && d->critic_h2 == H2;
 }
 
+static bool fixed_nets(const ssc_ddpg_desc *d) {
+    return (d->obs_dim == 2 || d->obs_dim == 3) && d->act_dim == 1 && d->actor_h1 == H1 && d->actor_h2 == H2 && d->critic_h1 == H1 &&
+           d->critic_h2 == H2 && !d->layer_norm;
+}
+
+bool ddpg_fixed_tiled_shape(const ssc_ddpg_desc *d) {
+    return fixed_nets(d) && d->batch_size > kB && d->batch_size % kB == 0 && d->batch_size <= 4096;
+}
+
+// arguments already validated by ssc_ddpg_train_ws; the workspace is sized by ddpg_wide_workspace_bytes (16-row partials:
+// four times what the 64-row tiles write)
+int ddpg_train_fixed_tiled(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
+                           float *d_losses, void *d_workspace, size_t workspace_bytes, hipStream_t stream) {
+    const size_t need = ddpg_wide_workspace_bytes(d);
+    SSC_REQUIRE(d_workspace != nullptr && workspace_bytes >= need,
+                "ssc_ddpg_train_ws: workspace %zu < %zu bytes (ssc_ddpg_train_workspace_bytes)", workspace_bytes, need);
+    const int tiles = d->batch_size / kB;
+    const WidePartials wp = ddpg_wide_partials(d, d_workspace, tiles);
+    FixedArgs g{*d, *rp, d_batch_idx, nullptr, 1, 1.0f / (float)d->batch_size, wp.gpart, wp.lpart};
+    const bool t2 = d->last_layer_tanh != 0;
+    for (int it = 0; it < n_iters; ++it) {
+        g.batch_idx = d_batch_idx + (int64_t)it * d->batch_size;
+        int rc;
+        if (d->obs_dim == 2) rc = t2 ? launch_fixed<2, true, true>(g, stream, tiles) : launch_fixed<2, false, true>(g, stream, tiles);
+        else rc = t2 ? launch_fixed<3, true, true>(g, stream, tiles) : launch_fixed<3, false, true>(g, stream, tiles);
+        if (rc) return rc;
+        ddpg_wide_apply(d, d_workspace, tiles, it, d_losses ? d_losses + 2 * it : nullptr, stream);
+    }
+    ddpg_wide_finish(d, n_iters, stream);
+    return check_launch("ssc_ddpg_train_ws");
+}
+
 // arguments already validated by ssc_ddpg_train
 int ddpg_train_fixed(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
                      float *d_losses, hipStream_t stream) {
-    FixedArgs g{*d, *rp, d_batch_idx, d_losses, n_iters};
+    FixedArgs g{*d, *rp, d_batch_idx, d_losses, n_iters, 1.0f / (float)kB, nullptr, nullptr};
     const bool t2 = d->last_layer_tanh != 0;
     if (d->obs_dim == 2) return t2 ? launch_fixed<2, true>(g, stream) : launch_fixed<2, false>(g, stream);
     return t2 ? launch_fixed<3, true>(g, stream) : launch_fixed<3, false>(g, stream);

@@ -684,17 +684,63 @@ static int wide_params(const ssc_ddpg_desc *d) {
 }
 
 static bool wide_prepared(const ssc_ddpg_desc *d) { return d->critic_l2_reg != 0.0f || d->clip_norm > 0.0f; }
-static size_t wide_gpart_bytes(const ssc_ddpg_desc *d) { return ((size_t)wide_blocks(d) * (size_t)wide_params(d) * sizeof(float) + 255) & ~(size_t)255; }
-static size_t wide_lpart_bytes(const ssc_ddpg_desc *d) { return (((size_t)wide_blocks(d) * 2 * sizeof(float) + 255) & ~(size_t)255) + 1024; }
+static size_t wide_gpart_bytes(const ssc_ddpg_desc *d, int nb) { return ((size_t)nb * (size_t)wide_params(d) * sizeof(float) + 255) & ~(size_t)255; }
+static size_t wide_lpart_bytes(int nb) { return (((size_t)nb * 2 * sizeof(float) + 255) & ~(size_t)255) + 1024; }
 
-// [gpart | lpart (+ 1 KB the diagnostic build stamps into)] and, with critic_l2_reg / clip_norm, [gsum | regpart]
+// [gpart | lpart (+ 1 KB the diagnostic build stamps into)] and, with critic_l2_reg / clip_norm, [gsum | regpart]; sized
+// for 16-row workgroups (the 64-row tiles of ddpg_train_fixed_tiled lay out fewer partials in the same workspace)
 size_t ddpg_wide_workspace_bytes(const ssc_ddpg_desc *d) {
-    size_t bytes = wide_gpart_bytes(d) + wide_lpart_bytes(d);
+    size_t bytes = wide_gpart_bytes(d, wide_blocks(d)) + wide_lpart_bytes(wide_blocks(d));
     if (wide_prepared(d)) {
         const size_t n = (size_t)wide_params(d);
         bytes += ((n * sizeof(float) + 255) & ~(size_t)255) + (((n + 255) / 256 * sizeof(float) + 255) & ~(size_t)255);
     }
     return bytes;
+}
+
+WidePartials ddpg_wide_partials(const ssc_ddpg_desc *d, void *d_workspace, int n_blocks) {
+    return WidePartials{static_cast<float *>(d_workspace),
+                        reinterpret_cast<float *>(static_cast<char *>(d_workspace) + wide_gpart_bytes(d, n_blocks))};
+}
+
+void ddpg_wide_apply(const ssc_ddpg_desc *d, void *d_workspace, int n_blocks, int it, float *d_losses_it, hipStream_t stream) {
+    const int ln = d->layer_norm ? 1 : 0;
+    const WNet A{d->obs_dim, d->actor_h1, d->actor_h2, d->act_dim, 0, ln}, C{d->obs_dim, d->critic_h1, d->critic_h2, 1, d->act_dim, ln};
+    const int nA = A.total(), nC = C.total();
+    const WidePartials wp = ddpg_wide_partials(d, d_workspace, n_blocks);
+    ApplyArgs ap{};
+    ap.d = *d; ap.gpart = wp.gpart; ap.lpart = wp.lpart; ap.n_blocks = n_blocks; ap.nA = nA; ap.nC = nC;
+    ap.it = it; ap.losses = d_losses_it;
+    const unsigned apply_blocks = (unsigned)((nA + nC + 255) / 256);
+    if (!wide_prepared(d)) {
+        hipLaunchKernelGGL(ddpg_wide_apply_kernel<false>, dim3(apply_blocks), dim3(256), 0, stream, ap);
+        return;
+    }
+    char *tail = static_cast<char *>(d_workspace) + wide_gpart_bytes(d, n_blocks) + wide_lpart_bytes(n_blocks);
+    ap.gsum = reinterpret_cast<float *>(tail);
+    ap.regpart = reinterpret_cast<float *>(tail + (((size_t)(nA + nC) * sizeof(float) + 255) & ~(size_t)255));
+    // the name filter of ddpg_editted.py:184 ('kernel' in name, 'output' not in name) keeps all three dense kernels of
+    // models_editted.py's critic (none of its layers is named 'output'); biases and LayerNorm parameters stay out
+    const int lo[3] = {nA + C.oW1(), nA + C.oW2(), nA + C.oW3()}, hi[3] = {nA + C.ob1(), nA + C.ob2(), nA + C.ob3()};
+    for (int k = 0; k < 3; ++k) { ap.reg_lo[k] = lo[k]; ap.reg_hi[k] = hi[k]; }
+    int nv = 0;
+    for (int n = 0; n < 2; ++n) {
+        const WNet &N = n == 0 ? A : C;
+        const int base = n == 0 ? 0 : nA;
+        ap.var_lo[nv++] = base + N.oW1(); ap.var_lo[nv++] = base + N.ob1();
+        if (ln) { ap.var_lo[nv++] = base + N.obe1(); ap.var_lo[nv++] = base + N.og1(); }
+        ap.var_lo[nv++] = base + N.oW2(); ap.var_lo[nv++] = base + N.ob2();
+        if (ln) { ap.var_lo[nv++] = base + N.obe2(); ap.var_lo[nv++] = base + N.og2(); }
+        ap.var_lo[nv++] = base + N.oW3(); ap.var_lo[nv++] = base + N.ob3();
+    }
+    ap.n_var = nv;
+    ap.var_lo[nv] = nA + nC;
+    hipLaunchKernelGGL(ddpg_wide_prepare_kernel, dim3(apply_blocks), dim3(256), 0, stream, ap);
+    hipLaunchKernelGGL(ddpg_wide_apply_kernel<true>, dim3(apply_blocks), dim3(256), 0, stream, ap);
+}
+
+void ddpg_wide_finish(const ssc_ddpg_desc *d, int32_t n_iters, hipStream_t stream) {
+    hipLaunchKernelGGL(ddpg_wide_finish_kernel, dim3(1), dim3(1), 0, stream, d->adam_t, n_iters);
 }
 
 int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int32_t *d_batch_idx, int32_t n_iters,
@@ -864,51 +910,19 @@ int ddpg_train_wide(const ssc_ddpg_desc *d, const ssc_replay_view *rp, const int
     g.n_params = nA + nC;
     const int nb = wide_blocks(d);
     g.gpart = static_cast<float *>(d_workspace);
-    g.lpart = reinterpret_cast<float *>(static_cast<char *>(d_workspace) + wide_gpart_bytes(d));
+    g.lpart = ddpg_wide_partials(d, d_workspace, nb).lpart;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(ddpg_wide_grad_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "hipFuncSetAttribute(ddpg_wide_grad_kernel)");
         if (rc) return rc;
     }
-    ApplyArgs ap{};
-    ap.d = *d; ap.gpart = g.gpart; ap.lpart = g.lpart; ap.n_blocks = nb; ap.nA = nA; ap.nC = nC;
-    const unsigned apply_blocks = (unsigned)((nA + nC + 255) / 256);
-    const bool prepared = wide_prepared(d);
-    if (prepared) {
-        char *tail = static_cast<char *>(d_workspace) + wide_gpart_bytes(d) + wide_lpart_bytes(d);
-        ap.gsum = reinterpret_cast<float *>(tail);
-        ap.regpart = reinterpret_cast<float *>(tail + (((size_t)(nA + nC) * sizeof(float) + 255) & ~(size_t)255));
-        // the name filter of ddpg_editted.py:184 ('kernel' in name, 'output' not in name) keeps all three dense kernels of
-        // models_editted.py's critic (none of its layers is named 'output'); biases and LayerNorm parameters stay out
-        const int lo[3] = {nA + C.oW1(), nA + C.oW2(), nA + C.oW3()}, hi[3] = {nA + C.ob1(), nA + C.ob2(), nA + C.ob3()};
-        for (int k = 0; k < 3; ++k) { ap.reg_lo[k] = lo[k]; ap.reg_hi[k] = hi[k]; }
-        int nv = 0;
-        for (int n = 0; n < 2; ++n) {
-            const WNet &N = n == 0 ? A : C;
-            const int base = n == 0 ? 0 : nA;
-            ap.var_lo[nv++] = base + N.oW1(); ap.var_lo[nv++] = base + N.ob1();
-            if (ln) { ap.var_lo[nv++] = base + N.obe1(); ap.var_lo[nv++] = base + N.og1(); }
-            ap.var_lo[nv++] = base + N.oW2(); ap.var_lo[nv++] = base + N.ob2();
-            if (ln) { ap.var_lo[nv++] = base + N.obe2(); ap.var_lo[nv++] = base + N.og2(); }
-            ap.var_lo[nv++] = base + N.oW3(); ap.var_lo[nv++] = base + N.ob3();
-        }
-        ap.n_var = nv;
-        ap.var_lo[nv] = nA + nC;
-    }
     for (int it = 0; it < n_iters; ++it) {
         g.batch_idx = d_batch_idx + (int64_t)it * d->batch_size;
         hipLaunchKernelGGL(ddpg_wide_grad_kernel, dim3(nb), dim3(kWThreads), lds, stream, g);
-        ap.it = it;
-        ap.losses = d_losses ? d_losses + 2 * it : nullptr;
-        if (prepared) {
-            hipLaunchKernelGGL(ddpg_wide_prepare_kernel, dim3(apply_blocks), dim3(256), 0, stream, ap);
-            hipLaunchKernelGGL(ddpg_wide_apply_kernel<true>, dim3(apply_blocks), dim3(256), 0, stream, ap);
-        } else {
-            hipLaunchKernelGGL(ddpg_wide_apply_kernel<false>, dim3(apply_blocks), dim3(256), 0, stream, ap);
-        }
+        ddpg_wide_apply(d, d_workspace, nb, it, d_losses ? d_losses + 2 * it : nullptr, stream);
     }
-    hipLaunchKernelGGL(ddpg_wide_finish_kernel, dim3(1), dim3(1), 0, stream, d->adam_t, n_iters);
+    ddpg_wide_finish(d, n_iters, stream);
     return check_launch("ssc_ddpg_train (wide)");
 }
 

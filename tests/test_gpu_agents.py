@@ -526,6 +526,22 @@ def test_ddpg_train_l2_regularisation_and_gradient_clipping(ssc, obs_dim, h1, h2
                            critic_l2_reg=l2, clip_norm=clip)
 
 
+@pytest.mark.parametrize("obs_dim,B,l2,clip", [(2, 128, 0.0, None), (2, 1024, 0.0, None), (3, 192, 0.0, None), (3, 1024, 0.0, None),
+                                               (2, 256, 1e-2, 0.05), (3, 4096, 0.0, None)])
+def test_ddpg_train_shipped_networks_on_batches_of_64_row_tiles(ssc, obs_dim, B, l2, clip, monkeypatch):
+    """The 64-32 networks at a batch that is a multiple of 64 (the vectorised actor-learner loop trains on 1024): the
+    straight-line kernel of the shipped shape runs one 64-row tile per workgroup up to the gradients
+    (ddpg_train_fixed_kernel<.., TILED>) and the multi-workgroup apply pass sums the tiles -- same oracle, same tolerance;
+    SSC_DDPG_WIDE=1 keeps the 16-row-tile kernel reachable for the same shape (the two agree to rounding)."""
+    monkeypatch.delenv("SSC_DDPG_WIDE", raising=False)
+    monkeypatch.delenv("SSC_DDPG_INTERPRETER", raising=False)
+    llts = (True, False) if B <= 256 else (True,)
+    _ddpg_kernel_vs_oracle(ssc, obs_dim, 64, 32, B=B, llts=llts, cap=5000, critic_l2_reg=l2, clip_norm=clip)
+    if B == 1024:
+        monkeypatch.setenv("SSC_DDPG_WIDE", "1")
+        _ddpg_kernel_vs_oracle(ssc, obs_dim, 64, 32, B=B, llts=(True,), cap=5000)
+
+
 def test_ddpg_train_wide_on_the_shipped_shape_and_mixed_sizes(ssc, monkeypatch):
     """SSC_DDPG_WIDE=1 sends the shipped 64-32 / batch-64 shape through the multi-workgroup kernels as well (same
     oracle, same tolerance); actor and critic of different sizes; and the workspace-less entry point says which call
