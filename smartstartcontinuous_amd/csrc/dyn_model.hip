@@ -240,6 +240,168 @@ __global__ __launch_bounds__(256) void dyn_small_sim_kernel(SmallSimArgs g) {
         if (k < g.d) g.S[((int64_t)g.H * g.m + row) * g.d + k] = st[k];              // :240
 }
 
+// The same simulation for the shapes the shipped navigators have (state 2 or 3, ONE action, every byte offset below 2^31),
+// compiled per shape and TWO ROWS PER LANE: the fp32 FMAs of a row pair are v_pk_fma_f32 (both halves against the same
+// weight), so a hidden unit costs D + 1 packed FMAs in, two v_max, D packed FMAs out for two rows -- 7 instructions at
+// D = 2 where the general kernel above issues 16.  SW: the weights are SGPR operands of those FMAs, fetched by scalar
+// loads straight from W1 / b1 / W2 (four units a round; the loads of a wave hide under the FMAs of the others) -- with
+// the LDS image of the general kernel the pair kernel spent 44 % of its wave cycles waiting on broadcast reads.
+// The general kernel also spent ~45 % of its issue slots outside the network (64-bit divisions by runtime N, the generic
+// d / a selects, a branch around every store); here the row -> (problem, sample) split is one 32-bit division per PAIR,
+// the z-score's NaN / Inf mapping is two selects, and stores of switched-off rows are dropped by the buffer descriptor.
+// Same arithmetic per row (k-ordered FMA chains, z-score by division), so both kernels give the same bits.
+// normalise_one without branches: NaN -> 0, +-Inf -> +-FLT_MAX (v_med3_f32 clamps, a NaN is replaced first)
+__device__ __forceinline__ float normalise_sel(float x, float mean, float stdv) {
+    const float v = (x - mean) / stdv;
+    return v != v ? 0.0f : __builtin_amdgcn_fmed3f(v, -FLT_MAX, FLT_MAX);
+}
+
+template <int D, bool SAMPLE, bool SW>
+__global__ __launch_bounds__(256) void dyn_small_sim_pair_kernel(SmallSimArgs g) {
+    __shared__ __attribute__((aligned(16))) float rec[kSmallMaxDepth][8];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u2v __attribute__((__vector_size__(2 * sizeof(unsigned int))));
+    typedef const __attribute__((address_space(4))) float *cfloat;      // uniform reads of the weights: scalar loads
+    constexpr int IN = D + 1;
+    const uint32_t N = (uint32_t)g.N, m = (uint32_t)g.m;
+    uint32_t total = m;
+    if (g.live_list != nullptr) {
+        total = (uint32_t)*g.n_live * N;
+        if (blockIdx.x * 512u >= total) return;          // block-uniform, in front of the barrier
+    }
+    if (!SW) {
+        for (int e = threadIdx.x; e < g.depth * 8; e += 256) {
+            const int j = e >> 3, q = e & 7;
+            float v = 0.0f;
+            if (q < 4) v = (q < IN) ? g.W1[q * g.depth + j] : 0.0f;
+            else if (q == 4) v = g.b1[j];
+            else v = (q - 5 < D) ? g.W2[j * D + (q - 5)] : 0.0f;
+            rec[j][q] = v;
+        }
+        __syncthreads();
+    }
+    const uint32_t pos = (blockIdx.x * 256u + threadIdx.x) * 2u;
+    if (pos >= total) return;                             // (no barrier below)
+    const bool two = pos + 1 < total;
+    // position -> (problem slot, sample); the pair's second row is the next sample or the first one of the next slot
+    uint32_t q0 = 0, n0 = pos, q1 = 0, n1 = pos + 1;
+    if (SAMPLE) {
+        q0 = pos / N; n0 = pos - q0 * N;
+        q1 = q0; n1 = n0 + 1;
+        if (n1 == N) { q1 = q0 + 1; n1 = 0; }
+    }
+    if (!two) { q1 = q0; n1 = n0; }
+    uint32_t p0 = q0, p1 = q1;
+    if (g.live_list != nullptr) { p0 = (uint32_t)g.live_list[q0]; p1 = (uint32_t)g.live_list[q1]; }
+    const uint32_t r0 = SAMPLE ? p0 * N + n0 : n0, r1 = SAMPLE ? p1 * N + n1 : n1;
+    bool on0 = true, on1 = two;
+    if (SAMPLE && g.active != nullptr) { on0 = g.active[p0] != 0; on1 = on1 && g.active[p1] != 0; }
+    if (!on0 && !on1) return;
+    const uint32_t rps = (uint32_t)g.rows_per_state;
+    const uint32_t i0 = (SAMPLE && rps == N) ? p0 : r0 / rps, i1 = (SAMPLE && rps == N) ? p1 : r1 / rps;
+    f2 st[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) st[k] = f2{g.s0[i0 * D + k], g.s0[i1 * D + k]};
+    // candidate actions: Philox words of (problem, sample), four (t, action) slots per call (ssc_mpc_sample_actions)
+    const uint32_t c1_0 = (uint32_t)(g.pid0 + p0), c1_1 = (uint32_t)(g.pid0 + p1);
+    const uint64_t tt = SAMPLE ? (g.t + (g.t_base != nullptr ? *g.t_base : 0)) * (uint64_t)((g.H + 3) / 4) : 0;
+    u32x4 wa = u32x4{0, 0, 0, 0}, wb = wa;
+    // The stores go through buffer descriptors: a row that is switched off (its problem inactive, or the odd row past the
+    // end) gets an offset past the descriptor's range and the hardware drops the store -- no branch around any of them.
+    const uint32_t s_bytes = (uint32_t)((size_t)(g.H + 1) * m * D * sizeof(float));
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(g.S, 0, (int)s_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(g.A_out, 0, g.A_out != nullptr ? (int)((size_t)m * g.H * sizeof(float)) : 0, 0x00020000);
+    constexpr uint32_t kOff = 0x80000000u;               // past any range the launcher admits (< 2^31 bytes)
+    uint32_t o0 = on0 ? r0 * (uint32_t)(D * sizeof(float)) : kOff, o1 = on1 ? r1 * (uint32_t)(D * sizeof(float)) : kOff;
+    const uint32_t ao0 = on0 ? r0 * (uint32_t)g.H * 4u : kOff, ao1 = on1 ? r1 * (uint32_t)g.H * 4u : kOff;
+    const uint32_t step_bytes = m * (uint32_t)(D * sizeof(float));
+    auto put_state = [&]() {
+        if (D == 2) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2{st[0][0], st[1][0]}), s_rsrc, (int)o0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2{st[0][1], st[1][1]}), s_rsrc, (int)o1, 0, 0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {       // (vector elements are not addressable: copy them out before the bit cast)
+                const float v0 = st[k][0], v1 = st[k][1];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), s_rsrc, (int)o0 + 4 * k, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), s_rsrc, (int)o1 + 4 * k, 0, 0);
+            }
+        }
+    };
+    const cfloat cW1 = (cfloat)g.W1, cb1 = (cfloat)g.b1, cW2 = (cfloat)g.W2;
+    for (int t = 0; t < g.H; ++t) {
+        put_state();                                                               // dynamics_model.py:225
+        if (on0) o0 += step_bytes;
+        if (on1) o1 += step_bytes;
+        f2 x[IN];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            x[k] = f2{normalise_sel(st[k][0], g.nm.mean_x[k], g.nm.std_x[k]), normalise_sel(st[k][1], g.nm.mean_x[k], g.nm.std_x[k])};
+        f2 av;
+        if (SAMPLE) {
+            if ((t & 3) == 0) {
+                const uint64_t ctr = tt + (uint64_t)(t >> 2);
+                const uint32_t c2 = (uint32_t)ctr, c3 = (uint32_t)(((ctr >> 32) << 8) | TAG_MPC);
+                wa = philox4x32_10(n0, c1_0, c2, c3, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+                wb = philox4x32_10(n1, c1_1, c2, c3, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+            }
+            av = f2{uniform_f32(pick(wa, (uint32_t)(t & 3)), g.low[0], g.span[0]), uniform_f32(pick(wb, (uint32_t)(t & 3)), g.low[0], g.span[0])};
+            const float av0 = av[0], av1 = av[1];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av0), a_rsrc, (int)(ao0 + 4u * (uint32_t)t), 0, 0);   // (a null A_out: range 0)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av1), a_rsrc, (int)(ao1 + 4u * (uint32_t)t), 0, 0);
+        } else {
+            av = f2{g.A[(size_t)r0 * g.H + t], g.A[(size_t)r1 * g.H + t]};
+        }
+        x[D] = f2{normalise_sel(av[0], g.nm.mean_y[0], g.nm.std_y[0]), normalise_sel(av[1], g.nm.mean_y[0], g.nm.std_y[0])};
+        f2 z[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) z[k] = f2{g.b2[k], g.b2[k]};
+        if (SW) {
+            // four hidden units per round: W1[k][j .. j + 3], b1[j .. j + 3], W2[j .. j + 3][:] as scalar loads (SGPR operands of
+            // the packed FMAs) -- the LDS stays out of the loop
+            for (int j = 0; j < g.depth; j += 4) {            // (depth % 4 == 0: the launcher's condition for this variant)
+                float w[IN][4], bb[4], u[4 * D];
+#pragma unroll
+                for (int k = 0; k < IN; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[k][e] = cW1[k * g.depth + j + e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bb[e] = cb1[j + e];
+#pragma unroll
+                for (int e = 0; e < 4 * D; ++e) u[e] = cW2[j * D + e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f2 h = f2{bb[e], bb[e]};
+#pragma unroll
+                    for (int k = 0; k < IN; ++k) h = __builtin_elementwise_fma(x[k], f2{w[k][e], w[k][e]}, h);
+                    h = f2{fmaxf(h[0], 0.0f), fmaxf(h[1], 0.0f)};                     // feedforward_network.py:19
+#pragma unroll
+                    for (int k = 0; k < D; ++k) z[k] = __builtin_elementwise_fma(h, f2{u[e * D + k], u[e * D + k]}, z[k]);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int j = 0; j < g.depth; ++j) {
+                const f4 w = *reinterpret_cast<const f4 *>(&rec[j][0]);
+                const f4 u = *reinterpret_cast<const f4 *>(&rec[j][4]);
+                f2 h = f2{u[0], u[0]};
+#pragma unroll
+                for (int k = 0; k < IN; ++k) h = __builtin_elementwise_fma(x[k], f2{w[k], w[k]}, h);
+                h = f2{fmaxf(h[0], 0.0f), fmaxf(h[1], 0.0f)};                         // feedforward_network.py:19
+#pragma unroll
+                for (int k = 0; k < D; ++k) z[k] = __builtin_elementwise_fma(h, f2{u[1 + k], u[1 + k]}, z[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {                                              // :234-237
+            st[k][0] = st[k][0] + (z[k][0] * g.nm.std_z[k] + g.nm.mean_z[k]);
+            st[k][1] = st[k][1] + (z[k][1] * g.nm.std_z[k] + g.nm.mean_z[k]);
+        }
+    }
+    put_state();                                                                   // :240
+}
+
 // the shapes the fused fp32 kernel takes
 static bool small_sim_shape(const ssc_mlp_desc *mlp, int state_dim, int act_dim) {
     return mlp->n_layers == 2 && mlp->dims[1] <= kSmallMaxDepth && state_dim <= 3 && state_dim + act_dim <= 4 && act_dim <= 3;
@@ -261,6 +423,23 @@ static int launch_small_sim(const ssc_mlp_desc *mlp, const ssc_norm *norm, const
         }
         g.active = sp->d_problem_active;
         if (sp->d_live_list != nullptr && sp->d_n_live != nullptr) { g.live_list = sp->d_live_list; g.n_live = sp->d_n_live; }
+    }
+    // the navigators' own shapes (state 2 or 3, one action) with every byte offset below 2^31: two rows per lane
+    const bool pair = (state_dim == 2 || state_dim == 3) && act_dim == 1 && (int64_t)m * (H + 1) * state_dim * 4 < (1ll << 31) &&
+                      (int64_t)m * H * 4 < (1ll << 31) &&
+                      (sp == nullptr || (sp->n_samples >= 1 && sp->problem_id0 + (uint64_t)(m / sp->n_samples) < (1ull << 32)));
+    if (pair) {
+        const dim3 grid((unsigned)((m + 511) / 512));
+        // weights as scalar loads, four hidden units a round, when the depth allows; else broadcast reads of an LDS image
+        // (measured at 1 Mi rows x 4 steps, depth 32: 27 us of kernel at 84 % VALU busy against 33 us waiting on the LDS;
+        // the general kernel: 50 us)
+        const bool sw = g.depth % 4 == 0;
+#define SSC_PAIR(DD, SS) do { if (sw) hipLaunchKernelGGL((dyn_small_sim_pair_kernel<DD, SS, true>), grid, dim3(256), 0, s, g); \
+                              else hipLaunchKernelGGL((dyn_small_sim_pair_kernel<DD, SS, false>), grid, dim3(256), 0, s, g); } while (0)
+        if (state_dim == 2) { if (sp != nullptr) SSC_PAIR(2, true); else SSC_PAIR(2, false); }
+        else { if (sp != nullptr) SSC_PAIR(3, true); else SSC_PAIR(3, false); }
+#undef SSC_PAIR
+        return check_launch("dyn_small_sim_pair_kernel");
     }
     hipLaunchKernelGGL(dyn_small_sim_kernel, dim3(blocks_for(m)), dim3(256), 0, s, g);
     return check_launch("dyn_small_sim_kernel");

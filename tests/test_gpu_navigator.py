@@ -887,6 +887,55 @@ def test_forward_sim_skips_masked_problems(nav, prec, dims):
     assert np.max(np.abs(g - ref)) <= tol * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("dims,P,N,H", [((3, 32, 2), 5, 7, 4), ((3, 30, 2), 5, 7, 9), ((4, 32, 3), 3, 401, 5), ((4, 50, 3), 6, 33, 4), ((3, 128, 2), 1, 1001, 2)])
+def test_fused_fp32_simulation_two_rows_per_lane(nav, dims, P, N, H):
+    """dyn_small_sim_pair_kernel (the navigators' shapes: state 2 or 3, one action): two rows per lane -- odd candidate
+    counts (a pair straddles two problems), odd row totals (the last lane has one row), depths that are and are not a
+    multiple of 4 (scalar-load and LDS-image weight paths), 2 and 3 Philox calls per row, masked problems, a compact work
+    list, actions from memory, one start state per problem / per row / for all rows -- against the fp64 oracle at 1e-5 and,
+    between the variants, bit for bit."""
+    rng = np.random.default_rng(sum(dims) + N)
+    d = dims[-1]
+    Ws, bs = make_mlp(rng, dims)
+    norm = make_norm(rng, d, 1)
+    model = nav.DynamicsModel(Ws, bs, norm, state_dim=d, act_dim=1, precision="f32")
+    nm64 = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in norm.items()}
+    M = P * N
+    s0 = torch.as_tensor((rng.normal(size=(P, d)) * 0.2).astype(np.float32), device="cuda")
+    sp = nav.mpc_sampling(N, [-1.0], [1.0], 19, 4, 6)
+    A_out = torch.full((M, H, 1), -7.0, device="cuda")
+    S = model.do_forward_sim_sampled(s0, sp, M, H, A_out=A_out).clone()
+    for p in range(P):
+        A = O.mpc_action_samples(19, 4 + p, N, H, 1, 6, [-1.0], [1.0])
+        assert np.array_equal(A_out[p * N:(p + 1) * N].cpu().numpy(), A.astype(np.float32))
+        ref = O.dyn_forward_sim(s0[p].cpu().numpy(), A, nm64, Ws, bs)
+        assert np.max(np.abs(S[:, p * N:(p + 1) * N].cpu().numpy() - ref)) <= 1e-5 * max(1.0, np.abs(ref).max())
+    # the same candidates read from memory: same bits
+    assert torch.equal(model.do_forward_sim(s0, A_out), S)
+    # one start state per ROW (rows_per_state = 1) and one for all rows
+    s_rows = s0.repeat_interleave(N, dim=0).contiguous()
+    assert torch.equal(model.do_forward_sim(s_rows, A_out), S)
+    one = model.do_forward_sim(s0[:1].contiguous(), A_out)
+    assert torch.equal(one[:, :N], S[:, :N])
+    # masked problems: their rows are left alone, the others do not change
+    active = torch.as_tensor((np.arange(P) % 2 == 0).astype(np.uint8), device="cuda")
+    out = torch.full((H + 1, M, d), 123.0, device="cuda")
+    A2 = torch.full((M, H, 1), -7.0, device="cuda")
+    got = model.do_forward_sim_sampled(s0, nav.mpc_sampling(N, [-1.0], [1.0], 19, 4, 6, active=active), M, H, out=out, A_out=A2)
+    live = active.bool().repeat_interleave(N)
+    assert torch.equal(got[:, live], S[:, live]) and bool((got[:, ~live] == 123.0).all())
+    assert torch.equal(A2[live], A_out[live]) and bool((A2[~live] == -7.0).all())
+    # a compact work list of the live problems: the same rows again
+    lst = torch.nonzero(active).flatten().to(torch.int32)
+    n_live = torch.tensor([lst.numel()], dtype=torch.int32, device="cuda")
+    live_list = torch.zeros(P, dtype=torch.int32, device="cuda")
+    live_list[:lst.numel()] = lst
+    out2 = torch.full((H + 1, M, d), 123.0, device="cuda")
+    got2 = model.do_forward_sim_sampled(s0, nav.mpc_sampling(N, [-1.0], [1.0], 19, 4, 6, active=active, live_list=live_list, n_live=n_live),
+                                        M, H, out=out2)
+    assert torch.equal(got2, got)
+
+
 @pytest.mark.parametrize("P,N,H,sampled", [(5000, 16, 4, True), (5000, 16, 1, True), (1, 70000 + 37, 3, True), (300, 257, 2, False)])
 def test_streamed_sim_kernel_walking_over_row_tiles_equals_one_tile_per_block(nav, P, N, H, sampled):
     """More row tiles than CUs: a block of the streamed-W2 kernel (2 x 500) WALKS over row tiles (the W2 ring, its barriers and
