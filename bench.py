@@ -513,10 +513,11 @@ def bench_mpc_reference_shape(args, torch, emit=True, H=4):
     """The MPC step in the shape every shipped SmartStart run uses (examples/continuous/SmartStart_DDPG_Baselines_example.py:94-95;
     class default NND_MB_agent.py:62): N = 5000 candidate sequences per problem (and 500), horizon 4, the 1 x 32 dynamics model,
     MountainCar dims -- P problems at once with P * N ~ 1 Mi simulated rows per step.  Three launches per step: the fused fp32
-    simulation of the small network (``dyn_small_sim_kernel``: a row per lane, weights broadcast from LDS, candidates drawn in the
-    kernel), and the two-pass scorer (generate_scores_add_delta's batch-global projection scalars, NND_MB_agent.py:566-628; pass B
+    simulation of the small network (``dyn_small_sim_pair_kernel``: two rows per lane on packed fp32 FMAs, weights as scalar-load
+    operands, candidates drawn in the kernel), and the two-pass scorer (generate_scores_add_delta's batch-global projection scalars, NND_MB_agent.py:566-628; pass B
     selects).  VALU-bound: 2 * (3 * 32 + 32 * 2) = 320 flop per row-step against the 157.3 TFLOP/s fp32 vector peak says little --
-    the issue-slot share (``valu_issue``, from the committed PMC pass) is the roof that binds."""
+    how busy the vector ALU is over the launch (``valu_busy``, from the committed PMC pass) is the roof that binds: 46 % of the
+    issued vector instructions are the network's FMAs, the rest the z-score divisions, Philox and the ReLU."""
     import numpy as np
 
     from smartstartcontinuous_amd import RandomPolicy, VecEnv
@@ -581,13 +582,13 @@ def bench_mpc_reference_shape(args, torch, emit=True, H=4):
            "config": {"workload": "MountainCar dims (in 3, out 2), num_fc_layers 1, depth 32; N = 5000 x %d problems (and 500 x %d) ~ 1 Mi rows, "
                                   "horizon %d; simulate (in-kernel sampling) + score A + score B/select = 3 launches per MPC step"
                                   % (out["N5000"]["problems"], out["N500"]["problems"], H)},
-           "roofline": {"bound": "valu_issue", "achieved": r5["sim_tflops"], "peak": 157.3, "unit": "TFLOP/s", "frac": r5["sim_tflops"] / 157.3,
-                        "traffic": None, "kernel": "ssc::dyn_small_sim_kernel", "kernel_ms": r5["sim_kernel_ms"],
-                        "note": "fp32 vector flop of the network alone against the vector peak; the kernel spends most of its issue slots on the "
-                                "z-score, Philox sampling and LDS weight broadcasts around them (valu_issue)"}}
+           "roofline": {"bound": "valu", "achieved": r5["sim_tflops"], "peak": 157.3, "unit": "TFLOP/s", "frac": r5["sim_tflops"] / 157.3,
+                        "traffic": None, "kernel": "ssc::dyn_small_sim_pair_kernel", "kernel_ms": r5["sim_kernel_ms"],
+                        "note": "fp32 vector flop of the network alone against the packed-FMA vector peak; the z-score divisions, Philox "
+                                "sampling and ReLU around them issue on the same pipe (valu_busy: its busy share over the launch)"}}
     vi = profiled_small_sim_issue()
     if vi is not None:
-        res["roofline"]["valu_issue"] = vi
+        res["roofline"]["valu_busy"] = vi
     if emit:
         print(json.dumps(res), flush=True)
     return res
@@ -597,11 +598,12 @@ SMALL_SIM_SOURCES = ("dyn_model.hip",)
 
 
 def profiled_small_sim_issue():
-    """SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of dyn_small_sim_kernel from the committed PMC pass of `bench.py --config 5`
-    (profiles/*/mpc_ref/valu_issue.json), reported only for the kernel source it was measured on."""
+    """Vector-ALU busy share of the small simulation kernel's launch (SQ_ACTIVE_INST_VALU x 4 per SIMD over SQ_BUSY_CYCLES per
+    shader engine) from the committed PMC pass of `bench.py --config 5` (profiles/*/mpc_ref/valu_busy.json), reported only for
+    the kernel source it was measured on."""
     import glob
     sha, best = source_sha_of(SMALL_SIM_SOURCES), None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "mpc_ref", "valu_issue.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "mpc_ref", "valu_busy.json"))):
         try:
             d = json.load(open(f))
         except Exception:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/prof_r04_final/{c4_per_env,c4_h20,mpc_ref,ssvec,vec_ddpg} (tools/gpu_r04_final.sh) -> profiles/r04_final/<same>:
 kernel-stats CSVs, per-kernel PMC means, the derived figures bench.py reads back (mfma_busy.json of the walking kernel,
-valu_issue.json of the small-network simulation) and, for the actor-learner loop, how much of a chunk is kernels and how
+valu_busy.json of the small-network simulation) and, for the actor-learner loop, how much of a chunk is kernels and how
 much is launch boundaries.
 
     python3 tools/summarize_r04.py gpurun_out/prof_r04_final profiles/r04_final
@@ -76,17 +76,21 @@ def main(src, dst):
                 json.dump(out, open(os.path.join(d, "mfma_busy.json"), "w"), indent=1)
                 print(name, json.dumps(out))
         if name == "mpc_ref":
-            names = [n for n in pmc if "dyn_small_sim_kernel" in n]
+            names = [n for n in pmc if "dyn_small_sim" in n]
             if names:
                 c = pmc[names[0]]
                 g = lambda key: c.get(key, {}).get("mean")
-                wave, valu = g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_VALU")
-                out = {"bound": "valu_issue", "kernel": names[0], "frac": valu / wave if wave and valu else None,
-                       "SQ_ACTIVE_INST_VALU": valu, "SQ_WAVE_CYCLES": wave, "SQ_INSTS_VALU": g("SQ_INSTS_VALU"),
+                wave, valu, busy = g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_VALU"), g("SQ_BUSY_CYCLES")
+                # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count in units of four cycles (a wave64 VALU instruction occupies its SIMD
+                # for four), SQ_BUSY_CYCLES in cycles per shader engine: the share of the launch in which a SIMD's vector ALU is busy
+                out = {"bound": "valu", "kernel": names[0],
+                       "frac": (valu * 4.0 / N_SIMD) / (busy / N_SE) if valu and busy else None,
+                       "waves_resident_per_simd": (wave * 4.0 / N_SIMD) / (busy / N_SE) if wave and busy else None,
+                       "SQ_ACTIVE_INST_VALU": valu, "SQ_WAVE_CYCLES": wave, "SQ_BUSY_CYCLES": busy, "SQ_INSTS_VALU": g("SQ_INSTS_VALU"),
                        "SQ_ACTIVE_INST_ANY": g("SQ_ACTIVE_INST_ANY"), "SQ_WAIT_INST_ANY": g("SQ_WAIT_INST_ANY"),
-                       "note": "share of the resident waves' cycles in which a VALU instruction was issuing (per-SE sums of the same launch)",
+                       "note": "vector-ALU busy cycles per SIMD over the launch's own length in shader cycles (same PMC pass; per-SE sums)",
                        "source_sha": sha(("dyn_model.hip",))}
-                json.dump(out, open(os.path.join(d, "valu_issue.json"), "w"), indent=1)
+                json.dump(out, open(os.path.join(d, "valu_busy.json"), "w"), indent=1)
                 print(name, json.dumps(out))
         if name == "vec_ddpg" and rows:
             # the steady half of the trace: kernel time vs wall time between the first and the last kernel
