@@ -33,10 +33,13 @@ struct WalkState {
 // One horizon step t of one sample at point pt.  PASS 0: accumulate a.b / b.b into sums[t][2].
 // PASS 1: add the progress and penalty terms to the score using the global G1/G2 of step t.
 // G = lanes that share one problem's reduction (64: a whole wave; 16 / 32: the small-N kernel's sub-wave groups).
-template <int PASS, int G = 64>
+// DEFER (pass A, prefetched trajectories): the lane's a.b / b.b of step t go to LDS as they are (acc[t][2][thread]) and the
+// block sums them once, after the walk (block_sums_deferred) -- the per-step fp64 butterflies were 24 ds_bpermute + 12 v_add_f64
+// per horizon step and wave, more than the walk itself.
+template <int PASS, int G = 64, bool DEFER = false>
 __device__ __forceinline__ void walk_step(const MpcArgs &a, const float *pt, int t, const float *wps, const float *lefts,
                                           int W, const float *inv_r, double *wave_sums, const float *cproj,
-                                          WalkState &w) {
+                                          WalkState &w, float *acc = nullptr) {
     const int d = a.d;
     if (t == 0) w.prev = lefts[w.idx] + ell_dist(pt, wps + w.idx * d, inv_r, d);  // NND_MB_agent.py:573-576
     const int nxt = min(w.idx + 1, W - 1);
@@ -60,7 +63,10 @@ __device__ __forceinline__ void walk_step(const MpcArgs &a, const float *pt, int
             ab = fmaf(av[k], bv[k], ab);
             bb = fmaf(bv[k], bv[k], bb);
         }
-    if (PASS == 0) {
+    if (PASS == 0 && DEFER) {
+        acc[(t * 2 + 0) * kMpcBlock + threadIdx.x] = w.live ? ab : 0.0f;
+        acc[(t * 2 + 1) * kMpcBlock + threadIdx.x] = w.live ? bb : 0.0f;
+    } else if (PASS == 0) {
         // every lane of the wave is at the same t: reduce now (fixed butterfly order) instead of keeping a
         // per-thread [H+1][2] array of doubles, which a runtime t would push into scratch memory
         double v0 = w.live ? (double)ab : 0.0, v1 = w.live ? (double)bb : 0.0;
@@ -122,15 +128,31 @@ __device__ __forceinline__ void mpc_fetch_pts(const MpcArgs &a, const float *__r
             pts.v[t][k] = (live && k < kPreD && t <= a.H && k < a.d) ? S[((int64_t)t * M + row) * a.d + k] : 0.0f;
 }
 
-template <int PASS, int G = 64>
+template <int PASS, int G = 64, bool DEFER = false>
 __device__ __forceinline__ float mpc_walk_pre(const MpcArgs &a, const PrePts &pp, const float *wps, const float *lefts, int W,
-                                              int idx0, const float *inv_r, bool live, double *wave_sums, const float *cproj) {
+                                              int idx0, const float *inv_r, bool live, double *wave_sums, const float *cproj,
+                                              float *acc = nullptr) {
     const float (&pts)[kPreT][SSC_MAX_STATE] = pp.v;
     WalkState w{idx0, 0.0f, 0.0f, 1.0f, live};
 #pragma unroll
     for (int t = 0; t < kPreT; ++t)
-        if (t <= a.H) walk_step<PASS, G>(a, pts[t], t, wps, lefts, W, inv_r, wave_sums, cproj, w);
+        if (t <= a.H) walk_step<PASS, G, DEFER>(a, pts[t], t, wps, lefts, W, inv_r, wave_sums, cproj, w, acc);
     return w.score;
+}
+
+// The block's sums of the deferred terms: sum e = (t, a.b | b.b) belongs to the 16 lanes of group e; a lane adds threads
+// lane, lane + 16, ... in order (fp64), the group's 16 subtotals meet in a butterfly -- the same order in every run.
+__device__ __forceinline__ void block_sums_deferred(const float *acc, int n_sums, double *out) {
+    const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    double v = 0.0;
+    if (grp < n_sums) {
+        const float *src = acc + grp * kMpcBlock + l16;
+#pragma unroll
+        for (int j = 0; j < kMpcBlock / 16; ++j) v += (double)src[16 * j];
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (l16 == 0 && grp < n_sums) out[grp] = v;
 }
 
 __device__ __forceinline__ bool mpc_can_prefetch(const MpcArgs &a) { return a.H + 1 <= kPreT && a.d <= kPreD; }  // block-uniform
@@ -210,6 +232,8 @@ __device__ __forceinline__ void mpc_pass_a_body(MpcArgs a, const float *__restri
                                                 int32_t *__restrict__ ticket) {
     __shared__ double red[4 * kMaxH1 * 2];  // [4 waves][H+1][2]
     __shared__ float win[kWinFloats];
+    __shared__ float acc[kPreT * 2 * kMpcBlock];   // deferred sums of the prefetched walk: [t][a.b | b.b][thread]
+    static_assert(kPreT * 2 <= kMpcBlock / 16, "one 16-lane group per deferred sum");
     const int p = blockIdx.x / a.nblk, bx = blockIdx.x - p * a.nblk;
     if (bx == 0 && threadIdx.x == 0) ticket[p] = 0;  // pass B elects its last block with it
     const int n = bx * kMpcBlock + threadIdx.x;
@@ -220,7 +244,13 @@ __device__ __forceinline__ void mpc_pass_a_body(MpcArgs a, const float *__restri
     int W, idx0;
     load_problem(a, p, win, W, idx0);
     const float *wps = win, *lefts = win + kWinMax * a.d, *inv_r = lefts + kWinMax;
-    mpc_walk_any<0>(a, pp, S, row, M, wps, lefts, W, idx0, inv_r, live, red + (threadIdx.x >> 6) * kMaxH1 * 2, nullptr);
+    if (mpc_can_prefetch(a)) {    // block-uniform
+        mpc_walk_pre<0, 64, true>(a, pp, wps, lefts, W, idx0, inv_r, live, nullptr, nullptr, acc);
+        __syncthreads();
+        block_sums_deferred(acc, (a.H + 1) * 2, partial + ((int64_t)p * a.nblk + bx) * (a.H + 1) * 2);
+        return;
+    }
+    mpc_walk<0>(a, S, row, M, wps, lefts, W, idx0, inv_r, live, red + (threadIdx.x >> 6) * kMaxH1 * 2, nullptr);
     __syncthreads();
     for (int e = threadIdx.x; e < (a.H + 1) * 2; e += kMpcBlock) {
         double v = 0.0;
