@@ -215,15 +215,16 @@ __device__ __forceinline__ void block_argmax(float &score, int &best, float *rs,
             if (rs[w] > score || (rs[w] == score && ri[w] < best)) { score = rs[w]; best = ri[w]; }
 }
 
-// The kernels below dispatch on the state dimension once and run a copy of their (inlined) body in which `a.d` is a
-// known constant: the walk's distance and projection loops are written over SSC_MAX_STATE = 8 slots with `k < d` guards,
+// The kernels below are compiled per state dimension (D = 0: any d, read from the arguments) and run a body in which `a.d` is
+// a known constant -- separate kernels, not branches of one (a kernel's register count is that of its widest branch, and
+// the any-d copy keeps 64 prefetched floats per sample): the walk's distance and projection loops are written over SSC_MAX_STATE = 8 slots with `k < d` guards,
 // which for the 2- and 3-d states of the shipped envs is otherwise two thirds predicated-off work per sample and point.
-#define SSC_MPC_DISPATCH_D(a, CALL)                                  \
-    do {                                                            \
-        if ((a).d == 2) { (a).d = 2; CALL; }                        \
-        else if ((a).d == 3) { (a).d = 3; CALL; }                   \
-        else if ((a).d == 1) { (a).d = 1; CALL; }                   \
-        else { CALL; }                                              \
+#define SSC_MPC_LAUNCH_D(d, KERNEL_OF_D, ...)                                   \
+    do {                                                                        \
+        if ((d) == 2) hipLaunchKernelGGL((KERNEL_OF_D(2)), __VA_ARGS__);       \
+        else if ((d) == 3) hipLaunchKernelGGL((KERNEL_OF_D(3)), __VA_ARGS__);  \
+        else if ((d) == 1) hipLaunchKernelGGL((KERNEL_OF_D(1)), __VA_ARGS__);  \
+        else hipLaunchKernelGGL((KERNEL_OF_D(0)), __VA_ARGS__);                \
     } while (0)
 
 // Blocks are numbered problem-major in grid.x (block = p * nblk + b): a problem count of 65 536 -- one navigation
@@ -259,10 +260,12 @@ __device__ __forceinline__ void mpc_pass_a_body(MpcArgs a, const float *__restri
     }
 }
 
+template <int D>
 __global__ __launch_bounds__(kMpcBlock) void mpc_pass_a_kernel(MpcArgs a, const float *__restrict__ S,
                                                                double *__restrict__ partial,
                                                                int32_t *__restrict__ ticket) {
-    SSC_MPC_DISPATCH_D(a, mpc_pass_a_body(a, S, partial, ticket));
+    if (D > 0) a.d = D;
+    mpc_pass_a_body(a, S, partial, ticket);
 }
 
 // What ssc_mpc_select_action does, folded into pass B's last block (ssc_mpc_score_select)
@@ -395,6 +398,7 @@ __device__ __forceinline__ void mpc_pass_b_body(MpcArgs a, int stage_partials, c
 #error "mpc.hip: the relaxed ticket handoff of pass B is written for gfx950 (MI355X) only"
 #endif
 
+template <int D>
 __global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int stage_partials, SelectArgs sel, const float *__restrict__ S,
                                                                const double *__restrict__ partial,
                                                                float *__restrict__ scores,
@@ -402,8 +406,8 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int st
                                                                int32_t *__restrict__ ticket,
                                                                int32_t *__restrict__ best_idx,
                                                                float *__restrict__ best_score) {
-    SSC_MPC_DISPATCH_D(a, mpc_pass_b_body(a, stage_partials, sel, S, partial, scores, blk_best_score, blk_best_idx, ticket,
-                                          best_idx, best_score));
+    if (D > 0) a.d = D;
+    mpc_pass_b_body(a, stage_partials, sel, S, partial, scores, blk_best_score, blk_best_idx, ticket, best_idx, best_score);
 }
 
 // ---- N <= 64 samples per problem: the whole scoring of a problem in ONE launch ---------------------------------------
@@ -470,11 +474,12 @@ __device__ __forceinline__ void mpc_small_body(MpcArgs a, const SelectArgs &sel,
     if (sel.action != nullptr) mpc_select_epilogue(a, sel, S, p, best, n, G);
 }
 
-template <int G>
+template <int G, int D>
 __global__ __launch_bounds__(kMpcBlock) void mpc_small_kernel(MpcArgs a, SelectArgs sel, const float *__restrict__ S,
                                                               float *__restrict__ scores, int32_t *__restrict__ best_idx,
                                                               float *__restrict__ best_score) {
-    SSC_MPC_DISPATCH_D(a, mpc_small_body<G>(a, sel, S, scores, best_idx, best_score));
+    if (D > 0) a.d = D;
+    mpc_small_body<G>(a, sel, S, scores, best_idx, best_score);
 }
 
 // The navigating envs as a compact list (ssc_nav_compact): ballot + prefix inside a wave, the 16 wave counts of a block
@@ -635,9 +640,15 @@ static int mpc_score_common(const char *who, const ssc_mpc_problems *pr, const f
         const int64_t blocks = ((int64_t)a.P + kMpcBlock / G - 1) / (kMpcBlock / G);
         SSC_REQUIRE(blocks <= 0x7fffffff, "%s: too many problems", who);
         const dim3 grid((unsigned)blocks);
-        if (G == 16) hipLaunchKernelGGL(mpc_small_kernel<16>, grid, dim3(kMpcBlock), 0, s, a, sel, d_S, d_scores, d_best_idx, d_best_score);
-        else if (G == 32) hipLaunchKernelGGL(mpc_small_kernel<32>, grid, dim3(kMpcBlock), 0, s, a, sel, d_S, d_scores, d_best_idx, d_best_score);
-        else hipLaunchKernelGGL(mpc_small_kernel<64>, grid, dim3(kMpcBlock), 0, s, a, sel, d_S, d_scores, d_best_idx, d_best_score);
+#define SSC_SMALL16(D) mpc_small_kernel<16, D>
+#define SSC_SMALL32(D) mpc_small_kernel<32, D>
+#define SSC_SMALL64(D) mpc_small_kernel<64, D>
+        if (G == 16) SSC_MPC_LAUNCH_D(a.d, SSC_SMALL16, grid, dim3(kMpcBlock), 0, s, a, sel, d_S, d_scores, d_best_idx, d_best_score);
+        else if (G == 32) SSC_MPC_LAUNCH_D(a.d, SSC_SMALL32, grid, dim3(kMpcBlock), 0, s, a, sel, d_S, d_scores, d_best_idx, d_best_score);
+        else SSC_MPC_LAUNCH_D(a.d, SSC_SMALL64, grid, dim3(kMpcBlock), 0, s, a, sel, d_S, d_scores, d_best_idx, d_best_score);
+#undef SSC_SMALL16
+#undef SSC_SMALL32
+#undef SSC_SMALL64
         return check_launch(who);
     }
     SSC_REQUIRE((int64_t)a.P * a.nblk <= 0x7fffffff, "%s: too many blocks", who);
@@ -653,9 +664,13 @@ static int mpc_score_common(const char *who, const ssc_mpc_problems *pr, const f
     const int stage_partials = part_bytes <= 32 * 1024;
     const size_t lds_b = stage_partials ? part_bytes : 0;
     const dim3 grid((unsigned)((int64_t)a.P * a.nblk));     // problem-major in x: P may exceed the gridDim.y limit
-    hipLaunchKernelGGL(mpc_pass_a_kernel, grid, dim3(kMpcBlock), 0, s, a, d_S, partial, ticket);
-    hipLaunchKernelGGL(mpc_pass_b_kernel, grid, dim3(kMpcBlock), lds_b, s, a, stage_partials, sel, d_S, partial, d_scores, bbs, bbi,
-                       ticket, d_best_idx, d_best_score);
+#define SSC_PASS_A(D) mpc_pass_a_kernel<D>
+#define SSC_PASS_B(D) mpc_pass_b_kernel<D>
+    SSC_MPC_LAUNCH_D(a.d, SSC_PASS_A, grid, dim3(kMpcBlock), 0, s, a, d_S, partial, ticket);
+    SSC_MPC_LAUNCH_D(a.d, SSC_PASS_B, grid, dim3(kMpcBlock), lds_b, s, a, stage_partials, sel, d_S, partial, d_scores, bbs, bbi,
+                     ticket, d_best_idx, d_best_score);
+#undef SSC_PASS_A
+#undef SSC_PASS_B
     return check_launch(who);
 }
 
