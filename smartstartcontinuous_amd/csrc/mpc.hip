@@ -417,12 +417,13 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_pass_b_kernel(MpcArgs a, int st
 // "one navigator per env" at the BASELINE env count (P = 65 536 problems x 16-64 candidates); the f64 sums are formed
 // in the same order as the two-pass path forms them for N <= 64 (lanes past N add exact zeros), so scores and
 // winners are bit-identical to it.
-template <int G>
+template <int G, int D>
 __device__ __forceinline__ void mpc_small_body(MpcArgs a, const SelectArgs &sel, const float *__restrict__ S,
                                                float *__restrict__ scores, int32_t *__restrict__ best_idx,
                                                float *__restrict__ best_score) {
     constexpr int kGroups = kMpcBlock / G;
-    __shared__ float win[kGroups][kWinFloats];
+    constexpr int DM = D > 0 ? D : SSC_MAX_STATE;      // a window is wps [kWinMax][d] | lefts [kWinMax] | inv_r [d]
+    __shared__ float win[kGroups][kWinMax * (DM + 1) + DM];
     __shared__ double sums[kGroups][kMaxH1 * 2];
     __shared__ float cproj[kGroups][kMaxH1 + 1];
     const int g = threadIdx.x / G, n = threadIdx.x & (G - 1);
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(kMpcBlock) void mpc_small_kernel(MpcArgs a, SelectA
                                                               float *__restrict__ scores, int32_t *__restrict__ best_idx,
                                                               float *__restrict__ best_score) {
     if (D > 0) a.d = D;
-    mpc_small_body<G>(a, sel, S, scores, best_idx, best_score);
+    mpc_small_body<G, D>(a, sel, S, scores, best_idx, best_score);
 }
 
 // The navigating envs as a compact list (ssc_nav_compact): ballot + prefix inside a wave, the 16 wave counts of a block
