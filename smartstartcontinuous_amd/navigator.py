@@ -432,7 +432,13 @@ class PlanPool:
             for q in getattr(self, "_on_offer", []):       # the plans on offer until now go off offer
                 ages[q] = now
             self._on_offer = [(first + j) % self.n_slots for j in range(len(plans))]
-        wpv, lv = self.wp.view(self.n_slots, self.w_max, self.d), self.left.view(self.n_slots, self.w_max)
+        # all plans of this refresh travel together: four host -> device copies and four scatters by slot, not eight small
+        # operations per plan (they sit on the rollout's stream between two chunks)
+        n = len(plans)
+        wp_h = np.zeros((n, self.w_max, self.d), np.float32)
+        left_h = np.zeros((n, self.w_max), np.float32)
+        len_h = np.zeros(n, np.int32)
+        radii_h = np.zeros((n, self.d), np.float32)
         for j, (w, l, r) in enumerate(plans):
             w = np.asarray(w, np.float32)
             l = np.asarray(l, np.float32)
@@ -440,11 +446,15 @@ class PlanPool:
                 w, l = np.concatenate([w, w], axis=0), np.zeros(2, np.float32)
             if len(w) > self.w_max:
                 raise ValueError("plan of %d waypoints > w_max %d" % (len(w), self.w_max))
-            q = (first + j) % self.n_slots
-            wpv[q, :len(w)] = torch.as_tensor(w, device=self.device)
-            lv[q, :len(w)] = torch.as_tensor(l, device=self.device)
-            self.wp_len[q] = len(w)
-            self.radii[q] = torch.as_tensor(np.asarray(r, np.float32), device=self.device)
+            wp_h[j, :len(w)], left_h[j, :len(w)], len_h[j], radii_h[j] = w, l, len(w), np.asarray(r, np.float32)
+            # (rows behind a plan's length keep whatever the slot held before in the reference-free sense: nothing reads
+            # them -- every index is clamped to wp_len; they are zero here)
+        slots = torch.as_tensor([(first + j) % self.n_slots for j in range(n)], dtype=torch.int64, device=self.device)
+        dev = lambda a: torch.as_tensor(a, device=self.device)
+        self.wp.view(self.n_slots, self.w_max, self.d).index_copy_(0, slots, dev(wp_h))
+        self.left.view(self.n_slots, self.w_max).index_copy_(0, slots, dev(left_h))
+        self.wp_len.index_copy_(0, slots, dev(len_h))
+        self.radii.index_copy_(0, slots, dev(radii_h))
         self.pool.copy_(torch.tensor([first, len(plans), self.n_slots], dtype=torch.int32))
         self._next = (first + len(plans)) % self.n_slots
         self.published += len(plans)
