@@ -194,6 +194,42 @@ __device__ __forceinline__ void load_window(const MpcArgs &a, int p, int lane, i
     idx0 = iabs - wb;
 }
 
+// The same staging in two phases for a whole block (nl = kMpcBlock >= 36 * 8 / 2): `issue` computes the window and puts its
+// loads in flight (<= 2 waypoint floats, one distance, one radius per thread), `commit` writes them to LDS -- so that a
+// caller can request other data between the two and pay ONE round trip for both.
+struct WindowLoads {
+    float w0, w1, l0, r0;
+    int cnt, d;
+};
+__device__ __forceinline__ WindowLoads load_window_issue(const MpcArgs &a, int p, int &W, int &idx0) {
+    const int q = plan_index(a, p);
+    const int off = a.wp_off[q];
+    const int Wabs = plan_len(a, q);
+    const int iabs = min(a.cur_idx[p], max(Wabs - 1, 0));     // (clamped: see load_window)
+    const int wb = max(iabs - 1, 0);
+    WindowLoads r;
+    r.cnt = max(min(Wabs - wb, a.H + 4), 0);
+    r.d = a.d;
+    const float *wsrc = a.wp + (int64_t)(off + wb) * a.d;
+    const int t = threadIdx.x, n = r.cnt * a.d;
+    r.w0 = t < n ? wsrc[t] : 0.0f;
+    r.w1 = t + kMpcBlock < n ? wsrc[t + kMpcBlock] : 0.0f;
+    r.l0 = t < r.cnt ? a.left[off + wb + t] : 0.0f;
+    r.r0 = t < a.d ? a.radii[q * a.d + t] : 1.0f;
+    W = Wabs - wb;
+    idx0 = iabs - wb;
+    return r;
+}
+__device__ __forceinline__ void load_window_commit(const WindowLoads &r, float *win) {
+    float *wps = win, *lefts = win + kWinMax * r.d, *inv_r = lefts + kWinMax;
+    const int t = threadIdx.x, n = r.cnt * r.d;
+    if (t < n) wps[t] = r.w0;
+    if (t + kMpcBlock < n) wps[t + kMpcBlock] = r.w1;
+    if (t < r.cnt) lefts[t] = r.l0;
+    if (t < r.d) inv_r[t] = 1.0f / r.r0;
+}
+static_assert(kWinMax * SSC_MAX_STATE <= 2 * 256, "two waypoint floats per thread cover a window");
+
 __device__ __forceinline__ void load_problem(const MpcArgs &a, int p, float *win, int &W, int &idx0) {
     load_window(a, p, threadIdx.x, blockDim.x, win, W, idx0);
     __syncthreads();
@@ -333,11 +369,22 @@ __device__ __forceinline__ void mpc_pass_b_body(MpcArgs a, int stage_partials, c
     // fixed-order reduction of the per-block partials of this problem.  The partials come in with ONE round trip (every
     // thread fetches its share into LDS) and are then summed in block order by thread t -- H + 1 threads walking nblk
     // dependent global loads each was most of this kernel's run time.
+    // The partials, the waypoint window (behind its index loads) and the trajectory points are requested TOGETHER: one
+    // wait, one barrier -- with the window loaded after the reduction every block paid one more dependent round trip
+    // (five in all, at ~7 blocks per CU the whole launch is a chain of them).
     const int n_part = a.nblk * (a.H + 1) * 2;
-    if (pstage != nullptr) {
+    const bool one_trip = pstage != nullptr && n_part <= kMpcBlock;     // block-uniform
+    double pv = 0.0;
+    if (one_trip && threadIdx.x < n_part) pv = partial[(int64_t)p * n_part + threadIdx.x];
+    int W, idx0;
+    const WindowLoads wl = load_window_issue(a, p, W, idx0);
+    if (one_trip) {
+        if (threadIdx.x < n_part) pstage[threadIdx.x] = pv;
+    } else if (pstage != nullptr) {
         for (int e = threadIdx.x; e < n_part; e += kMpcBlock) pstage[e] = partial[(int64_t)p * n_part + e];
-        __syncthreads();
     }
+    load_window_commit(wl, win);
+    __syncthreads();
     for (int t = threadIdx.x; t <= a.H; t += kMpcBlock) {
         double g0 = 0.0, g1 = 0.0;
         for (int b = 0; b < a.nblk; ++b) {
@@ -347,8 +394,7 @@ __device__ __forceinline__ void mpc_pass_b_body(MpcArgs a, int stage_partials, c
         }
         cproj[t] = (float)(g0 / g1);
     }
-    int W, idx0;
-    load_problem(a, p, win, W, idx0);  // ends with __syncthreads()
+    __syncthreads();
     const float *wps = win, *lefts = win + kWinMax * a.d, *inv_r = lefts + kWinMax;
     float score = -INFINITY;
     int best = 0x7fffffff;
