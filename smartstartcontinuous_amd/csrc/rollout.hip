@@ -595,6 +595,10 @@ struct SsStepArgs {
 template <class EnvT, bool SS = false>
 __global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT::Const ec, RolloutArgs ra, MpcStepArgs ma, SsStepArgs sa) {
     constexpr int OBS = EnvT::OBS;
+    // the navigator plans in observation space (checked on the host): with the dimension a constant the waypoint / radii loads of
+    // the bookkeeping below are straight-line and go out together -- as a run-time bound every one of them was a branch with a
+    // load and a full wait behind it, a dozen dependent round trips in a kernel that is one wave per SIMD
+    ma.nav.d = OBS;
     const int64_t gi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (SS && gi == 0 && sa.n_live != nullptr) *sa.n_live = 0;   // simulation and scoring of this step are behind us in the stream
     const bool active = gi < ra.n;
@@ -610,6 +614,11 @@ __global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT:
         float ep_ret = ra.st.ep_ret[i];
         float obs[OBS], obs2[OBS];
         env.observe(obs);
+        // the navigator's bookkeeping state and plan: requested here, with the env's state, not behind the log stores below
+        // (which the compiler cannot move loads across)
+        int idx = ma.cur_idx[i];
+        int done_act = ma.actions_done[i];
+        const NavPlan plan = nav_plan_load(ma.nav, (int)i);
         // SmartStartContinuous.get_action (smartexplorationcontinuous.py:307-317): the navigator while smart_start_pathing,
         // the base agent otherwise
         bool navigating = true;
@@ -667,12 +676,10 @@ __global__ __launch_bounds__(kBlock) void mpc_rollout_step_kernel(typename EnvT:
         float x[SSC_MAX_STATE];
 #pragma unroll
         for (int c = 0; c < SSC_MAX_STATE; ++c) x[c] = (c < OBS) ? obs2[c < OBS ? c : 0] : 0.0f;
-        int idx = ma.cur_idx[i];
-        int done_act = ma.actions_done[i];
         bool at_goal = false;
         if (navigating) {
             done_act += 1;
-            at_goal = nav_observe_one(ma.nav, (int)i, x, idx, done_act, ma.give_up, ma.final_steps);
+            at_goal = nav_observe_plan(ma.nav, plan, x, idx, done_act, ma.give_up, ma.final_steps);
         }
         if (ma.at_goal != nullptr) ma.at_goal[i] = at_goal ? 1 : 0;
         if (SS && navigating && at_goal) navigating = false;     // :336-339: the base agent takes over
