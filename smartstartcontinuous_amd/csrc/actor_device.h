@@ -187,18 +187,23 @@ struct ActorMfma {
         // (sum_j w3_j) + sum_j (-2 w3_j) r_j  with r_j = 1 / (2^(c x_j) + 1): per hidden unit that
         // is v_exp_f32, v_add, v_rcp_f32, v_fma -- 4 VALU ops instead of 6.
         const float cs = last_tanh ? 2.88539008177792681472f : 1.0f;
+        // Every load below is UNCONDITIONAL (index clamped into the array, value dropped by a select): a guarded load is a
+        // branch with a full wait behind it, and this function was ~50 of them in a row -- most of the standalone actor
+        // kernel's 11 us at 65 536 rows.
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
             const int unit = ut * 32 + r;
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 const int k = 2 * ks + half;
-                a1[ut][ks] = (k < OBS && unit < H1) ? w.W1[k * H1 + unit] : 0.0f;
+                const float v = w.W1[min(k, OBS - 1) * H1 + min(unit, H1 - 1)];
+                a1[ut][ks] = (k < OBS && unit < H1) ? v : 0.0f;
             }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int u = ut * 32 + acc_row(reg, half);
-                c1[ut][reg] = (u < H1) ? w.b1[u] : 0.0f;
+                const float v = w.b1[min(u, H1 - 1)];
+                c1[ut][reg] = (u < H1) ? v : 0.0f;
             }
         }
 #pragma unroll
@@ -212,19 +217,26 @@ struct ActorMfma {
                     for (int j = 0; j < 8; ++j) {
                         // k slot (8*half + j) of k-step (ut, s) carries hidden unit u
                         const int u = ut * 32 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
-                        const float v = (u < H1 && col < H2) ? w.W2[u * H2 + col] * cs : 0.0f;
+                        const float x = w.W2[min(u, H1 - 1) * H2 + min(col, H2 - 1)];
+                        const float v = (u < H1 && col < H2) ? x * cs : 0.0f;
                         a2[jt][ut][s][j] = (__bf16)v;
                     }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int o = jt * 32 + acc_row(reg, half);
-                c2[jt][reg] = (o < H2) ? w.b2[o] * cs : 0.0f;
-                w3[jt][reg] = (o < H2) ? w.W3[o] * (last_tanh ? -2.0f : 1.0f) : 0.0f;
+                const float xb = w.b2[min(o, H2 - 1)], xw = w.W3[min(o, H2 - 1)];
+                c2[jt][reg] = (o < H2) ? xb * cs : 0.0f;
+                w3[jt][reg] = (o < H2) ? xw * (last_tanh ? -2.0f : 1.0f) : 0.0f;
             }
         }
         b3 = w.b3[0];
-        if (last_tanh)
-            for (int j = 0; j < H2; ++j) b3 += w.W3[j];
+        if (last_tanh) {     // b3 + sum_j W3[j], added in index order as before; the (uniform) loads go out together
+            float w3v[32 * JT];
+#pragma unroll
+            for (int j = 0; j < 32 * JT; ++j) w3v[j] = w.W3[min(j, H2 - 1)];
+#pragma unroll
+            for (int j = 0; j < 32 * JT; ++j) b3 += (j < H2) ? w3v[j] : 0.0f;
+        }
     }
 
     // obs: this lane's env observation.  Returns the actor output for this lane's env.
@@ -500,9 +512,11 @@ struct ActorMfma2 {
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
             const int unit = ut * 32 + r;
-            const bool ok = unit < H1;
-            const float w0 = ok ? w.W1[0 * H1 + unit] : 0.0f, w1 = ok ? w.W1[1 * H1 + unit] : 0.0f;
-            const float bb = ok ? w.b1[unit] : 0.0f;
+            const bool ok = unit < H1;           // (unconditional loads, clamped index + select: see ActorMfma::init)
+            const int uc = min(unit, H1 - 1);
+            const float x0 = w.W1[0 * H1 + uc], x1 = w.W1[1 * H1 + uc], xb = w.b1[uc];
+            const float w0 = ok ? x0 : 0.0f, w1 = ok ? x1 : 0.0f;
+            const float bb = ok ? xb : 0.0f;
             const float w0h = bf16_head_f(w0), w1h = bf16_head_f(w1), bh = bf16_head_f(bb);
             i32x4 p;
             p[0] = (int)pack_bf16(w0h, w1h);            // x (xh0, xh1)
@@ -519,18 +533,25 @@ struct ActorMfma2 {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int u = ut * 32 + 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
-                    const float v = (u < H1 && col < H2) ? w.W2[u * H2 + col] * cs : 0.0f;
+                    const float x = w.W2[min(u, H1 - 1) * H2 + min(col, H2 - 1)];
+                    const float v = (u < H1 && col < H2) ? x * cs : 0.0f;
                     a2[ut][s][j] = (__bf16)v;
                 }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int o = acc_row(reg, half);
-            c2[reg] = (o < H2) ? w.b2[o] * cs : 0.0f;
-            w3[reg] = (o < H2) ? w.W3[o] * (LAST_TANH ? -2.0f : 1.0f) : 0.0f;
+            const float xb = w.b2[min(o, H2 - 1)], xw = w.W3[min(o, H2 - 1)];
+            c2[reg] = (o < H2) ? xb * cs : 0.0f;
+            w3[reg] = (o < H2) ? xw * (LAST_TANH ? -2.0f : 1.0f) : 0.0f;
         }
         b3 = w.b3[0];
-        if (LAST_TANH)
-            for (int j = 0; j < H2; ++j) b3 += w.W3[j];
+        if (LAST_TANH) {     // same order of additions as before, the loads together
+            float w3v[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) w3v[j] = w.W3[min(j, H2 - 1)];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) b3 += (j < H2) ? w3v[j] : 0.0f;
+        }
     }
 
     // Wave-collective.  Returns the PRE-tanh output sum_j w3_j h2_j + b3 of this lane's env (the caller applies
