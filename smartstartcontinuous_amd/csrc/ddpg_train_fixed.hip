@@ -259,8 +259,30 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
     float *const th_tc = th_ta + NA::size;
     auto row = [&](int r) { return act + r * kP; };
 
-    for (int e = tid; e < NA::gsize; e += kT) { const int l = NA::to_lds(e); th_a[l] = d.actor[e]; th_ta[l] = d.target_actor[e]; }
-    for (int e = tid; e < NC::gsize; e += kT) { const int l = NC::to_lds(e); th_c[l] = d.critic[e]; th_tc[l] = d.target_critic[e]; }
+    // (the first batch's record numbers: requested in front of the parameter loads, their round trip runs under them)
+    int64_t rec0 = 0;
+    if (tid < kB) rec0 = (int64_t)g.batch_idx[(TILED ? (int64_t)blockIdx.x * kB : 0) + tid];
+    // The four parameter vectors -> LDS images: ALL loads first (about twenty per thread, indices clamped), then the stores --
+    // as a load / store loop this was ten dependent round trips in front of the first level, half of a one-iteration
+    // (TILED) launch.
+    {
+        constexpr int kIA = (NA::gsize + kT - 1) / kT, kIC = (NC::gsize + kT - 1) / kT;
+        float va[kIA], vta[kIA], vc[kIC], vtc[kIC];
+#pragma unroll
+        for (int k = 0; k < kIA; ++k) { const int e = min(tid + k * kT, NA::gsize - 1); va[k] = d.actor[e]; vta[k] = d.target_actor[e]; }
+#pragma unroll
+        for (int k = 0; k < kIC; ++k) { const int e = min(tid + k * kT, NC::gsize - 1); vc[k] = d.critic[e]; vtc[k] = d.target_critic[e]; }
+#pragma unroll
+        for (int k = 0; k < kIA; ++k) {
+            const int e = tid + k * kT;
+            if (e < NA::gsize) { const int l = NA::to_lds(e); th_a[l] = va[k]; th_ta[l] = vta[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < kIC; ++k) {
+            const int e = tid + k * kT;
+            if (e < NC::gsize) { const int l = NC::to_lds(e); th_c[l] = vc[k]; th_tc[l] = vtc[k]; }
+        }
+    }
 
     // ---- owners of the Adam moments ------------------------------------------------------------------------------
     // wide tiles (W2 rows 0..63 of both nets): wave -> (ib = wave >> 1, jb = wave & 1), lane -> 4 elements
@@ -324,7 +346,7 @@ __global__ __launch_bounds__(kT) void ddpg_train_fixed_kernel(FixedArgs g) {
         else return (int64_t)g.batch_idx[(int64_t)(it_ < g.n_iters ? it_ : g.n_iters - 1) * kB + tid];
     };
     if (tid < kB) {
-        fetch_rows(idx_of(0));
+        fetch_rows(rec0);
         if constexpr (!TILED) rec_next = idx_of(1);
     }
     __syncthreads();   // parameter images complete
