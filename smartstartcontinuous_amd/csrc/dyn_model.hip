@@ -295,14 +295,15 @@ __global__ __launch_bounds__(256) void dyn_small_sim_pair_kernel(SmallSimArgs g)
     uint32_t p0 = q0, p1 = q1;
     if (g.live_list != nullptr) { p0 = (uint32_t)g.live_list[q0]; p1 = (uint32_t)g.live_list[q1]; }
     const uint32_t r0 = SAMPLE ? p0 * N + n0 : n0, r1 = SAMPLE ? p1 * N + n1 : n1;
-    bool on0 = true, on1 = two;
-    if (SAMPLE && g.active != nullptr) { on0 = g.active[p0] != 0; on1 = on1 && g.active[p1] != 0; }
-    if (!on0 && !on1) return;
+    // (the start states are requested with the mask bytes -- both need nothing but the problem index -- not behind them)
     const uint32_t rps = (uint32_t)g.rows_per_state;
     const uint32_t i0 = (SAMPLE && rps == N) ? p0 : r0 / rps, i1 = (SAMPLE && rps == N) ? p1 : r1 / rps;
     f2 st[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) st[k] = f2{g.s0[i0 * D + k], g.s0[i1 * D + k]};
+    bool on0 = true, on1 = two;
+    if (SAMPLE && g.active != nullptr) { on0 = g.active[p0] != 0; on1 = on1 && g.active[p1] != 0; }
+    if (!on0 && !on1) return;
     // candidate actions: Philox words of (problem, sample), four (t, action) slots per call (ssc_mpc_sample_actions)
     const uint32_t c1_0 = (uint32_t)(g.pid0 + p0), c1_1 = (uint32_t)(g.pid0 + p1);
     const uint64_t tt = SAMPLE ? (g.t + (g.t_base != nullptr ? *g.t_base : 0)) * (uint64_t)((g.H + 3) / 4) : 0;

@@ -175,14 +175,15 @@ constexpr int kWinMax = kMaxH1 + 3;                   // waypoints in a window
 constexpr int kWinFloats = kWinMax * (SSC_MAX_STATE + 1) + SSC_MAX_STATE;   // wps | lefts | inv_r
 
 // lanes `lane` of `nl` cooperating lanes stage problem p's window; the caller synchronises them afterwards
-__device__ __forceinline__ void load_window(const MpcArgs &a, int p, int lane, int nl, float *win, int &W, int &idx0) {
-    const int q = plan_index(a, p);     // == p unless the problems share a plan pool
+// (q = plan_index(a, p) and cur = a.cur_idx[p] come in as values: a caller that needs other per-problem data too can request
+// them all in one round trip)
+__device__ __forceinline__ void load_window_at(const MpcArgs &a, int q, int cur, int lane, int nl, float *win, int &W, int &idx0) {
     const int off = a.wp_off[q];
     const int Wabs = plan_len(a, q);
     // (clamped: a plan slot re-published under an env that still follows it -- a pool too small for the refresh cadence --
     // may be shorter than the env's waypoint index; the env then heads for the new plan's last waypoint instead of reading
     // outside the window)
-    const int iabs = min(a.cur_idx[p], max(Wabs - 1, 0));
+    const int iabs = min(cur, max(Wabs - 1, 0));
     const int wb = max(iabs - 1, 0);
     const int cnt = max(min(Wabs - wb, a.H + 4), 0);
     float *wps = win, *lefts = win + kWinMax * a.d, *inv_r = lefts + kWinMax;
@@ -192,6 +193,9 @@ __device__ __forceinline__ void load_window(const MpcArgs &a, int p, int lane, i
     if (lane < a.d) inv_r[lane] = 1.0f / a.radii[q * a.d + lane];
     W = Wabs - wb;
     idx0 = iabs - wb;
+}
+__device__ __forceinline__ void load_window(const MpcArgs &a, int p, int lane, int nl, float *win, int &W, int &idx0) {
+    load_window_at(a, plan_index(a, p), a.cur_idx[p], lane, nl, win, W, idx0);   // plan_index == p unless the problems share a plan pool
 }
 
 // The same staging in two phases for a whole block (nl = kMpcBlock >= 36 * 8 / 2): `issue` computes the window and puts its
@@ -482,6 +486,8 @@ __device__ __forceinline__ void mpc_small_body(MpcArgs a, const SelectArgs &sel,
     const bool has = pq < n_serve;
     const int ps = has ? pq : n_serve - 1;       // a group past the last problem shadows it and writes nothing
     const int p = a.live_list != nullptr ? a.live_list[ps] : ps;
+    // the mask byte, the plan index and the waypoint index need nothing but p: one round trip for the three
+    const int q_pre = plan_index(a, p), cur_pre = a.cur_idx[p];
     // a problem masked out by a.active (an env that is not navigating) costs its group three barriers and nothing else
     const bool scored = a.active == nullptr || a.active[p] != 0;    // group-uniform
     const bool live = has && n < a.N && scored;
@@ -489,7 +495,7 @@ __device__ __forceinline__ void mpc_small_body(MpcArgs a, const SelectArgs &sel,
     PrePts pp;
     if (scored && mpc_can_prefetch(a)) mpc_fetch_pts(a, S, row, M, live, pp);
     int W = 2, idx0 = 0;
-    if (scored) load_window(a, p, n, G, win[g], W, idx0);
+    if (scored) load_window_at(a, q_pre, cur_pre, n, G, win[g], W, idx0);
     __syncthreads();
     const float *wps = win[g], *lefts = win[g] + kWinMax * a.d, *inv_r = lefts + kWinMax;
     if (scored) mpc_walk_any<0, G>(a, pp, S, row, M, wps, lefts, W, idx0, inv_r, live, sums[g], nullptr);
