@@ -265,23 +265,38 @@ __global__ __launch_bounds__(kFT) void mlp_train_fused_kernel(FusedTrainArgs g) 
     const int hp = g.hd_pad + 1;
 
     // this thread's unit: column u of W1, b1[u], row u of W2 (registers)
-    float w1[IN], w2[OUT], bb1 = unit_ok ? g.b1[u] : 0.0f;
+    // (every load unconditional -- index clamped into the array, value dropped by a select: a guarded load compiles to a
+    // branch with a full wait behind it, and this prologue was seven round trips in a row; the batch's record numbers go
+    // out first, their rows are the only dependent request)
+    const bool live = t < nrows;
+    const int64_t src = g.idx[row0 + (live ? t : 0)];          // (threads >= kFRows read a valid entry too and drop it)
+    const int uc = min(u, g.hd - 1);
+    float w1[IN], w2[OUT];
+    const float xb1 = g.b1[uc];
 #pragma unroll
-    for (int i = 0; i < IN; ++i) w1[i] = (unit_ok && i < g.in) ? g.W1[i * g.hd + u] : 0.0f;
+    for (int i = 0; i < IN; ++i) w1[i] = g.W1[min(i, g.in - 1) * g.hd + uc];
 #pragma unroll
-    for (int o = 0; o < OUT; ++o) w2[o] = (unit_ok && o < g.out) ? g.W2[u * g.out + o] : 0.0f;
+    for (int o = 0; o < OUT; ++o) w2[o] = g.W2[uc * g.out + min(o, g.out - 1)];
+    float xr[IN], zr[OUT];
+#pragma unroll
+    for (int i = 0; i < IN; ++i) xr[i] = g.X[src * g.in + min(i, g.in - 1)];
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) zr[o] = g.Z[src * g.out + min(o, g.out - 1)];
+    const float bb1 = unit_ok ? xb1 : 0.0f;
+#pragma unroll
+    for (int i = 0; i < IN; ++i) w1[i] = (unit_ok && i < g.in) ? w1[i] : 0.0f;
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) w2[o] = (unit_ok && o < g.out) ? w2[o] : 0.0f;
     if (s == 0) {
 #pragma unroll
         for (int o = 0; o < OUT; ++o) w2_s[u * OUT + o] = w2[o];
     }
     // batch rows of this block (train_gather_kernel's job)
     if (t < kFRows) {
-        const bool live = t < nrows;
-        const int64_t src = live ? g.idx[row0 + t] : 0;
 #pragma unroll
-        for (int i = 0; i < IN; ++i) x_s[t * IN + i] = (live && i < g.in) ? g.X[src * g.in + i] : 0.0f;
+        for (int i = 0; i < IN; ++i) x_s[t * IN + i] = (live && i < g.in) ? xr[i] : 0.0f;
 #pragma unroll
-        for (int o = 0; o < OUT; ++o) z_s[t * OUT + o] = (live && o < g.out) ? g.Z[src * g.out + o] : 0.0f;
+        for (int o = 0; o < OUT; ++o) z_s[t * OUT + o] = (live && o < g.out) ? zr[o] : 0.0f;
     }
     __syncthreads();
 
