@@ -24,51 +24,79 @@ struct ReplayAppendArgs {
     float reward_scale;
 };
 
+// One record's reads, all requested before the first store of it (the ring and the log may alias as far as the compiler knows:
+// written load -> store -> load -> store, every column was a round trip of its own).  OD = 0: any obs_dim, guarded.
+template <int OD>
+struct AppendRow {
+    float s[OD > 0 ? OD : SSC_MAX_OBS], s2[OD > 0 ? OD : SSC_MAX_OBS], a, r;
+    uint8_t t;
+    __device__ __forceinline__ void load(const ReplayAppendArgs &g, int64_t src, int64_t done_src) {
+        const int od = OD > 0 ? OD : g.ring.obs_dim;
+#pragma unroll
+        for (int c = 0; c < (OD > 0 ? OD : SSC_MAX_OBS); ++c) {
+            const int cc = c < od ? c : od - 1;      // (clamped column: no guard around the load)
+            s[c] = g.log.obs[cc][src];
+            s2[c] = g.log.obs2[cc][src];
+        }
+        a = g.log.act[src];
+        r = g.log.rew[src];
+        t = g.log.done[done_src];
+    }
+    __device__ __forceinline__ void store(const ReplayAppendArgs &g, int64_t pos) const {
+        const int od = OD > 0 ? OD : g.ring.obs_dim;
+#pragma unroll
+        for (int c = 0; c < (OD > 0 ? OD : SSC_MAX_OBS); ++c)
+            if (c < od) {
+                g.ring.s[pos * od + c] = s[c];
+                g.ring.s2[pos * od + c] = s2[c];
+            }
+        g.ring.a[pos] = a;
+        g.ring.r[pos] = r * g.reward_scale;   // DDPG_Baselines_agent.observe scales the reward (:238-240)
+        g.ring.t[pos] = t;
+    }
+};
+
+template <int OD>
 __global__ __launch_bounds__(kBlock) void replay_append_kernel(ReplayAppendArgs g) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= g.count) return;
     const int64_t j = g.first + i;           // record number inside the chunk: step-major, then env
     const int64_t k = j / g.n, e = j - k * g.n;
     const int64_t pos = (g.start + k * g.n_total + g.env_off + e) % g.ring.capacity;
-    const int64_t src = k * g.row_stride + e;
-    const int od = g.ring.obs_dim;
-#pragma unroll
-    for (int c = 0; c < SSC_MAX_OBS; ++c)
-        if (c < od) {
-            g.ring.s[pos * od + c] = g.log.obs[c][src];
-            g.ring.s2[pos * od + c] = g.log.obs2[c][src];
-        }
-    g.ring.a[pos] = g.log.act[src];
-    g.ring.r[pos] = g.log.rew[src] * g.reward_scale;   // DDPG_Baselines_agent.observe scales the reward (:238-240)
-    g.ring.t[pos] = g.log.done[k * g.done_row_stride + e];
+    AppendRow<OD> row;
+    row.load(g, k * g.row_stride + e, k * g.done_row_stride + e);
+    row.store(g, pos);
 }
 
 // The same append with the episode index (ssc_replay_ring::ep_steps / ep_run): one thread per env walks its column
-// of the chunk in step order (coalesced across envs on both sides), counting the steps of its running episode.
+// of the chunk in step order (coalesced across envs on both sides), counting the steps of its running episode -- four
+// steps' reads in flight at a time.
+template <int OD>
 __global__ __launch_bounds__(kBlock) void replay_append_indexed_kernel(ReplayAppendArgs g, int32_t K) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= g.n) return;
-    const int od = g.ring.obs_dim;
     int32_t run = g.ring.ep_run[g.env_off + e];
-    for (int32_t k = 0; k < K; ++k) {
-        const int64_t src = (int64_t)k * g.row_stride + e;
-        const uint8_t t = g.log.done[(int64_t)k * g.done_row_stride + e];
-        run += 1;
-        const int64_t j = (int64_t)k * g.n + e;
-        if (j >= g.first) {
-            const int64_t pos = (g.start + (int64_t)k * g.n_total + g.env_off + e) % g.ring.capacity;
+    constexpr int kU = 4;
+    for (int32_t k0 = 0; k0 < K; k0 += kU) {
+        AppendRow<OD> rows[kU];
 #pragma unroll
-            for (int c = 0; c < SSC_MAX_OBS; ++c)
-                if (c < od) {
-                    g.ring.s[pos * od + c] = g.log.obs[c][src];
-                    g.ring.s2[pos * od + c] = g.log.obs2[c][src];
-                }
-            g.ring.a[pos] = g.log.act[src];
-            g.ring.r[pos] = g.log.rew[src] * g.reward_scale;
-            g.ring.t[pos] = t;
-            g.ring.ep_steps[pos] = run;
+        for (int u = 0; u < kU; ++u) {
+            const int32_t k = min(k0 + u, K - 1);      // (a step past the chunk re-reads the last one and is dropped below)
+            rows[u].load(g, (int64_t)k * g.row_stride + e, (int64_t)k * g.done_row_stride + e);
         }
-        if (t) run = 0;  // rlTrain breaks on done and the next step opens a new episode (rlTrain.py:97, replay_buffer.py:109-115)
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int32_t k = k0 + u;
+            if (k >= K) break;
+            run += 1;
+            const int64_t j = (int64_t)k * g.n + e;
+            if (j >= g.first) {
+                const int64_t pos = (g.start + (int64_t)k * g.n_total + g.env_off + e) % g.ring.capacity;
+                rows[u].store(g, pos);
+                g.ring.ep_steps[pos] = run;
+            }
+            if (rows[u].t) run = 0;  // rlTrain breaks on done and the next step opens a new episode (rlTrain.py:97, replay_buffer.py:109-115)
+        }
     }
     g.ring.ep_run[g.env_off + e] = run;
 }
@@ -347,10 +375,14 @@ static int replay_append_impl(const char *fn, const ssc_replay_ring *ring, const
     if (ring->ep_steps != nullptr) {
         SSC_REQUIRE(start % n_total == 0, "%s: an indexed ring takes whole steps of n = %lld envs (start = %lld)", fn,
                     (long long)n_total, (long long)start);
-        hipLaunchKernelGGL(replay_append_indexed_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream), g, K);
+        if (ring->obs_dim == 2) hipLaunchKernelGGL(replay_append_indexed_kernel<2>, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream), g, K);
+        else if (ring->obs_dim == 3) hipLaunchKernelGGL(replay_append_indexed_kernel<3>, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream), g, K);
+        else hipLaunchKernelGGL(replay_append_indexed_kernel<0>, dim3(blocks_for(n)), dim3(kBlock), 0, as_stream(stream), g, K);
         return check_launch(fn);
     }
-    hipLaunchKernelGGL(replay_append_kernel, dim3(blocks_for(g.count)), dim3(kBlock), 0, as_stream(stream), g);
+    if (ring->obs_dim == 2) hipLaunchKernelGGL(replay_append_kernel<2>, dim3(blocks_for(g.count)), dim3(kBlock), 0, as_stream(stream), g);
+    else if (ring->obs_dim == 3) hipLaunchKernelGGL(replay_append_kernel<3>, dim3(blocks_for(g.count)), dim3(kBlock), 0, as_stream(stream), g);
+    else hipLaunchKernelGGL(replay_append_kernel<0>, dim3(blocks_for(g.count)), dim3(kBlock), 0, as_stream(stream), g);
     return check_launch(fn);
 }
 
