@@ -188,9 +188,17 @@ __device__ __forceinline__ void load_window_at(const MpcArgs &a, int q, int cur,
     const int cnt = max(min(Wabs - wb, a.H + 4), 0);
     float *wps = win, *lefts = win + kWinMax * a.d, *inv_r = lefts + kWinMax;
     const float *wsrc = a.wp + (int64_t)(off + wb) * a.d;
-    for (int e = lane; e < cnt * a.d; e += nl) wps[e] = wsrc[e];
-    for (int e = lane; e < cnt; e += nl) lefts[e] = a.left[off + wb + e];
-    if (lane < a.d) inv_r[lane] = 1.0f / a.radii[q * a.d + lane];
+    if (cnt * a.d <= nl) {   // one element of each array per lane: the three loads together (clamped index), then the stores
+        const float wv = wsrc[max(min(lane, cnt * a.d - 1), 0)], lv = a.left[off + wb + max(min(lane, cnt - 1), 0)];
+        const float rv = a.radii[q * a.d + min(lane, a.d - 1)];
+        if (lane < cnt * a.d) wps[lane] = wv;
+        if (lane < cnt) lefts[lane] = lv;
+        if (lane < a.d) inv_r[lane] = 1.0f / rv;
+    } else {
+        for (int e = lane; e < cnt * a.d; e += nl) wps[e] = wsrc[e];
+        for (int e = lane; e < cnt; e += nl) lefts[e] = a.left[off + wb + e];
+        if (lane < a.d) inv_r[lane] = 1.0f / a.radii[q * a.d + lane];
+    }
     W = Wabs - wb;
     idx0 = iabs - wb;
 }
